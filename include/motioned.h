@@ -1,0 +1,207 @@
+/*
+ * motioned.h -- C ABI of libmotioned.so, the MI355X (gfx950) kernel library behind the
+ * MotionEditor two-branch DDIM denoising step.
+ *
+ * The reference (Francis-Rings/MotionEditor) has NO FFI: its seams are Python call signatures and
+ * every arithmetic op is a torch / xformers / cuDNN call (SURVEY.md layer L1).  Each entry point
+ * below replaces one family of those L1 calls; the reference call sites it stands in for are cited
+ * per function (paths relative to the reference repo root).  The Python mirror of the reference
+ * interface (motioneditor_amd.pipelines / .attn_control / .models) binds these through ctypes --
+ * see INTEGRATION.md for the stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C types only; all tensors are raw DEVICE pointers owned by the caller
+ *   - activations are fp16 ("u16" storage), token-major / channels-last: row = (batch*frame, pixel),
+ *     columns = channels, with an explicit row stride (ld*) in ELEMENTS; 16-byte aligned rows
+ *   - weights are fp16, [N_out][taps][C_in] (C_in contiguous) -- torch Linear layout, conv kernels
+ *     repacked tap-major by the host packer
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); no hidden sync
+ *   - return 0 on success, negative ME_E* code on failure; me_last_error() gives the message
+ *   - not thread-safe per stream; one process per GPU
+ */
+#ifndef MOTIONED_H
+#define MOTIONED_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_OK 0
+#define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
+#define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
+
+#define ME_ABI_VERSION 1
+
+/* ---- library ------------------------------------------------------------------------------ */
+int me_abi_version(void);
+const char* me_last_error(void);
+/* number of CUs / XCD-count etc. of the current device; returns ME_EHIP if no gfx950 device */
+int me_device_info(int* cus, int* lds_bytes, char* arch, int arch_len);
+
+/* ---- gather-GEMM (implicit convolution) ---------------------------------------------------- *
+ * C[m, n] = epilogue( sum_{tap, c} X[src(m, tap), c] * W[n, tap, c] )
+ * Replaces: nn.Linear (attention_2d.py:83-92, temporal_attn.py:63-72, controlnet_adapter.py:55-64),
+ * InflatedConv3d 3x3 / 1x1 / stride-2 / after nearest-2x (resnet_2d.py:28-36, 39-125),
+ * TemporalConv (resnet_2d.py:10-26, controlnet_adapter.py:411-434), GEGLU FeedForward
+ * (diffusers FeedForward, used attention_2d.py:427,531), Transformer2DModel proj_in/out
+ * (attention_2d.py:307,336), time_emb_proj (resnet_2d.py:172,211).
+ */
+#define ME_GATHER_DENSE 0  /* taps = 1, src(m) = m                                                  */
+#define ME_GATHER_CONV3 1  /* taps = 9, 3x3 pad 1 over [img][Hin][Win] pixels; stride 1|2; ups 0|1 */
+#define ME_GATHER_TCONV 2  /* taps = 3, k=3 pad 1 over frames inside chunks of `chunk` frames       */
+
+typedef struct me_gemm_args {
+  const void* X;      /* fp16 [rows_in, ldx]                                   */
+  const void* W;      /* fp16 [N, taps, K]                                     */
+  void* C;            /* fp16 [M, ldc]                                         */
+  int32_t M, N, K;    /* K = input channels per tap (multiple of 8)            */
+  int32_t ldx, ldc;   /* row strides in elements (multiples of 8 / 4)          */
+  int32_t gather;     /* ME_GATHER_*                                           */
+  /* CONV3: M = n_img * Hout * Wout */
+  int32_t Hin, Win, Hout, Wout, stride, ups;
+  /* TCONV: row m = ((b * frames + fr) * npix + p) */
+  int32_t frames, npix, chunk;
+  /* epilogue (all optional, applied in this order) */
+  const void* bias;   /* fp16 [N]                                              */
+  const void* rowvec; /* fp16: += rowvec[(m / rows_per_vec) * ldrv + n]        */
+  int32_t ldrv, rows_per_vec;
+  const void* res;    /* fp16 [M, ldr]: += res[m, n]                           */
+  int32_t ldr;
+  int32_t geglu;      /* 1: W rows interleaved (16 a-rows, 16 gate-rows); C gets N/2 columns a*gelu(g) */
+  float alpha;        /* scale applied to the accumulator before the epilogue adds */
+} me_gemm_args;
+
+int me_gemm(const me_gemm_args* a, void* stream);
+
+/* ---- direct convolution for tiny channel counts (C_in < 8) --------------------------------- *
+ * conv_in of the UNet / ControlNet on fp32 latents in the REFERENCE layout, and the first conv of
+ * controlnet_cond_embedding.  Replaces InflatedConv3d conv_in (unet_2d_condition.py:160,451).
+ * in : fp32, element (img, c, y, x) at  in[img*img_stride + c*ch_stride + y*Win + x]
+ * out: fp16 channels-last [n_img*H*W, Cout]; W fp16 [Cout][9][Cin]; 3x3 pad 1 stride 1.
+ */
+typedef struct me_conv_small_args {
+  const void* in;
+  const void* W;
+  const void* bias;
+  void* out;
+  int32_t n_img, Cin, Cout, H, Wd;
+  int64_t img_stride, ch_stride;
+  int32_t in_is_f16; /* 0: fp32 input, 1: fp16 input */
+  int32_t silu;      /* apply SiLU to the output */
+  int32_t frames;    /* >0: img = b*frames + f and in offset = b*img_stride + f*frame_stride (5-D latents) */
+  int64_t frame_stride;
+} me_conv_small_args;
+
+int me_conv_small(const me_conv_small_args* a, void* stream);
+
+/* ---- fused attention ------------------------------------------------------------------------ *
+ * O[item, q, h, :] = softmax_over_all_segments( Q.K^T * scale ) . V, never materialising scores
+ * or gathered keys.  Replaces xformers.ops.memory_efficient_attention and baddbmm/softmax/bmm
+ * (attention_2d.py:172-201,246-253, fully_control_utils.py:48-66,191-203, controlnet_adapter.py:144-225)
+ * AND the spatial editor's masked 5N-key attention (fully_control.py:372-460) via seg modes.
+ */
+#define ME_SEG_PLAIN 0     /* weight exp(s)                                                            */
+#define ME_SEG_DUAL_CUR 1  /* weight exp(m*s) + exp((1-m)*s), m = mask[head][key]                      */
+#define ME_SEG_DUAL_PREV 2 /* same with m = mask[max(head-1,0)][key]                                   */
+
+typedef struct me_attn_args {
+  const void* Q;  /* fp16 rows (item*nq + q), cols head*dh + d */
+  const void* K;  /* fp16 rows (kv_item*nk + key)               */
+  const void* V;
+  void* O;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t heads, dh; /* dh in {40, 80, 160} */
+  int32_t n_items, nq, nk, nseg; /* nseg in 1..3 */
+  const int32_t* seg_item; /* device int32 [n_items][nseg]: kv item index of each segment */
+  const int32_t* seg_mode; /* device int32 [n_items][nseg]: ME_SEG_*                       */
+  const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL modes)              */
+  float scale;
+} me_attn_args;
+
+int me_attn(const me_attn_args* a, void* stream);
+
+/* ---- temporal (per-pixel, over frames) causal attention ------------------------------------- *
+ * rows (b*frames + fr)*npix + p.  For batch b, K/V are read from batch kv_map[b] (the temporal
+ * editor's recon->edit replacement, temporal_control.py:70-88).  Causal: key frame <= query frame
+ * (the reference adds -10000 above the diagonal, attention_2d.py:542-543; identical in fp32).
+ * Replaces TemporalSelfAttention._attention (temporal_attn.py:152-181) and the patched closure
+ * (temporal_control_utils.py:81-123).
+ */
+typedef struct me_tattn_args {
+  const void* Q;
+  const void* K;
+  const void* V;
+  void* O;
+  int32_t ldq, ldk, ldv, ldo;
+  int32_t heads, dh;
+  int32_t batch, frames, npix; /* frames in {8,16,24,32,40,48} */
+  int32_t kv_map[8];           /* batch <= 8 */
+  float scale;
+} me_tattn_args;
+
+int me_tattn(const me_tattn_args* a, void* stream);
+
+/* ---- GroupNorm (channels-last) -------------------------------------------------------------- *
+ * Statistics over rows_per_group rows x (C/32) channels.  rows_per_group = frames*npix reproduces
+ * the reference's 5-D GroupNorm whose statistics span ALL frames (resnet_2d.py:202,230);
+ * rows_per_group = npix is the per-frame GroupNorm of Transformer2DModel (attention_2d.py:303,348).
+ */
+typedef struct me_groupnorm_args {
+  const void* X;   /* fp16 [rows, ldx]                                        */
+  void* Y;         /* fp16 [rows, ldy]                                        */
+  const void* gamma;
+  const void* beta;
+  float* stats;    /* device scratch fp32 [n_groups_of_rows][32][2], zeroed by the call */
+  int32_t rows, rows_per_group;
+  int32_t C, ldx, ldy;
+  int32_t groups;  /* 32 */
+  float eps;
+  int32_t silu;
+} me_groupnorm_args;
+
+int me_groupnorm(const me_groupnorm_args* a, void* stream);
+
+/* ---- LayerNorm over the channel axis (nn.LayerNorm, eps 1e-5; attention_2d.py:443-463) ------ */
+typedef struct me_layernorm_args {
+  const void* X;
+  void* Y;
+  const void* gamma;
+  const void* beta;
+  int32_t rows, C, ldx, ldy;
+  float eps;
+} me_layernorm_args;
+
+int me_layernorm(const me_layernorm_args* a, void* stream);
+
+/* ---- small element-wise helpers -------------------------------------------------------------- */
+/* Y[r, c] = X[r, c] + alpha * A[r, c]  on fp16 views (ControlNet/adapter residual adds,
+ * unet_2d_condition.py:487-494,508-509) */
+int me_axpy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, const void* A, int32_t lda,
+                 int64_t rows, int32_t cols, float alpha, void* stream);
+/* copy a [rows, cols] fp16 view (skip concat, unet_2d_blocks.py "torch.cat([hidden, res], dim=1)") */
+int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream);
+/* y = silu(x), n fp16 elements */
+int me_silu(void* Y, const void* X, int64_t n, void* stream);
+/* y = relu(x), n fp16 elements (adapter ResnetBlock.act, controlnet_adapter.py:452,504) */
+int me_relu(void* Y, const void* X, int64_t n, void* stream);
+/* sinusoidal timestep embedding, diffusers get_timestep_embedding(flip_sin_to_cos=True, shift=0):
+ * out fp16 [rows, dim] all rows equal (unet_2d_condition.py:430-432) */
+int me_timestep_embed(void* out, int32_t rows, int32_t dim, float t, void* stream);
+/* Classifier-free guidance + DDIM update (pipeline_motion_editor.py:643-648; util.py:77-87):
+ * eps channels-last fp16 rows ((b*frames+f)*npix+p) with b in [0, 2*nb): [uncond x nb, cond x nb];
+ * latents fp32 in the reference layout [nb, C, frames, npix];  out = ca*x + cb*(eu + g*(ec-eu)). */
+int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C,
+                int32_t frames, int32_t npix, float guidance, float ca, float cb, void* stream);
+/* fp32 [n_img, C, H*W] (img/channel strides in elements) -> fp16 channels-last [n_img*H*W, ldy] */
+int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride,
+                    int32_t n_img, int32_t C, int32_t npix, void* stream);
+/* fp16 channels-last [n_img*npix, ldx] -> fp32 [n_img, C, npix] */
+int me_rows_to_nchw(float* Y, int64_t img_stride, int64_t ch_stride, const void* X, int32_t ldx,
+                    int32_t n_img, int32_t C, int32_t npix, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOTIONED_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of ``libmotioned.so`` (``include/motioned.h``).
+
+The library is the ONLY compute path of this package: there is no PyTorch / CPU fallback.  Loading
+fails loudly when the shared object is missing (build it with ``python -m motioneditor_amd.build``
+or ``__graft_entry__.build()``); compute calls fail loudly on a non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
+
+ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
+GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
+SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV = 0, 1, 2
+
+_i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("X", _vp), ("W", _vp), ("C", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("ldx", _i32), ("ldc", _i32), ("gather", _i32),
+        ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
+        ("frames", _i32), ("npix", _i32), ("chunk", _i32),
+        ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
+        ("res", _vp), ("ldr", _i32), ("geglu", _i32), ("alpha", _f32),
+    ]
+
+
+class ConvSmallArgs(C.Structure):
+    _fields_ = [
+        ("inp", _vp), ("W", _vp), ("bias", _vp), ("out", _vp),
+        ("n_img", _i32), ("Cin", _i32), ("Cout", _i32), ("H", _i32), ("Wd", _i32),
+        ("img_stride", _i64), ("ch_stride", _i64),
+        ("in_is_f16", _i32), ("silu", _i32), ("frames", _i32), ("frame_stride", _i64),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", _vp), ("K", _vp), ("V", _vp), ("O", _vp),
+        ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32),
+        ("heads", _i32), ("dh", _i32),
+        ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
+        ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32),
+    ]
+
+
+class TAttnArgs(C.Structure):
+    _fields_ = [
+        ("Q", _vp), ("K", _vp), ("V", _vp), ("O", _vp),
+        ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32),
+        ("heads", _i32), ("dh", _i32),
+        ("batch", _i32), ("frames", _i32), ("npix", _i32),
+        ("kv_map", _i32 * 8), ("scale", _f32),
+    ]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [
+        ("X", _vp), ("Y", _vp), ("gamma", _vp), ("beta", _vp), ("stats", _vp),
+        ("rows", _i32), ("rows_per_group", _i32),
+        ("C", _i32), ("ldx", _i32), ("ldy", _i32), ("groups", _i32), ("eps", _f32), ("silu", _i32),
+    ]
+
+
+class LayerNormArgs(C.Structure):
+    _fields_ = [
+        ("X", _vp), ("Y", _vp), ("gamma", _vp), ("beta", _vp),
+        ("rows", _i32), ("C", _i32), ("ldx", _i32), ("ldy", _i32), ("eps", _f32),
+    ]
+
+
+# every symbol include/motioned.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "me_abi_version": (C.c_int, []),
+    "me_last_error": (C.c_char_p, []),
+    "me_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "me_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "me_conv_small": (C.c_int, [C.POINTER(ConvSmallArgs), _vp]),
+    "me_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
+    "me_tattn": (C.c_int, [C.POINTER(TAttnArgs), _vp]),
+    "me_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "me_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), _vp]),
+    "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
+    "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
+    "me_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "me_relu": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "me_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f32, _vp]),
+    "me_cfg_ddim": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "me_nchw_to_rows": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "me_rows_to_nchw": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class MotionedError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load libmotioned.so once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise MotionedError(
+                f"{LIB_PATH} is missing: the HIP library is the only compute path of motioneditor_amd "
+                "(no CPU / PyTorch fallback). Build it with `python -m motioneditor_amd.build`.")
+        L = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if L.me_abi_version() != 1:
+            raise MotionedError(f"libmotioned ABI {L.me_abi_version()} != 1")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != ME_OK:
+        msg = lib().me_last_error().decode(errors="replace")
+        if rc == ME_EINVAL:
+            raise ValueError(f"libmotioned {what}: {msg}")
+        raise MotionedError(f"libmotioned {what}: {msg} (rc={rc})")

@@ -1,0 +1,298 @@
+// Fused multi-segment attention on MFMA (gfx950): O = softmax(Q K^T * scale) V with online softmax,
+// scores and gathered keys never materialised.
+//
+// A query item (one frame of one batch row) attends `nseg` key segments, each a whole kv item
+// (nk keys) named by seg_item[item][seg]:
+//   attn1 un-edited  : [prev frame | cur frame]                         (attention_2d.py:732-740)
+//   attn1 edited     : [src prev (dual-mask) | src cur (dual-mask) | edit cur]  (fully_control.py:372-447)
+//   attn2 / ControlNet / adapter attn_pose : one segment
+//   adapter sparse-causal : [first frame of chunk | prev frame]         (controlnet_adapter.py:352-361)
+// DUAL segments implement the reference's "K*M | K*(1-M)" key duplication without duplicating
+// anything: a masked key has logit m*s in the foreground copy and (1-m)*s in the background copy
+// and BOTH copies carry the same (unmasked) V, so the key's total weight is exp(m s) + exp((1-m) s).
+//
+// Structure (per block: one (item, head), BQ = 64*QT queries, 4 waves x QT x 16 queries):
+//   S^T = K Q^T   : MFMA A = K tile rows from LDS, B = Q fragments held in registers
+//                   -> lane (q = lane&15, g = lane>>4) holds keys t*16 + g*4 + r: row max / sum need
+//                      only 2 xor-shuffles across g; alpha and 1/l are lane-local for O^T.
+//   O^T += V^T P^T: MFMA A = V^T fragments (V is transposed into LDS while staging),
+//                   B = P^T straight from the S^T accumulator registers (fp16), no LDS round trip:
+//                   MFMA k-slot (g, j) carries key kk*32 + (j>>2)*16 + g*4 + (j&3) for BOTH operands.
+#include "me_common.h"
+#include "../../include/motioned.h"
+
+namespace {
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr int KT = 64;        // keys per tile
+constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: conflict-free ds_read_b64)
+
+template <int DH, int QT>
+__global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
+  constexpr int CH = DH / 8;
+  constexpr int D32 = (DH + 31) / 32;
+  constexpr int DT = (DH + 15) / 16;
+  constexpr int KLD = D32 * 32 + 8;
+  constexpr int BQ = 64 * QT;
+  constexpr int NLD = (KT * CH + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) f16 sK[KT * KLD];
+  __shared__ __attribute__((aligned(16))) f16 sVt[DT * 16 * VLD];
+  __shared__ __attribute__((aligned(16))) f16 sM[KT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int g = lane >> 4;
+  const int l15 = lane & 15;
+
+  const int nqb = (a.nq + BQ - 1) / BQ;
+  const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
+  const int qb = w % nqb;
+  const int rest = w / nqb;
+  const int h = rest % a.heads;
+  const int item = rest / a.heads;
+
+  const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
+  const f16* __restrict__ K = reinterpret_cast<const f16*>(a.K);
+  const f16* __restrict__ V = reinterpret_cast<const f16*>(a.V);
+  const f16* __restrict__ Mk = reinterpret_cast<const f16*>(a.mask);
+  f16* __restrict__ O = reinterpret_cast<f16*>(a.O);
+
+  // zero the LDS padding that staging never writes (K columns >= DH, V^T rows >= DH)
+  for (int i = tid; i < KT * KLD; i += 256) sK[i] = (f16)0.f;
+  for (int i = tid; i < DT * 16 * VLD; i += 256) sVt[i] = (f16)0.f;
+
+  // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
+  f16x8 fq[QT][D32];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
+    qrow[qt] = q < a.nq ? item * a.nq + q : -1;
+#pragma unroll
+    for (int ks = 0; ks < D32; ++ks) {
+      const int d = ks * 32 + g * 8;
+      U128 u;
+      u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
+      fq[qt][ks] = u.h;
+    }
+  }
+
+  const int ntk = (a.nk + KT - 1) / KT;
+  const int T = a.nseg * ntk;
+  const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
+
+  uint4 rk[NLD], rv[NLD];
+  auto gload = [&](int ti) {
+    const int seg = ti / ntk, kt = ti - seg * ntk;
+    const int kit = a.seg_item[item * a.nseg + seg];
+    const int key0 = kt * KT;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      const int key = idx / CH, cc = idx - key * CH;
+      const bool ok = idx < KT * CH && key0 + key < a.nk;
+      const long row = (long)kit * a.nk + key0 + key;
+      rk[i] = ok ? ldg128(K + row * a.ldk + h * DH + cc * 8) : zero128();
+      rv[i] = ok ? ldg128(V + row * a.ldv + h * DH + cc * 8) : zero128();
+    }
+  };
+  auto sstore = [&](int ti) {
+    const int seg = ti / ntk, kt = ti - seg * ntk;
+    const int mode = a.seg_mode[item * a.nseg + seg];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < KT * CH) {
+        const int key = idx / CH, cc = idx - key * CH;
+        *reinterpret_cast<uint4*>(sK + key * KLD + cc * 8) = rk[i];
+        U128 u;
+        u.u = rv[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sVt[(cc * 8 + e) * VLD + key] = u.e[e];
+      }
+    }
+    if (tid < KT) {
+      f16 mv = (f16)0.f;
+      const int key = kt * KT + tid;
+      if (mode != ME_SEG_PLAIN && key < a.nk) {
+        const int plane = mode == ME_SEG_DUAL_CUR ? h : (h > 0 ? h - 1 : 0);
+        mv = Mk[(long)plane * a.nk + key];
+      }
+      sM[tid] = mv;
+    }
+  };
+
+  f32x4 o[QT][DT];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = NEG_BIG;
+    lrun[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  gload(0);
+  for (int ti = 0; ti < T; ++ti) {
+    __syncthreads();
+    sstore(ti);
+    __syncthreads();
+    if (ti + 1 < T) gload(ti + 1);
+
+    const int seg = ti / ntk, kt = ti - seg * ntk;
+    const int mode = a.seg_mode[item * a.nseg + seg];
+    const int kbase = kt * KT + g * 4;  // + t*16 + r
+
+    // ---- S^T = K Q^T ----
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D32; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KLD + ks * 32 + g * 8);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
+      }
+    }
+
+    // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
+    f16x8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float x1[4][4], x2[4][4];
+      float mx = NEG_BIG;
+      if (mode == ME_SEG_PLAIN) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kbase + t * 16 + r < a.nk;
+            x1[t][r] = ok ? s[qt][t][r] * c : NEG_BIG;
+            mx = fmaxf(mx, x1[t][r]);
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          U64 mk;
+          mk.u = *reinterpret_cast<const uint2*>(sM + t * 16 + g * 4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool ok = kbase + t * 16 + r < a.nk;
+            const float sc = s[qt][t][r] * c;
+            const float fg = sc * (float)mk.e[r];
+            x1[t][r] = ok ? fg : NEG_BIG;
+            x2[t][r] = ok ? sc - fg : NEG_BIG;
+            mx = fmaxf(mx, fmaxf(x1[t][r], x2[t][r]));
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float psum = 0.f;
+      float p[4][4];
+      if (mode == ME_SEG_PLAIN) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[t][r] = __builtin_amdgcn_exp2f(x1[t][r] - mnew);
+            psum += p[t][r];
+          }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[t][r] = __builtin_amdgcn_exp2f(x1[t][r] - mnew) + __builtin_amdgcn_exp2f(x2[t][r] - mnew);
+            psum += p[t][r];
+          }
+      }
+      lrun[qt] = lrun[qt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f16x8 f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = (f16)p[2 * kk][r];
+          f[4 + r] = (f16)p[2 * kk + 1][r];
+        }
+        pf[qt][kk] = f;
+      }
+    }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const f16* vp = sVt + (dt * 16 + l15) * VLD + kk * 32 + g * 4;
+        U128 fv;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vp + 16);
+        fv.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.h, pf[qt][kk], o[qt][dt]);
+      }
+    }
+  }
+
+  // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] / l ----
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qrow[qt] < 0) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (d >= DH) continue;
+      U64 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov.e[r] = (f16)(o[qt][dt][r] * inv);
+      *reinterpret_cast<uint2*>(O + (long)qrow[qt] * a.ldo + h * DH + d) = ov.u;
+    }
+  }
+}
+
+template <int DH, int QT>
+int launch_attn(const me_attn_args* a, hipStream_t st) {
+  constexpr int BQ = 64 * QT;
+  const int nqb = (a->nq + BQ - 1) / BQ;
+  const long total = (long)a->n_items * a->heads * nqb;
+  hipLaunchKernelGGL((attn_kernel<DH, QT>), dim3((unsigned)total), dim3(256), 0, st, *a);
+  return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
+}
+
+}  // namespace
+
+extern "C" void me_set_error(const char* msg);
+
+extern "C" int me_attn(const me_attn_args* a, void* stream) {
+  if (!a || !a->Q || !a->K || !a->V || !a->O || !a->seg_item || !a->seg_mode) { me_set_error("me_attn: null pointer"); return ME_EINVAL; }
+  if (a->n_items <= 0 || a->nq <= 0 || a->nk <= 0 || a->heads <= 0 || a->nseg < 1 || a->nseg > 3) { me_set_error("me_attn: bad sizes"); return ME_EINVAL; }
+  if (a->ldq % 8 || a->ldk % 8 || a->ldv % 8 || a->ldo % 4) { me_set_error("me_attn: row strides must be multiples of 8 (Q,K,V) / 4 (O)"); return ME_EINVAL; }
+  if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15 || ((uintptr_t)a->O & 7)) { me_set_error("me_attn: misaligned pointer"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int rc;
+  switch (a->dh) {
+    case 40: rc = launch_attn<40, 2>(a, st); break;
+    case 80: rc = launch_attn<80, 2>(a, st); break;
+    case 160: rc = launch_attn<160, 1>(a, st); break;
+    default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
+  }
+  if (rc != ME_OK) me_set_error("me_attn: kernel launch failed");
+  return rc;
+}

@@ -1,0 +1,31 @@
+// Library-level entry points of libmotioned.so: ABI version, last-error string, device probe.
+#include "me_common.h"
+#include "../../include/motioned.h"
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+extern "C" void me_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+extern "C" int me_abi_version(void) { return ME_ABI_VERSION; }
+
+extern "C" const char* me_last_error(void) { return g_err; }
+
+extern "C" int me_device_info(int* cus, int* lds_bytes, char* arch, int arch_len) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { me_set_error("me_device_info: no HIP device"); return ME_EHIP; }
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) { me_set_error("me_device_info: hipGetDeviceProperties failed"); return ME_EHIP; }
+  if (cus) *cus = p.multiProcessorCount;
+  if (lds_bytes) *lds_bytes = (int)p.maxSharedMemoryPerMultiProcessor;
+  if (arch && arch_len > 0) {
+    strncpy(arch, p.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return ME_OK;
+}

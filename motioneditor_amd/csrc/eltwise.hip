@@ -1,0 +1,231 @@
+// Small element-wise / layout kernels of libmotioned (gfx950): direct 3x3 conv for tiny C_in,
+// strided adds / copies, SiLU / ReLU, timestep embedding, fused CFG + DDIM update, layout converts.
+#include "me_common.h"
+#include "../../include/motioned.h"
+
+namespace {
+
+// one thread = one output pixel x 8 consecutive output channels
+__global__ __launch_bounds__(256) void conv_small_kernel(const me_conv_small_args a) {
+  const int cgs = a.Cout / 8;
+  const long total = (long)a.n_img * a.H * a.Wd * cgs;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int cgi = (int)(idx % cgs);
+  const long pix = idx / cgs;
+  const int x = (int)(pix % a.Wd);
+  const int y = (int)((pix / a.Wd) % a.H);
+  const int img = (int)(pix / ((long)a.Wd * a.H));
+  long base;
+  if (a.frames > 0) base = (long)(img / a.frames) * a.img_stride + (long)(img % a.frames) * a.frame_stride;
+  else base = (long)img * a.img_stride;
+
+  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = bias ? (float)bias[cgi * 8 + e] : 0.f;
+
+  for (int tap = 0; tap < 9; ++tap) {
+    const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+    if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.Wd) continue;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+      const long off = base + (long)ci * a.ch_stride + (long)iy * a.Wd + ix;
+      const float v = a.in_is_f16 ? (float)reinterpret_cast<const f16*>(a.in)[off] : reinterpret_cast<const float*>(a.in)[off];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v * (float)W[((long)(cgi * 8 + e) * 9 + tap) * a.Cin + ci];
+    }
+  }
+  U128 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.e[e] = (f16)(a.silu ? silu_f(acc[e]) : acc[e]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(a.out) + pix * a.Cout + cgi * 8) = o.u;
+}
+
+// Y = X + alpha * A over a [rows, cols] view, 4 halves per thread
+__global__ __launch_bounds__(256) void axpy_rows_kernel(f16* Y, int ldy, const f16* X, int ldx, const f16* A, int lda, long rows, int cols, float alpha) {
+  const int vpr = cols / 4;
+  const long n = rows * vpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const long r = idx / vpr;
+    const int c = (int)(idx - r * vpr) * 4;
+    U64 x, av, o;
+    x.u = *reinterpret_cast<const uint2*>(X + r * ldx + c);
+    av.u = *reinterpret_cast<const uint2*>(A + r * lda + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.e[e] = (f16)((float)x.e[e] + alpha * (float)av.e[e]);
+    *reinterpret_cast<uint2*>(Y + r * ldy + c) = o.u;
+  }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(f16* Y, int ldy, const f16* X, int ldx, long rows, int cols) {
+  const int vpr = cols / 8;
+  const long n = rows * vpr;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const long r = idx / vpr;
+    const int c = (int)(idx - r * vpr) * 8;
+    *reinterpret_cast<uint4*>(Y + r * ldy + c) = ldg128(X + r * ldx + c);
+  }
+}
+
+template <int OP>  // 0 silu, 1 relu
+__global__ __launch_bounds__(256) void unary_kernel(f16* Y, const f16* X, long n) {
+  for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8; idx < n; idx += (long)gridDim.x * 256 * 8) {
+    if (idx + 8 <= n) {
+      U128 u, o;
+      u.u = ldg128(X + idx);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = (float)u.e[e];
+        o.e[e] = (f16)(OP == 0 ? silu_f(v) : fmaxf(v, 0.f));
+      }
+      *reinterpret_cast<uint4*>(Y + idx) = o.u;
+    } else {
+      for (long k = idx; k < n; ++k) {
+        const float v = (float)X[k];
+        Y[k] = (f16)(OP == 0 ? silu_f(v) : fmaxf(v, 0.f));
+      }
+    }
+  }
+}
+
+__global__ void timestep_embed_kernel(f16* out, int rows, int dim, float t) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * dim) return;
+  const int d = idx % dim;
+  const int k = d < half ? d : d - half;
+  const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+  const float ang = t * freq;
+  out[idx] = (f16)(d < half ? cosf(ang) : sinf(ang));
+}
+
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(float* lat_out, const float* lat_in, const f16* eps, int lde, int nb, int C, int frames,
+                                                       int npix, float guidance, float ca, float cb) {
+  const long total = (long)nb * C * frames * npix;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = (int)(idx % npix);
+  long r = idx / npix;
+  const int f = (int)(r % frames);
+  r /= frames;
+  const int c = (int)(r % C);
+  const int b = (int)(r / C);
+  const long row_u = ((long)b * frames + f) * npix + p;
+  const long row_c = ((long)(b + nb) * frames + f) * npix + p;
+  const float eu = (float)eps[row_u * lde + c];
+  const float ec = (float)eps[row_c * lde + c];
+  const float e = eu + guidance * (ec - eu);
+  lat_out[idx] = ca * lat_in[idx] + cb * e;
+}
+
+__global__ __launch_bounds__(256) void nchw_to_rows_kernel(f16* Y, int ldy, const float* X, long img_stride, long ch_stride, int n_img, int C, int npix) {
+  const long total = (long)n_img * npix * C;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long row = idx / C;
+  const int p = (int)(row % npix);
+  const int img = (int)(row / npix);
+  Y[row * ldy + c] = (f16)X[(long)img * img_stride + (long)c * ch_stride + p];
+}
+
+__global__ __launch_bounds__(256) void rows_to_nchw_kernel(float* Y, long img_stride, long ch_stride, const f16* X, int ldx, int n_img, int C, int npix) {
+  const long total = (long)n_img * npix * C;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int p = (int)(idx % npix);
+  long r = idx / npix;
+  const int c = (int)(r % C);
+  const int img = (int)(r / C);
+  Y[(long)img * img_stride + (long)c * ch_stride + p] = (float)X[((long)img * npix + p) * ldx + c];
+}
+
+inline unsigned grid_for(long n, long cap = 16384) {
+  long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" void me_set_error(const char* msg);
+
+#define ME_CHECK_LAUNCH(name)                                         \
+  if (hipGetLastError() != hipSuccess) {                              \
+    me_set_error(name ": kernel launch failed");                      \
+    return ME_EHIP;                                                   \
+  }                                                                   \
+  return ME_OK;
+
+extern "C" int me_conv_small(const me_conv_small_args* a, void* stream) {
+  if (!a || !a->in || !a->W || !a->out) { me_set_error("me_conv_small: null pointer"); return ME_EINVAL; }
+  if (a->Cin <= 0 || a->Cin > 8 || a->Cout % 8 || a->n_img <= 0 || a->H <= 0 || a->Wd <= 0) { me_set_error("me_conv_small: bad geometry"); return ME_EINVAL; }
+  const long total = (long)a->n_img * a->H * a->Wd * (a->Cout / 8);
+  hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  ME_CHECK_LAUNCH("me_conv_small")
+}
+
+extern "C" int me_axpy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, const void* A, int32_t lda, int64_t rows, int32_t cols, float alpha,
+                            void* stream) {
+  if (!Y || !X || !A || rows <= 0 || cols <= 0 || cols % 4 || ldy % 4 || ldx % 4 || lda % 4) { me_set_error("me_axpy_rows: bad arguments"); return ME_EINVAL; }
+  hipLaunchKernelGGL(axpy_rows_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
+                     reinterpret_cast<const f16*>(X), ldx, reinterpret_cast<const f16*>(A), lda, (long)rows, cols, alpha);
+  ME_CHECK_LAUNCH("me_axpy_rows")
+}
+
+extern "C" int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream) {
+  if (!Y || !X || rows <= 0 || cols <= 0 || cols % 8 || ldy % 8 || ldx % 8) { me_set_error("me_copy_rows: bad arguments"); return ME_EINVAL; }
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
+                     reinterpret_cast<const f16*>(X), ldx, (long)rows, cols);
+  ME_CHECK_LAUNCH("me_copy_rows")
+}
+
+extern "C" int me_silu(void* Y, const void* X, int64_t n, void* stream) {
+  if (!Y || !X || n <= 0 || (((uintptr_t)Y | (uintptr_t)X) & 15)) { me_set_error("me_silu: bad arguments"); return ME_EINVAL; }
+  hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y),
+                     reinterpret_cast<const f16*>(X), (long)n);
+  ME_CHECK_LAUNCH("me_silu")
+}
+
+extern "C" int me_relu(void* Y, const void* X, int64_t n, void* stream) {
+  if (!Y || !X || n <= 0 || (((uintptr_t)Y | (uintptr_t)X) & 15)) { me_set_error("me_relu: bad arguments"); return ME_EINVAL; }
+  hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y),
+                     reinterpret_cast<const f16*>(X), (long)n);
+  ME_CHECK_LAUNCH("me_relu")
+}
+
+extern "C" int me_timestep_embed(void* out, int32_t rows, int32_t dim, float t, void* stream) {
+  if (!out || rows <= 0 || dim <= 0 || dim % 2) { me_set_error("me_timestep_embed: bad arguments"); return ME_EINVAL; }
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(out), rows,
+                     dim, t);
+  ME_CHECK_LAUNCH("me_timestep_embed")
+}
+
+extern "C" int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C, int32_t frames, int32_t npix,
+                           float guidance, float ca, float cb, void* stream) {
+  if (!lat_out || !lat_in || !eps || nb <= 0 || C <= 0 || frames <= 0 || npix <= 0 || lde < C) { me_set_error("me_cfg_ddim: bad arguments"); return ME_EINVAL; }
+  const long total = (long)nb * C * frames * npix;
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lat_out, lat_in,
+                     reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, guidance, ca, cb);
+  ME_CHECK_LAUNCH("me_cfg_ddim")
+}
+
+extern "C" int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride, int32_t n_img, int32_t C, int32_t npix,
+                               void* stream) {
+  if (!Y || !X || n_img <= 0 || C <= 0 || npix <= 0 || ldy < C) { me_set_error("me_nchw_to_rows: bad arguments"); return ME_EINVAL; }
+  const long total = (long)n_img * npix * C;
+  hipLaunchKernelGGL(nchw_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy, X,
+                     (long)img_stride, (long)ch_stride, n_img, C, npix);
+  ME_CHECK_LAUNCH("me_nchw_to_rows")
+}
+
+extern "C" int me_rows_to_nchw(float* Y, int64_t img_stride, int64_t ch_stride, const void* X, int32_t ldx, int32_t n_img, int32_t C, int32_t npix,
+                               void* stream) {
+  if (!Y || !X || n_img <= 0 || C <= 0 || npix <= 0 || ldx < C) { me_set_error("me_rows_to_nchw: bad arguments"); return ME_EINVAL; }
+  const long total = (long)n_img * npix * C;
+  hipLaunchKernelGGL(rows_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Y, (long)img_stride,
+                     (long)ch_stride, reinterpret_cast<const f16*>(X), ldx, n_img, C, npix);
+  ME_CHECK_LAUNCH("me_rows_to_nchw")
+}

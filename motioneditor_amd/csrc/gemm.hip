@@ -1,0 +1,297 @@
+// gather-GEMM / implicit convolution on MFMA (gfx950).
+//
+//   C[m, n] = epilogue( sum_{tap} sum_{c < K} X[src(m, tap), c] * W[n, tap, c] )
+//
+// One kernel serves nn.Linear, 1x1 conv, 3x3 conv (stride 1/2, optional nearest-2x upsample of the
+// input folded into the gather) and the k=3 temporal conv: only the row-gather src(m, tap) differs.
+// Activations are channels-last so every tap is a contiguous K-run of one source row.
+//
+// Tiling: 128 x BN x 64 block tile, 256 threads = 4 waves in a 2 x 2 grid, each wave 64 x (BN/2)
+// built from v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as MFMA operand A and the ACTIVATION
+// fragment as operand B, so a lane ends up holding 4 consecutive output channels of one output row
+// (8-byte stores, bias/GEGLU epilogue without cross-lane traffic).
+// Staging: global -> registers (16-byte loads, zero-filled for padding taps / tails) -> LDS with
+// 16 bytes of row padding, double-buffered: the next K-slab's global loads are in flight while the
+// current slab feeds the MFMAs; one barrier per slab.
+#include "me_common.h"
+#include "../../include/motioned.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LDS_LD = BK + 8;  // halves; 144-byte rows keep ds_read_b128 16-byte aligned
+
+struct RowInfo {
+  // CONV3: base = img * Hin * Win, y0 = oy*stride - 1, x0 = ox*stride - 1
+  // TCONV: base = m, y0 = frame index inside its chunk
+  // DENSE: base = m
+  int base, y0, x0;
+  bool valid;
+};
+
+__device__ __forceinline__ RowInfo make_row(const me_gemm_args& a, int m) {
+  RowInfo r;
+  r.valid = m < a.M;
+  r.base = m;
+  r.y0 = 0;
+  r.x0 = 0;
+  if (!r.valid) return r;
+  if (a.gather == ME_GATHER_CONV3) {
+    const int hw = a.Hout * a.Wout;
+    const int img = m / hw;
+    const int rem = m - img * hw;
+    const int oy = rem / a.Wout;
+    const int ox = rem - oy * a.Wout;
+    r.base = img * a.Hin * a.Win;
+    r.y0 = oy * a.stride - 1;
+    r.x0 = ox * a.stride - 1;
+  } else if (a.gather == ME_GATHER_TCONV) {
+    const int fr = (m / a.npix) % a.frames;
+    r.y0 = fr % a.chunk;
+  }
+  return r;
+}
+
+// source row of (row, tap) or -1 when the tap falls into zero padding
+__device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, int tap) {
+  if (!r.valid) return -1;
+  if (a.gather == ME_GATHER_DENSE) return r.base;
+  if (a.gather == ME_GATHER_CONV3) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = r.y0 + ky, ix = r.x0 + kx;
+    const int Hv = a.Hin << a.ups, Wv = a.Win << a.ups;
+    if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) return -1;
+    return r.base + (iy >> a.ups) * a.Win + (ix >> a.ups);
+  }
+  // TCONV
+  const int dt = tap - 1;
+  const int fc = r.y0 + dt;
+  if (fc < 0 || fc >= a.chunk) return -1;
+  return r.base + dt * a.npix;
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
+  constexpr int WN = BN / 2;     // per-wave N extent
+  constexpr int NT = WN / 16;    // 16-wide n tiles per wave
+  constexpr int MT = 4;          // 16-wide m tiles per wave (64 rows)
+  constexpr int WROWS = BN / 32; // W rows staged per thread
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f16* sX = reinterpret_cast<f16*>(smem);         // [2][BM][LDS_LD]
+  f16* sW = sX + 2 * BM * LDS_LD;                 // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM;
+  const int w = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tile_n = w % nbn, tile_m = w / nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
+  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
+
+  const int taps = a.gather == ME_GATHER_CONV3 ? 9 : (a.gather == ME_GATHER_TCONV ? 3 : 1);
+  const int nkc = (a.K + BK - 1) / BK;
+  const int nit = taps * nkc;
+
+  // staging assignment: thread -> (row = tid/8 + 32*i, 16-byte chunk = tid%8)
+  const int srow = tid >> 3;
+  const int scol = (tid & 7) * 8;  // halves
+
+  RowInfo rinfo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + 32 * i);
+
+  uint4 rx[4], rw[WROWS];
+  long xoff[4];  // element offset of the source row for the current tap, or -1
+  int cur_tap = -1;
+
+  auto gload = [&](int it) {
+    const int tap = it / nkc;
+    const int c = (it - tap * nkc) * BK + scol;
+    if (tap != cur_tap) {
+      cur_tap = tap;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = src_row(a, rinfo[i], tap);
+        xoff[i] = s < 0 ? -1L : (long)s * a.ldx;
+      }
+    }
+    const bool kok = c < a.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+      const int n = n0 + srow + 32 * i;
+      rw[i] = (kok && n < a.N) ? ldg128(W + ((long)n * taps + tap) * a.K + c) : zero128();
+    }
+  };
+  auto sstore = [&](int buf) {
+    f16* dx = sX + buf * BM * LDS_LD;
+    f16* dw = sW + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + 32 * i) * LDS_LD + scol) = rx[i];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + 32 * i) * LDS_LD + scol) = rw[i];
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 8;
+
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) gload(it + 1);
+    const f16* bx = sX + buf * BM * LDS_LD + (wm * 64 + frow) * LDS_LD + fk;
+    const f16* bw = sW + buf * BN * LDS_LD + (wn * WN + frow) * LDS_LD + fk;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      f16x8 fx[MT], fw[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fx[i] = *reinterpret_cast<const f16x8*>(bx + i * 16 * LDS_LD + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const f16x8*>(bw + j * 16 * LDS_LD + ks * 32);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(fw[j], fx[i], acc[j][i]);
+    }
+    if (it + 1 < nit) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile ----
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
+  const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const int nq = (lane >> 4) * 4;
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= a.M) continue;
+    const f16* rv = rowvec ? rowvec + (long)(m / a.rows_per_vec) * a.ldrv : nullptr;
+    if (!a.geglu) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + nq;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
+        if (bias) {
+          U64 b;
+          b.u = *reinterpret_cast<const uint2*>(bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+        }
+        if (rv) {
+          U64 b;
+          b.u = *reinterpret_cast<const uint2*>(rv + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+        }
+        if (res) {
+          U64 b;
+          b.u = *reinterpret_cast<const uint2*>(res + (long)m * a.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+        }
+        U64 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.e[r] = (f16)v[r];
+        *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
+      }
+    } else {
+      // packed rows: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns
+#pragma unroll
+      for (int jj = 0; jj < NT / 2; ++jj) {
+        const int np = n0 + wn * WN + jj * 32 + nq;  // packed row of the value part
+        if (np >= a.N) continue;
+        const int no = (n0 + wn * WN) / 2 + jj * 16 + nq;  // output column
+        float va[4], vg[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          va[r] = acc[2 * jj][i][r] * a.alpha;
+          vg[r] = acc[2 * jj + 1][i][r] * a.alpha;
+        }
+        if (bias) {
+          U64 b, g;
+          b.u = *reinterpret_cast<const uint2*>(bias + np);
+          g.u = *reinterpret_cast<const uint2*>(bias + np + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            va[r] += (float)b.e[r];
+            vg[r] += (float)g.e[r];
+          }
+        }
+        U64 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.e[r] = (f16)(va[r] * gelu_erf_f(vg[r]));
+        *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" void me_set_error(const char* msg);
+
+template <int BN>
+static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(f16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return ME_EHIP;
+    }
+    attr_set = true;
+  }
+  const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
+  hipLaunchKernelGGL(gemm_kernel<BN>, dim3(nbm * nbn), dim3(256), lds, st, *a);
+  if (hipGetLastError() != hipSuccess) {
+    me_set_error("me_gemm: kernel launch failed");
+    return ME_EHIP;
+  }
+  return ME_OK;
+}
+
+extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
+  if (!a || !a->X || !a->W || !a->C) { me_set_error("me_gemm: null pointer"); return ME_EINVAL; }
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) { me_set_error("me_gemm: non-positive dimension"); return ME_EINVAL; }
+  if (a->K % 8 || a->ldx % 8 || a->ldc % 4 || a->N % 4) { me_set_error("me_gemm: K, ldx must be multiples of 8 and N, ldc of 4"); return ME_EINVAL; }
+  if (((uintptr_t)a->X | (uintptr_t)a->W) & 15 || ((uintptr_t)a->C & 7)) { me_set_error("me_gemm: misaligned pointer"); return ME_EINVAL; }
+  if (a->gather < 0 || a->gather > 2) { me_set_error("me_gemm: bad gather mode"); return ME_EINVAL; }
+  if (a->gather == ME_GATHER_CONV3) {
+    if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0 || (a->stride != 1 && a->stride != 2) || (a->ups != 0 && a->ups != 1) ||
+        a->M % (a->Hout * a->Wout)) { me_set_error("me_gemm: bad conv geometry"); return ME_EINVAL; }
+  }
+  if (a->gather == ME_GATHER_TCONV) {
+    if (a->frames <= 0 || a->npix <= 0 || a->chunk <= 0 || a->frames % a->chunk || a->M % (a->frames * a->npix)) { me_set_error("me_gemm: bad tconv geometry"); return ME_EINVAL; }
+  }
+  if (a->rowvec && (a->rows_per_vec <= 0 || a->ldrv % 4 || ((uintptr_t)a->rowvec & 7))) { me_set_error("me_gemm: bad rowvec"); return ME_EINVAL; }
+  if (a->res && (a->ldr % 4 || ((uintptr_t)a->res & 7))) { me_set_error("me_gemm: bad residual"); return ME_EINVAL; }
+  if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
+  if (a->geglu && (a->N % 32 || a->rowvec || a->res)) { me_set_error("me_gemm: geglu needs N % 32 == 0 and no rowvec/res"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (a->N % 128 == 0 || a->N % 64 != 0) return launch_gemm<128>(a, st);
+  return launch_gemm<64>(a, st);
+}

@@ -1,0 +1,59 @@
+// Shared device-side helpers for libmotioned (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define ME_WAVE 64
+
+// v_mfma_f32_16x16x32_f16: D(16x16) += A(16x32) * B(32x16).
+//   A operand: lane l holds A[i = l & 15][k = (l >> 4) * 8 + 0..7]
+//   B operand: lane l holds B[k = (l >> 4) * 8 + 0..7][n = l & 15]
+//   C/D      : lane l, reg r holds D[i = (l >> 4) * 4 + r][n = l & 15]
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+union U128 {
+  uint4 u;
+  f16x8 h;
+  f16 e[8];
+};
+
+union U64 {
+  uint2 u;
+  f16x4 h;
+  f16 e[4];
+};
+
+__device__ __forceinline__ uint4 ldg128(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 zero128() { return make_uint4(0u, 0u, 0u, 0u); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give each
+// XCD a contiguous run of work items so neighbouring tiles share one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}

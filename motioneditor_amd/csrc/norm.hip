@@ -1,0 +1,199 @@
+// GroupNorm(+SiLU) and LayerNorm on channels-last fp16 activations (HBM-bound kernels, gfx950).
+//
+// GroupNorm: pass 1 accumulates (sum, sum of squares) per (row-group, channel-group) with 16-byte
+// loads, register accumulation down the rows, LDS float atomics across the block and one global
+// atomic per (block, group); pass 2 re-reads X, normalises, applies gamma/beta (+SiLU), writes Y.
+// Algorithmic bytes per call: rows*C*2 (read) + rows*C*2 (write); the statistics pass re-reads X.
+// LayerNorm: one wave per row, two-pass mean/variance in registers.
+#include "me_common.h"
+#include "../../include/motioned.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X, float* __restrict__ stats, int rows_per_group,
+                                                       int chunk_rows, int C, int ldx, int groups) {
+  __shared__ float sacc[64][2];
+  const int tid = threadIdx.x;
+  if (tid < 64) { sacc[tid][0] = 0.f; sacc[tid][1] = 0.f; }
+  __syncthreads();
+
+  const int sg = blockIdx.y;
+  const int r0 = blockIdx.x * chunk_rows;
+  const int r1 = min(r0 + chunk_rows, rows_per_group);
+  const int tpr = C / 8;                       // 16-byte vectors per row
+  const int tprc = tpr < 256 ? tpr : 256;      // vector columns handled per pass
+  const int rl = tid / tprc, vc0 = tid - rl * tprc;
+  const int RL = 256 / tprc;                   // row lanes
+  const int cg = C / groups;
+  const f16* base = X + (long)sg * rows_per_group * ldx;
+
+  if (rl < RL) {
+    for (int vc = vc0; vc < tpr; vc += tprc) {
+      float s[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int r = r0 + rl; r < r1; r += RL) {
+        U128 u;
+        u.u = ldg128(base + (long)r * ldx + vc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = (float)u.e[e];
+          s[e] += v;
+          q[e] += v * v;
+        }
+      }
+      // fold the 8 channels into their (at most two when cg >= 8, else more) groups
+      int gcur = (vc * 8) / cg;
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ge = (vc * 8 + e) / cg;
+        if (ge != gcur) {
+          atomicAdd(&sacc[gcur][0], ss);
+          atomicAdd(&sacc[gcur][1], qq);
+          gcur = ge;
+          ss = 0.f;
+          qq = 0.f;
+        }
+        ss += s[e];
+        qq += q[e];
+      }
+      atomicAdd(&sacc[gcur][0], ss);
+      atomicAdd(&sacc[gcur][1], qq);
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    atomicAdd(&stats[((long)sg * groups + tid) * 2 + 0], sacc[tid][0]);
+    atomicAdd(&stats[((long)sg * groups + tid) * 2 + 1], sacc[tid][1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, const float* __restrict__ stats,
+                                                       const f16* __restrict__ gamma, const f16* __restrict__ beta, long rows,
+                                                       int rows_per_group, int C, int ldx, int ldy, int groups, float eps, int silu) {
+  const int tpr = C / 8;
+  const long nvec = rows * tpr;
+  const int cg = C / groups;
+  const float inv_cnt = 1.0f / ((float)rows_per_group * (float)cg);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long)gridDim.x * 256) {
+    const long row = idx / tpr;
+    const int vc = (int)(idx - row * tpr);
+    const int sg = (int)(row / rows_per_group);
+    U128 u, gm, bt, o;
+    u.u = ldg128(X + row * ldx + vc * 8);
+    gm.u = ldg128(gamma + vc * 8);
+    bt.u = ldg128(beta + vc * 8);
+    int gprev = -1;
+    float mean = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ge = (vc * 8 + e) / cg;
+      if (ge != gprev) {
+        gprev = ge;
+        const float s = stats[((long)sg * groups + ge) * 2 + 0];
+        const float q = stats[((long)sg * groups + ge) * 2 + 1];
+        mean = s * inv_cnt;
+        const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
+        rstd = rsqrtf(var + eps);
+      }
+      float v = ((float)u.e[e] - mean) * rstd * (float)gm.e[e] + (float)bt.e[e];
+      if (silu) v = silu_f(v);
+      o.e[e] = (f16)v;
+    }
+    *reinterpret_cast<uint4*>(Y + row * ldy + vc * 8) = o.u;
+  }
+}
+
+// One wave per row; NV = 16-byte vectors per lane.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ X, f16* __restrict__ Y, const f16* __restrict__ gamma,
+                                                        const f16* __restrict__ beta, long rows, int C, int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int tpr = C / 8;
+  U128 u[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    u[k].u = vc < tpr ? ldg128(X + row * ldx + vc * 8) : zero128();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)u[k].e[e];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    if (vc < tpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)u[k].e[e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    if (vc < tpr) {
+      U128 gm, bt, o;
+      gm.u = ldg128(gamma + vc * 8);
+      bt.u = ldg128(beta + vc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (f16)(((float)u[k].e[e] - mean) * rstd * (float)gm.e[e] + (float)bt.e[e]);
+      *reinterpret_cast<uint4*>(Y + row * ldy + vc * 8) = o.u;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" void me_set_error(const char* msg);
+
+extern "C" int me_groupnorm(const me_groupnorm_args* a, void* stream) {
+  if (!a || !a->X || !a->Y || !a->gamma || !a->beta || !a->stats) { me_set_error("me_groupnorm: null pointer"); return ME_EINVAL; }
+  if (a->rows <= 0 || a->rows_per_group <= 0 || a->rows % a->rows_per_group) { me_set_error("me_groupnorm: rows must be a multiple of rows_per_group"); return ME_EINVAL; }
+  if (a->groups <= 0 || a->groups > 64 || a->C % a->groups || a->C % 8 || a->ldx % 8 || a->ldy % 8) { me_set_error("me_groupnorm: bad channel geometry"); return ME_EINVAL; }
+  if (((uintptr_t)a->X | (uintptr_t)a->Y | (uintptr_t)a->gamma | (uintptr_t)a->beta) & 15) { me_set_error("me_groupnorm: misaligned pointer"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nsg = a->rows / a->rows_per_group;
+  if (hipMemsetAsync(a->stats, 0, (size_t)nsg * a->groups * 2 * sizeof(float), st) != hipSuccess) { me_set_error("me_groupnorm: memset failed"); return ME_EHIP; }
+  // aim at ~2048 blocks in total for the statistics pass
+  int chunks = 2048 / nsg;
+  if (chunks < 1) chunks = 1;
+  int chunk_rows = (a->rows_per_group + chunks - 1) / chunks;
+  if (chunk_rows < 8) chunk_rows = 8;
+  chunks = (a->rows_per_group + chunk_rows - 1) / chunk_rows;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), a->stats, a->rows_per_group,
+                     chunk_rows, a->C, a->ldx, a->groups);
+  const long nvec = (long)a->rows * (a->C / 8);
+  long blocks = (nvec + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), reinterpret_cast<f16*>(a->Y),
+                     a->stats, reinterpret_cast<const f16*>(a->gamma), reinterpret_cast<const f16*>(a->beta), (long)a->rows, a->rows_per_group,
+                     a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu);
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm: kernel launch failed"); return ME_EHIP; }
+  return ME_OK;
+}
+
+extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {
+  if (!a || !a->X || !a->Y || !a->gamma || !a->beta) { me_set_error("me_layernorm: null pointer"); return ME_EINVAL; }
+  if (a->rows <= 0 || a->C <= 0 || a->C % 8 || a->C > 1536 || a->ldx % 8 || a->ldy % 8) { me_set_error("me_layernorm: C must be a multiple of 8 and <= 1536"); return ME_EINVAL; }
+  if (((uintptr_t)a->X | (uintptr_t)a->Y | (uintptr_t)a->gamma | (uintptr_t)a->beta) & 15) { me_set_error("me_layernorm: misaligned pointer"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((a->rows + 3) / 4);
+  const int nv = (a->C / 8 + 63) / 64;
+  const f16* X = reinterpret_cast<const f16*>(a->X);
+  f16* Y = reinterpret_cast<f16*>(a->Y);
+  const f16* gm = reinterpret_cast<const f16*>(a->gamma);
+  const f16* bt = reinterpret_cast<const f16*>(a->beta);
+  if (nv == 1) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
+  else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
+  else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_layernorm: kernel launch failed"); return ME_EHIP; }
+  return ME_OK;
+}

@@ -1,0 +1,235 @@
+"""Thin tensor-level wrappers over the C ABI.  PyTorch-ROCm is used ONLY for device memory and the
+current HIP stream; every arithmetic op below is a ``libmotioned.so`` kernel.
+
+Activation convention: 2-D fp16 tensors ``[rows, C]`` (possibly strided views, unit column stride),
+rows ordered ``(batch, frame, pixel)`` -- channels-last / token-major everywhere, so the reference's
+``rearrange`` calls between "(b f) c h w", "(b f) (h w) c" and "(b d) f c" are free.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import capi
+from .capi import AttnArgs, ConvSmallArgs, GemmArgs, GroupNormArgs, LayerNormArgs, TAttnArgs
+
+F16 = torch.float16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t: torch.Tensor, name: str) -> None:
+    if t.dtype != F16 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA fp16 2-D tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
+def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty((rows, cols), dtype=F16, device=like.device)
+
+
+def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Optional[torch.Tensor] = None,
+         bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
+         res: Optional[torch.Tensor] = None, geglu: bool = False, alpha: float = 1.0,
+         conv: Optional[Tuple[int, int, int, int, int, int]] = None,
+         tconv: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+    """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
+
+    w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
+    3 for ``tconv=(frames, npix, chunk)``)."""
+    _chk2d(x, "gemm.x")
+    if w.dtype != F16 or not w.is_contiguous() or w.dim() != 3:
+        raise ValueError("gemm.w: expected contiguous fp16 [N, taps, K]")
+    N, taps, K = w.shape
+    a = GemmArgs()
+    a.gather = capi.GATHER_DENSE
+    if conv is not None:
+        a.gather = capi.GATHER_CONV3
+        a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.ups = conv
+        if taps != 9:
+            raise ValueError("gemm: conv needs 9 taps")
+    elif tconv is not None:
+        a.gather = capi.GATHER_TCONV
+        a.frames, a.npix, a.chunk = tconv
+        if taps != 3:
+            raise ValueError("gemm: tconv needs 3 taps")
+    elif taps != 1:
+        raise ValueError("gemm: dense needs 1 tap")
+    if M is None:
+        M = x.shape[0]
+    if x.shape[1] < K:
+        raise ValueError(f"gemm: x has {x.shape[1]} columns < K={K}")
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = empty(M, n_out, x)
+    _chk2d(out, "gemm.out")
+    if out.shape[0] < M or out.shape[1] < n_out:
+        raise ValueError("gemm: out too small")
+    a.X, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K = M, N, K
+    a.ldx, a.ldc = x.stride(0), out.stride(0)
+    a.bias = _p(bias)
+    if rowvec is not None:
+        _chk2d(rowvec, "gemm.rowvec")
+        a.rowvec, a.ldrv, a.rows_per_vec = rowvec.data_ptr(), rowvec.stride(0), rows_per_vec
+    if res is not None:
+        _chk2d(res, "gemm.res")
+        a.res, a.ldr = res.data_ptr(), res.stride(0)
+    a.geglu = 1 if geglu else 0
+    a.alpha = alpha
+    capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
+    return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
+
+
+def conv_small(inp: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n_img: int, Cin: int, H: int, Wd: int,
+               img_stride: int, ch_stride: int, frames: int = 0, frame_stride: int = 0, silu: bool = False) -> torch.Tensor:
+    Cout = w.shape[0]
+    out = torch.empty((n_img * H * Wd, Cout), dtype=F16, device=inp.device)
+    a = ConvSmallArgs()
+    a.inp, a.W, a.bias, a.out = inp.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr()
+    a.n_img, a.Cin, a.Cout, a.H, a.Wd = n_img, Cin, Cout, H, Wd
+    a.img_stride, a.ch_stride = img_stride, ch_stride
+    if inp.dtype == torch.float32:
+        a.in_is_f16 = 0
+    elif inp.dtype == F16:
+        a.in_is_f16 = 1
+    else:
+        raise ValueError("conv_small: input must be fp32 or fp16")
+    a.silu = 1 if silu else 0
+    a.frames, a.frame_stride = frames, frame_stride
+    capi.check(capi.lib().me_conv_small(C.byref(a), _stream()), "me_conv_small")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, dh: int, n_items: int, nq: int, nk: int,
+              seg_item: torch.Tensor, seg_mode: torch.Tensor, mask: Optional[torch.Tensor] = None,
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk2d(t, "attention." + n)
+    if seg_item.dtype != torch.int32 or seg_mode.dtype != torch.int32 or seg_item.shape != seg_mode.shape or seg_item.shape[0] != n_items:
+        raise ValueError("attention: seg tables must be int32 [n_items, nseg]")
+    if out is None:
+        out = empty(n_items * nq, heads * dh, q)
+    a = AttnArgs()
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.heads, a.dh = heads, dh
+    a.n_items, a.nq, a.nk, a.nseg = n_items, nq, nk, seg_item.shape[1]
+    a.seg_item, a.seg_mode, a.mask = seg_item.data_ptr(), seg_mode.data_ptr(), _p(mask)
+    a.scale = dh ** -0.5 if scale is None else scale
+    capi.check(capi.lib().me_attn(C.byref(a), _stream()), "me_attn")
+    return out
+
+
+def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, dh: int, batch: int, frames: int, npix: int,
+                       kv_map: Optional[Sequence[int]] = None, scale: Optional[float] = None) -> torch.Tensor:
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk2d(t, "temporal_attention." + n)
+    out = empty(batch * frames * npix, heads * dh, q)
+    a = TAttnArgs()
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.heads, a.dh, a.batch, a.frames, a.npix = heads, dh, batch, frames, npix
+    km = list(kv_map) if kv_map is not None else list(range(batch))
+    for i in range(8):
+        a.kv_map[i] = km[i] if i < len(km) else 0
+    a.scale = dh ** -0.5 if scale is None else scale
+    capi.check(capi.lib().me_tattn(C.byref(a), _stream()), "me_tattn")
+    return out
+
+
+_gn_scratch = {}
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_per_group: int, eps: float, silu: bool,
+              groups: int = 32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk2d(x, "groupnorm.x")
+    rows, Cc = x.shape
+    if out is None:
+        out = empty(rows, Cc, x)
+    nsg = rows // rows_per_group
+    key = (x.device, nsg * groups)
+    stats = _gn_scratch.get(key)
+    if stats is None:
+        stats = _gn_scratch[key] = torch.empty(nsg * groups * 2, dtype=torch.float32, device=x.device)
+    a = GroupNormArgs()
+    a.X, a.Y, a.gamma, a.beta, a.stats = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr()
+    a.rows, a.rows_per_group, a.C, a.ldx, a.ldy = rows, rows_per_group, Cc, x.stride(0), out.stride(0)
+    a.groups, a.eps, a.silu = groups, eps, 1 if silu else 0
+    capi.check(capi.lib().me_groupnorm(C.byref(a), _stream()), "me_groupnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _chk2d(x, "layernorm.x")
+    out = empty(x.shape[0], x.shape[1], x)
+    a = LayerNormArgs()
+    a.X, a.Y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.rows, a.C, a.ldx, a.ldy, a.eps = x.shape[0], x.shape[1], x.stride(0), out.stride(0), eps
+    capi.check(capi.lib().me_layernorm(C.byref(a), _stream()), "me_layernorm")
+    return out
+
+
+def axpy_rows(y: torch.Tensor, x: torch.Tensor, a_: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """y = x + alpha * a_ on equal-shape [rows, cols] views (y may alias x)."""
+    for t, n in ((y, "y"), (x, "x"), (a_, "a")):
+        _chk2d(t, "axpy_rows." + n)
+    capi.check(capi.lib().me_axpy_rows(y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), a_.data_ptr(), a_.stride(0),
+                                       y.shape[0], y.shape[1], alpha, _stream()), "me_axpy_rows")
+    return y
+
+
+def copy_rows(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    _chk2d(y, "copy_rows.y")
+    _chk2d(x, "copy_rows.x")
+    capi.check(capi.lib().me_copy_rows(y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "me_copy_rows")
+    return y
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    capi.check(capi.lib().me_silu(out.data_ptr(), x.data_ptr(), x.numel(), _stream()), "me_silu")
+    return out
+
+
+def relu(x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    capi.check(capi.lib().me_relu(out.data_ptr(), x.data_ptr(), x.numel(), _stream()), "me_relu")
+    return out
+
+
+def timestep_embed(rows: int, dim: int, t: float, device) -> torch.Tensor:
+    out = torch.empty((rows, dim), dtype=F16, device=device)
+    capi.check(capi.lib().me_timestep_embed(out.data_ptr(), rows, dim, float(t), _stream()), "me_timestep_embed")
+    return out
+
+
+def cfg_ddim(latents: torch.Tensor, eps_rows: torch.Tensor, *, guidance: float, ca: float, cb: float) -> torch.Tensor:
+    """latents fp32 [nb, C, f, h, w] (reference layout); eps_rows fp16 [(2nb*f*h*w), >=C] = [uncond | cond]."""
+    nb, Cc, f, h, w = latents.shape
+    if latents.dtype != torch.float32 or not latents.is_contiguous():
+        raise ValueError("cfg_ddim: latents must be contiguous fp32")
+    out = torch.empty_like(latents)
+    capi.check(capi.lib().me_cfg_ddim(out.data_ptr(), latents.data_ptr(), eps_rows.data_ptr(), eps_rows.stride(0), nb, Cc, f, h * w,
+                                      guidance, ca, cb, _stream()), "me_cfg_ddim")
+    return out
+
+
+def nchw_to_rows(x: torch.Tensor, n_img: int, Cc: int, npix: int, img_stride: int, ch_stride: int) -> torch.Tensor:
+    out = torch.empty((n_img * npix, Cc), dtype=F16, device=x.device)
+    capi.check(capi.lib().me_nchw_to_rows(out.data_ptr(), out.stride(0), x.data_ptr(), img_stride, ch_stride, n_img, Cc, npix, _stream()), "me_nchw_to_rows")
+    return out
+
+
+def rows_to_nchw(x: torch.Tensor, n_img: int, Cc: int, npix: int) -> torch.Tensor:
+    """fp16 rows [(n_img*npix), >=Cc] -> fp32 [n_img, Cc, npix]."""
+    out = torch.empty((n_img, Cc, npix), dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().me_rows_to_nchw(out.data_ptr(), Cc * npix, npix, x.data_ptr(), x.stride(0), n_img, Cc, npix, _stream()), "me_rows_to_nchw")
+    return out

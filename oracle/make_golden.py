@@ -1,0 +1,187 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own model code.
+
+CONTAINER-ONLY (needs /root/reference, which never travels to the GPU box).  Test infrastructure,
+not product code.  What it does:
+
+  1. imports ``motion_editor.models`` / ``motion_editor.attn_control`` from /root/reference through
+     the stub packages in oracle/shim (no diffusers / xformers in this image);
+  2. builds the reference ``UNet2DConditionModel`` (SD-1.5 widths) with the deterministic synthetic
+     weights of ``motioneditor_amd.synth`` (zero-init tensors re-randomised);
+  3. runs single-branch and two-branch forwards (both attention editors registered, inactive and
+     active steps) on seeded inputs, and checks that ``oracle/ref_cpu.py`` reproduces every output
+     to fp32 round-off -- this is what PINS the restatement;
+  4. stores the reference outputs (+ per-stage checksums for bisecting) as small .npz fixtures,
+     the state-dict key schema as unet_keys.txt, and DDIM vectors from the reference's in-tree
+     ``prev_step`` (p2p/null_text_optimization.py:26-36).
+
+Usage:  python oracle/make_golden.py [--skip-two-branch]
+"""
+from __future__ import annotations
+
+import ast
+import contextlib
+import io
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(ROOT / "oracle" / "shim"))
+sys.path.insert(1, str(REF))
+sys.path.insert(2, str(ROOT))
+
+from motioneditor_amd import synth  # noqa: E402
+from oracle import ref_cpu  # noqa: E402
+from motioneditor_amd.synth import make_case_inputs  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def stats(t: torch.Tensor):
+    t = t.double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.pow(2).sum().sqrt().item()], dtype=np.float64)
+
+
+def relerr(a: torch.Tensor, b: torch.Tensor) -> float:
+    return ((a - b).abs().max() / b.abs().mean().clamp_min(1e-12)).item()
+
+
+def build_reference_unet(sd_np):
+    from motion_editor.models.unet_2d_condition import UNet2DConditionModel
+    m = quiet(UNet2DConditionModel, sample_size=64, cross_attention_dim=768, attention_head_dim=8, use_sc_attn=True, use_st_attn=False)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    assert not missing and not unexpected
+    return m.eval()
+
+
+def reference_ddim_vectors():
+    """Execute the reference's own prev_step (p2p/null_text_optimization.py:26-36) without importing the
+    module (it loads a CLIP tokenizer at import time)."""
+    src = (REF / "motion_editor/p2p/null_text_optimization.py").read_text()
+    tree = ast.parse(src)
+    fn = None
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "prev_step":
+            fn = node
+    mod = ast.Module(body=[fn], type_ignores=[])
+    ns = {"Union": __import__("typing").Union, "torch": torch, "np": np}
+    exec(compile(mod, "ref_prev_step", "exec"), ns)
+    d = ref_cpu.DDIM()
+
+    class Sched:
+        class config:
+            num_train_timesteps = 1000
+        num_inference_steps = 50
+        alphas_cumprod = d.alphas_cumprod
+        final_alpha_cumprod = d.alphas_cumprod[0]
+
+    class Self:
+        scheduler = Sched
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, 8, 8, generator=g)
+    e = torch.randn(2, 4, 8, 8, generator=g)
+    out = {}
+    for t in (981, 501, 21, 1):
+        ref = ns["prev_step"](Self, e, t, x)
+        mine = d.step(e, t, x)
+        assert relerr(mine, ref) < 1e-6, (t, relerr(mine, ref))
+        ca, cb = d.coeffs(t)
+        assert relerr(ca * x + cb * e, ref) < 1e-5
+        out[f"prev_{t}"] = ref.numpy()
+    out["x"], out["eps"] = x.numpy(), e.numpy()
+    out["timesteps"] = np.array(d.timesteps, dtype=np.int64)
+    assert d.timesteps[0] == 981 and d.timesteps[-1] == 1 and len(d.timesteps) == 50
+    np.savez_compressed(GOLD / "ddim.npz", **out)
+    print("ddim.npz written; oracle DDIM == reference prev_step")
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 8)
+    GOLD.mkdir(parents=True, exist_ok=True)
+    reference_ddim_vectors()
+
+    t0 = time.time()
+    schema = synth.unet_schema()
+    sd_np = synth.synth_state_dict(schema)
+    print(f"weights: {sum(v.size for v in sd_np.values())/1e6:.1f} M params in {time.time()-t0:.1f}s")
+    unet = build_reference_unet(sd_np)
+    ref_sd = unet.state_dict()
+    with open(GOLD / "unet_keys.txt", "w") as fh:
+        for k, v in ref_sd.items():
+            fh.write(f"{k} {' '.join(str(int(s)) for s in v.shape)}\n")
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == dict(schema), "schema mismatch vs reference"
+    sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+
+    from motion_editor.attn_control.fully_control import FullySelfAttentionControlMask
+    from motion_editor.attn_control.fully_control_utils import regiter_fully_attention_editor_diffusers
+    from motion_editor.attn_control.temporal_control import TemporalSelfAttentionControl
+    from motion_editor.attn_control.temporal_control_utils import regiter_temporal_attention_editor_diffusers
+
+    # ---- case A: single branch, no editors (config-2 shape family, small) ----
+    ca = make_case_inputs("single", B=2, f=8, h=16, w=16)
+    with torch.no_grad():
+        t0 = time.time()
+        ref = quiet(unet, ca["sample"], torch.tensor(ca["t"]), ca["ehs"]).sample
+        print(f"reference single-branch forward {time.time()-t0:.1f}s")
+        taps = {}
+        mine = ref_cpu.unet_forward(sd, ca["sample"], ca["t"], ca["ehs"], taps=taps)
+    e = relerr(mine, ref)
+    print("single-branch oracle vs reference rel err", e)
+    assert e < 2e-4, e
+    np.savez_compressed(GOLD / "unet_single.npz", out=ref.numpy().astype(np.float32), out_stats=stats(ref),
+                        skip_stats=np.stack([stats(s) for s in taps["skips"]]), mid_stats=stats(taps["mid"]), oracle_relerr=e)
+
+    if "--skip-two-branch" in sys.argv:
+        return
+
+    # ---- case B: two branch (B=4), f=16 (exposes the adapter's chunk-of-8 quirk), both editors ----
+    cb = make_case_inputs("two", B=4, f=16, h=16, w=16)
+
+    class Holder:
+        pass
+
+    holder = Holder()
+    holder.unet = unet
+    ted = quiet(TemporalSelfAttentionControl, start_step=4, start_layer=10)
+    quiet(regiter_temporal_attention_editor_diffusers, holder, ted)
+    sed = quiet(FullySelfAttentionControlMask, start_step=4, start_layer=10, source_masks=cb["source_masks"])
+    quiet(regiter_fully_attention_editor_diffusers, holder, sed)
+    assert ted.num_att_layers == 16 and sed.num_att_layers == 32
+
+    for tag, step in (("inactive", 0), ("active", 4)):
+        ted.reset(); sed.reset()
+        ted.cur_step = sed.cur_step = step
+        my_sp = ref_cpu.SpatialEditor(cb["source_masks"])
+        my_tp = ref_cpu.TemporalEditor()
+        my_sp.cur_step = my_tp.cur_step = step
+        with torch.no_grad():
+            t0 = time.time()
+            ref = quiet(unet, cb["sample"], torch.tensor(cb["t"]), cb["ehs"], down_block_additional_residuals=cb["down_res"],
+                        mid_block_additional_residual=cb["mid_res"]).sample
+            print(f"reference two-branch forward ({tag}) {time.time()-t0:.1f}s")
+            taps = {}
+            mine = ref_cpu.unet_forward(sd, cb["sample"], cb["t"], cb["ehs"], cb["down_res"], cb["mid_res"], my_sp, my_tp, taps=taps)
+        e = relerr(mine, ref)
+        print(f"two-branch ({tag}) oracle vs reference rel err", e)
+        assert e < 2e-4, e
+        assert (ted.cur_step, ted.cur_att_layer, sed.cur_step, sed.cur_att_layer) == (my_tp.cur_step, my_tp.cur_att_layer, my_sp.cur_step, my_sp.cur_att_layer) == (step + 1, 0, step + 1, 0)
+        np.savez_compressed(GOLD / f"unet_two_{tag}.npz", out=ref.numpy().astype(np.float32), out_stats=stats(ref),
+                            skip_stats=np.stack([stats(s) for s in taps["skips"]]), motion_stats=np.stack([stats(s) for s in taps["motion"]]),
+                            mid_stats=stats(taps["mid"]), oracle_relerr=e)
+    print("golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()

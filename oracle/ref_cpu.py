@@ -1,0 +1,523 @@
+"""CPU oracle: fp32 PyTorch restatement of MotionEditor's two-branch DDIM denoising step.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` may import this module; the product path (``motioneditor_amd``) never does and
+fails loudly when its HIP library is missing.
+
+Every function cites the reference file:line it follows (paths relative to ``/root/reference``).
+The restatement is *functional*: weights live in a flat ``dict`` keyed by the reference's own
+state-dict names (``SURVEY.md §8b``), activations keep the reference layout ``[b, c, f, h, w]``.
+
+Pinning status (``SURVEY.md §8c``):
+  * UNet3D, ControlAdapter, both attention editors: pinned against the reference's own modules,
+    imported in the build container through ``oracle/shim`` by ``oracle/make_golden.py``; vectors in
+    ``tests/golden/``.
+  * GEGLU / FeedForward / Timesteps / TimestepEmbedding / DDIMScheduler / ControlNetModel live in
+    diffusers==0.15.1 (``requirements.txt:1``), whose source is NOT under ``/root/reference`` and
+    which the reference never tests: **parity unpinned** for those rows.  They are restated from
+    the published definitions; DDIM is additionally pinned by the reference's in-tree restatement
+    ``motion_editor/util.py:77-87`` and ``motion_editor/p2p/null_text_optimization.py:26-36``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+HEADS = 8  # models/unet_2d_condition.py:206 passes attention_head_dim=8 as the head COUNT
+
+
+# --------------------------------------------------------------------------------------------
+# small helpers
+# --------------------------------------------------------------------------------------------
+def _lin(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _split_heads(t: torch.Tensor, heads: int) -> torch.Tensor:
+    """[B, n, H*dh] -> [B*H, n, dh]  (attention_2d.py:95-100)."""
+    b, n, c = t.shape
+    return t.reshape(b, n, heads, c // heads).permute(0, 2, 1, 3).reshape(b * heads, n, c // heads)
+
+
+def _merge_heads(t: torch.Tensor, heads: int) -> torch.Tensor:
+    """[B*H, n, dh] -> [B, n, H*dh]  (attention_2d.py:102-107)."""
+    bh, n, d = t.shape
+    return t.reshape(bh // heads, heads, n, d).permute(0, 2, 1, 3).reshape(bh // heads, n, d * heads)
+
+
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(dh) + bias) v on [B*H, n, dh] tensors.
+
+    This is both ``CrossAttention._attention`` (attention_2d.py:172-201, baddbmm/softmax/bmm) and the
+    semantics of ``xformers.ops.memory_efficient_attention`` (attention_2d.py:246-253)."""
+    scale = q.shape[-1] ** -0.5
+    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(1, 2), beta=0, alpha=scale)
+    if bias is not None:
+        s = s + bias
+    return torch.bmm(s.softmax(dim=-1), v)
+
+
+# --------------------------------------------------------------------------------------------
+# R2: timestep embedding (diffusers Timesteps + TimestepEmbedding; called unet_2d_condition.py:432-438)
+# --------------------------------------------------------------------------------------------
+def timestep_sinusoid(t: torch.Tensor, dim: int = 320) -> torch.Tensor:
+    """diffusers ``get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)``."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+def time_embed(sd: SD, p: str, t: torch.Tensor) -> torch.Tensor:
+    e = timestep_sinusoid(t)
+    return _lin(sd, p + "time_embedding.linear_2", F.silu(_lin(sd, p + "time_embedding.linear_1", e)))
+
+
+# --------------------------------------------------------------------------------------------
+# R3/R5/R6: convolutions (resnet_2d.py:10-36, 39-125)
+# --------------------------------------------------------------------------------------------
+def inflated_conv(sd: SD, p: str, x: torch.Tensor, stride: int = 1, padding: int = 1) -> torch.Tensor:
+    """InflatedConv3d: per-frame Conv2d on "(b f) c h w" (resnet_2d.py:28-36)."""
+    b, c, f, h, w = x.shape
+    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w), sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+    return y.reshape(b, f, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def temporal_conv(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """TemporalConv: Conv1d(k=3, pad=1) over f on "(b h w) c f" (resnet_2d.py:10-26)."""
+    b, c, f, h, w = x.shape
+    y = F.conv1d(x.permute(0, 3, 4, 1, 2).reshape(b * h * w, c, f), sd[p + ".weight"], sd[p + ".bias"], padding=sd[p + ".weight"].shape[-1] // 2)
+    return y.reshape(b, h, w, c, f).permute(0, 3, 4, 1, 2)
+
+
+def upsample_nearest_2x(x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(scale_factor=[1,2,2], mode="nearest") (resnet_2d.py:77)."""
+    return x.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
+
+
+# --------------------------------------------------------------------------------------------
+# R4: ResnetBlock2D (resnet_2d.py:199-249).  GroupNorm runs on the 5-D tensor, so its statistics
+# span (C/32)*f*h*w -- across ALL frames (resnet_2d.py:202,230).
+# --------------------------------------------------------------------------------------------
+def resnet_block(sd: SD, p: str, x: torch.Tensor, temb: torch.Tensor, eps: float = 1e-5, temporal: bool = True) -> torch.Tensor:
+    h = F.group_norm(x, 32, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], eps)
+    h = inflated_conv(sd, p + ".conv1", F.silu(h))
+    if temporal and (p + ".temp_conv1.weight") in sd:
+        h = h + temporal_conv(sd, p + ".temp_conv1", h)
+    h = h + _lin(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None, None]
+    h = F.group_norm(h, 32, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], eps)
+    h = inflated_conv(sd, p + ".conv2", F.silu(h))
+    if temporal and (p + ".temp_conv2.weight") in sd:
+        h = h + temporal_conv(sd, p + ".temp_conv2", h)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = inflated_conv(sd, p + ".conv_shortcut", x, padding=0)
+    return x + h  # output_scale_factor == 1.0
+
+
+# --------------------------------------------------------------------------------------------
+# Editors (attn_control/*).  Restated as small state machines + the attention they compute.
+# --------------------------------------------------------------------------------------------
+class _EditorBase:
+    """Layer/step counter of MutualAttentionBase / TemporalAttentionBase
+    (fully_control_utils.py:29-46, temporal_control_utils.py:27-44)."""
+
+    def __init__(self, start_step=4, start_layer=10, layer_idx=None, step_idx=None, total_steps=50, total_layers=16):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+        self.num_att_layers = -1
+        self.layer_idx = list(layer_idx) if layer_idx is not None else list(range(start_layer, total_layers))
+        self.step_idx = list(step_idx) if step_idx is not None else list(range(start_step, total_steps))
+
+    def _tick(self):
+        self.cur_att_layer += 1
+        if self.cur_att_layer == self.num_att_layers:
+            self.cur_att_layer = 0
+            self.cur_step += 1
+
+    def reset(self):
+        self.cur_step = 0
+        self.cur_att_layer = 0
+
+
+class SpatialEditor(_EditorBase):
+    """FullySelfAttentionControlMask (fully_control.py:331-460) with target_masks=None."""
+
+    def __init__(self, source_masks: torch.Tensor, **kw):
+        super().__init__(**kw)
+        self.num_att_layers = 32
+        # fully_control.py:366-368: "b f c h w -> b c f h w"
+        self.source_masks = source_masks.permute(0, 2, 1, 3, 4).float()
+
+    def active(self, is_cross: bool) -> bool:
+        # fully_control.py:434
+        return (not is_cross) and self.cur_step in self.step_idx and (self.cur_att_layer // 2) in self.layer_idx
+
+    def masked_kv(self, k: torch.Tensor, v: torch.Tensor, N: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """attn_batch(is_mask_attn=True) (fully_control.py:372-413).  k, v: [(f*H), 4N, dh] =
+        [src prev | src cur | edit prev | edit cur].  Returns the 5N-key K and V.
+
+        The reference rearranges the (frame, head)-ordered rows with a hard-coded num_frames=8
+        (fully_control.py:377,393), so row r is multiplied by mask frame r % 8 == head index."""
+        nf = 8
+        Hs = int(math.isqrt(N))
+        assert Hs * Hs == N and k.shape[0] % nf == 0
+        m = F.interpolate(self.source_masks, (nf, Hs, Hs), mode="nearest")  # [1,1,8,Hs,Hs]
+        prev_idx = torch.arange(nf) - 1
+        prev_idx[0] = 0
+        m_prev, m_cur = m[:, :, prev_idx], m
+
+        def mul(part: torch.Tensor, mk: torch.Tensor) -> torch.Tensor:
+            rows, _, dh = part.shape
+            t = part.reshape(rows // nf, nf, Hs, Hs, dh).permute(0, 4, 1, 2, 3)  # b c f h w
+            t = t * mk
+            return t.permute(0, 2, 3, 4, 1).reshape(rows, N, dh)
+
+        ks = k[:, : 2 * N]
+        k_fg = torch.cat([mul(ks[:, :N], m_prev), mul(ks[:, N:], m_cur)], dim=1)
+        k_bg = torch.cat([mul(ks[:, :N], 1 - m_prev), mul(ks[:, N:], 1 - m_cur)], dim=1)
+        k5 = torch.cat([k_fg, k_bg, k[:, 3 * N:]], dim=1)
+        v5 = torch.cat([v[:, : 2 * N], v[:, : 2 * N], v[:, 3 * N:]], dim=1)
+        return k5, v5
+
+    def __call__(self, q, k, v, is_cross: bool) -> torch.Tensor:
+        """q: [B*f*H, N, dh]; k, v: [B*f*H, Nk, dh] (already prev|cur gathered for self).  Returns [B*f, N, C]."""
+        if not self.active(is_cross):
+            out = _merge_heads(sdpa(q, k, v), HEADS)  # fully_control_utils.py:48-66
+        else:
+            N = q.shape[1]
+            qs, ks, vs = q.chunk(4), k.chunk(4), v.chunk(4)  # [u.rec, u.edit, c.rec, c.edit]
+            outs = []
+            for i in range(4):
+                if i % 2 == 0:  # reconstruction rows: own keys (fully_control.py:442-443)
+                    outs.append(_merge_heads(sdpa(qs[i], ks[i], vs[i]), HEADS))
+                else:           # editing rows: [src | edit] -> 5N masked keys (fully_control.py:444-447)
+                    k5, v5 = self.masked_kv(torch.cat([ks[i - 1], ks[i]], 1), torch.cat([vs[i - 1], vs[i]], 1), N)
+                    outs.append(_merge_heads(sdpa(qs[i], k5, v5), HEADS))
+            out = torch.cat(outs, dim=0)
+        self._tick()
+        return out
+
+
+class TemporalEditor(_EditorBase):
+    """TemporalSelfAttentionControl (temporal_control.py:26-89)."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.num_att_layers = 16
+
+    def active(self) -> bool:
+        return self.cur_step in self.step_idx and self.cur_att_layer in self.layer_idx  # temporal_control.py:74
+
+    def __call__(self, q, k, v, bias) -> torch.Tensor:
+        """q,k,v: [(B*N*H), f, dh], rows ordered (branch-batch, pixel, head)."""
+        if self.active():
+            qs, ks, vs = q.chunk(4), list(k.chunk(4)), list(v.chunk(4))
+            ks[1], vs[1], ks[3], vs[3] = ks[0], vs[0], ks[2], vs[2]  # edit Q attends recon K,V (temporal_control.py:82-85)
+            out = torch.cat([sdpa(qs[i], ks[i], vs[i], bias) for i in range(4)], dim=0)
+        else:
+            out = sdpa(q, k, v, bias)
+        self._tick()
+        return _merge_heads(out, HEADS)
+
+
+# --------------------------------------------------------------------------------------------
+# R7-R12: Transformer2DModel / BasicTransformerBlock (attention_2d.py:338-389, 493-547)
+# --------------------------------------------------------------------------------------------
+def _prev_cur_gather(t: torch.Tensor, f: int) -> torch.Tensor:
+    """[B*f, N, C] -> [B*f, 2N, C] keys = [frame max(i-1,0) | frame i] (attention_2d.py:732-740)."""
+    bf, n, c = t.shape
+    t = t.reshape(bf // f, f, n, c)
+    prev = torch.arange(f) - 1
+    prev[0] = 0
+    return torch.cat([t[:, prev], t], dim=2).reshape(bf, 2 * n, c)
+
+
+def _first_prev_gather(t: torch.Tensor, f: int) -> torch.Tensor:
+    """keys = [frame 0 | frame max(i-1,0)] within chunks of f frames (controlnet_adapter.py:352-361)."""
+    bf, n, c = t.shape
+    t = t.reshape(bf // f, f, n, c)
+    prev = torch.arange(f) - 1
+    prev[0] = 0
+    return torch.cat([t[:, [0] * f], t[:, prev]], dim=2).reshape(bf, 2 * n, c)
+
+
+def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """diffusers FeedForward(geglu): Linear(C,8C) -> a*gelu_erf(g) -> Linear(4C,C)."""
+    a, g = _lin(sd, p + ".net.0.proj", x).chunk(2, dim=-1)
+    return _lin(sd, p + ".net.2", a * F.gelu(g))
+
+
+def causal_bias(f: int) -> torch.Tensor:
+    """(1 - tril) * -10000, shape [1,f,f] (attention_2d.py:542-543)."""
+    return (1.0 - torch.tril(torch.ones(f, f)))[None] * -10000.0
+
+
+def basic_block(sd: SD, p: str, x: torch.Tensor, ehs: Optional[torch.Tensor], f: int,
+                spatial: Optional[SpatialEditor], temporal: Optional[TemporalEditor],
+                sc_attn: bool = True, has_temp: bool = True) -> torch.Tensor:
+    """x: [B*f, N, C]; ehs: [B*f, 77, 768] (already repeated per frame, attention_2d.py:343)."""
+    # attn1: MotionFrameAttention.forward_sc_attn (attention_2d.py:705-768) or the patched closure
+    # (fully_control_utils.py:113-161)
+    n1 = F.layer_norm(x, x.shape[-1:], sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
+    q = _split_heads(_lin(sd, p + ".attn1.to_q", n1), HEADS)
+    k, v = _lin(sd, p + ".attn1.to_k", n1), _lin(sd, p + ".attn1.to_v", n1)
+    if sc_attn:
+        k, v = _prev_cur_gather(k, f), _prev_cur_gather(v, f)
+    k, v = _split_heads(k, HEADS), _split_heads(v, HEADS)
+    a = spatial(q, k, v, False) if spatial is not None else _merge_heads(sdpa(q, k, v), HEADS)
+    x = _lin(sd, p + ".attn1.to_out.0", a) + x
+    # attn2: CrossAttention (attention_2d.py:115-201) / closure (fully_control_utils.py:162-206)
+    if ehs is not None:
+        n2 = F.layer_norm(x, x.shape[-1:], sd[p + ".norm2.weight"], sd[p + ".norm2.bias"])
+        q = _split_heads(_lin(sd, p + ".attn2.to_q", n2), HEADS)
+        k = _split_heads(_lin(sd, p + ".attn2.to_k", ehs), HEADS)
+        v = _split_heads(_lin(sd, p + ".attn2.to_v", ehs), HEADS)
+        a = spatial(q, k, v, True) if spatial is not None else _merge_heads(sdpa(q, k, v), HEADS)
+        x = _lin(sd, p + ".attn2.to_out.0", a) + x
+    # feed-forward (attention_2d.py:531)
+    x = feed_forward(sd, p + ".ff", F.layer_norm(x, x.shape[-1:], sd[p + ".norm3.weight"], sd[p + ".norm3.bias"])) + x
+    # temporal attention (attention_2d.py:534-545; TemporalSelfAttention temporal_attn.py:95-181)
+    if has_temp:
+        bf, n, c = x.shape
+        xt = x.reshape(bf // f, f, n, c).permute(0, 2, 1, 3).reshape(bf // f * n, f, c)  # "(b f) d c -> (b d) f c"
+        nt = F.layer_norm(xt, (c,), sd[p + ".norm_temp.weight"], sd[p + ".norm_temp.bias"])
+        q = _split_heads(_lin(sd, p + ".attn_temp.to_q", nt), HEADS)
+        k = _split_heads(_lin(sd, p + ".attn_temp.to_k", nt), HEADS)
+        v = _split_heads(_lin(sd, p + ".attn_temp.to_v", nt), HEADS)
+        a = temporal(q, k, v, causal_bias(f)) if temporal is not None else _merge_heads(sdpa(q, k, v, causal_bias(f)), HEADS)
+        xt = _lin(sd, p + ".attn_temp.to_out.0", a) + xt
+        x = xt.reshape(bf // f, n, f, c).permute(0, 2, 1, 3).reshape(bf, n, c)
+    return x
+
+
+def transformer2d(sd: SD, p: str, x: torch.Tensor, ehs: Optional[torch.Tensor],
+                  spatial=None, temporal=None, sc_attn: bool = True, has_temp: bool = True) -> torch.Tensor:
+    """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GN(32, eps 1e-6), 1x1 proj."""
+    b, c, f, h, w = x.shape
+    xi = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    e = ehs.repeat_interleave(f, dim=0) if ehs is not None else None  # 'b n c -> (b f) n c'
+    t = F.group_norm(xi, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    t = F.conv2d(t, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    t = t.permute(0, 2, 3, 1).reshape(b * f, h * w, c)
+    t = basic_block(sd, p + ".transformer_blocks.0", t, e, f, spatial, temporal, sc_attn, has_temp)
+    t = t.reshape(b * f, h, w, c).permute(0, 3, 1, 2)
+    t = F.conv2d(t, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]) + xi
+    return t.reshape(b, f, c, h, w).permute(0, 2, 1, 3, 4)
+
+
+# --------------------------------------------------------------------------------------------
+# R15: ControlAdapter (controlnet_adapter.py:437-565)
+# --------------------------------------------------------------------------------------------
+ADAPTER_CHUNK = 8  # hard-coded num_frames=8 (controlnet_adapter.py:414,438,472)
+
+
+def adapter_block(sd: SD, p: str, x: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """ResnetBlock.forward (controlnet_adapter.py:497-534).  x: ControlNet residual [b,C,t,h,w];
+    src: UNet edit-branch skip [b,C,t,h,w].  Returns [(b t), C, h, w] reshaped to [b,C,t,h,w]."""
+    b, c, t, hh, ww = x.shape
+    assert t % ADAPTER_CHUNK == 0
+    n = hh * ww
+    # conv path: block1 (TemporalConv k=3) -> ReLU -> block2 (TemporalConv k=1) -> + x, on chunks of 8 frames
+    xc = x.permute(0, 2, 1, 3, 4).reshape(b * t // ADAPTER_CHUNK, ADAPTER_CHUNK, c, hh, ww).permute(0, 2, 1, 3, 4)
+    hc = temporal_conv(sd, p + ".block1", xc)
+    hc = temporal_conv(sd, p + ".block2", F.relu(hc)) + xc
+    hc = hc.permute(0, 2, 1, 3, 4).reshape(b, t, c, hh, ww).permute(0, 2, 1, 3, 4)
+    # attention path
+    xa = x.permute(0, 2, 3, 4, 1).reshape(b * t, n, c)  # "(b f) (h w) c"
+    na = F.layer_norm(xa, (c,), sd[p + ".norm_temp.weight"], sd[p + ".norm_temp.bias"])
+    q = _split_heads(_lin(sd, p + ".attn_temp.to_q", na), HEADS)
+    k = _split_heads(_first_prev_gather(_lin(sd, p + ".attn_temp.to_k", na), ADAPTER_CHUNK), HEADS)
+    v = _split_heads(_first_prev_gather(_lin(sd, p + ".attn_temp.to_v", na), ADAPTER_CHUNK), HEADS)
+    a = _lin(sd, p + ".attn_temp.to_out.0", _merge_heads(sdpa(q, k, v), HEADS)) + xa
+    a = F.layer_norm(a, (c,), sd[p + ".cross_pose_norm.weight"], sd[p + ".cross_pose_norm.bias"])  # replaces the stream (:518)
+    s = src.permute(0, 2, 3, 4, 1).reshape(b * t, n, c)
+    q = _split_heads(_lin(sd, p + ".attn_pose.to_q", a), HEADS)
+    k = _split_heads(_lin(sd, p + ".attn_pose.to_k", s), HEADS)
+    v = _split_heads(_lin(sd, p + ".attn_pose.to_v", s), HEADS)
+    a = _lin(sd, p + ".attn_pose.to_out.0", _merge_heads(sdpa(q, k, v), HEADS)) + a
+    a = feed_forward(sd, p + ".ff", F.layer_norm(a, (c,), sd[p + ".ff_norm.weight"], sd[p + ".ff_norm.bias"])) + a
+    at = a.reshape(b, t, n, c).permute(0, 2, 1, 3).reshape(b * n, t, c)  # "(b f) d c -> (b d) f c" with the TRUE t
+    nt = F.layer_norm(at, (c,), sd[p + ".norm_self_temp.weight"], sd[p + ".norm_self_temp.bias"])
+    q = _split_heads(_lin(sd, p + ".attn_self_temp.to_q", nt), HEADS)
+    k = _split_heads(_lin(sd, p + ".attn_self_temp.to_k", nt), HEADS)
+    v = _split_heads(_lin(sd, p + ".attn_self_temp.to_v", nt), HEADS)
+    at = _lin(sd, p + ".attn_self_temp.to_out.0", _merge_heads(sdpa(q, k, v, causal_bias(t)), HEADS)) + at
+    a = at.reshape(b, n, t, c).permute(0, 2, 1, 3)  # b t n c
+    a = a.reshape(b, t, hh, ww, c).permute(0, 4, 1, 2, 3)
+    return a + hc
+
+
+def adapter_forward(sd: SD, p: str, ctrl: Sequence[torch.Tensor], src: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """ControlAdapter.forward (controlnet_adapter.py:554-565)."""
+    return [adapter_block(sd, f"{p}body.{i}", ctrl[i], src[i]) for i in range(12)]
+
+
+# --------------------------------------------------------------------------------------------
+# R1: UNet2DConditionModel.forward (unet_2d_condition.py:363-546)
+# --------------------------------------------------------------------------------------------
+DOWN_HAS_ATTN = (True, True, True, False)
+UP_HAS_ATTN = (False, True, True, True)
+
+
+def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
+                 down_res: Optional[Sequence[torch.Tensor]] = None, mid_res: Optional[torch.Tensor] = None,
+                 spatial: Optional[SpatialEditor] = None, temporal: Optional[TemporalEditor] = None,
+                 taps: Optional[dict] = None) -> torch.Tensor:
+    B = sample.shape[0]
+    tt = torch.as_tensor(t).reshape(-1).expand(B)
+    emb = time_embed(sd, "", tt)
+    x = inflated_conv(sd, "conv_in", sample)
+    skips = [x]
+    for i in range(4):
+        for j in range(2):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, emb)
+            if DOWN_HAS_ATTN[i]:
+                x = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal)
+            skips.append(x)
+        if i < 3:
+            x = inflated_conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+            skips.append(x)
+    if taps is not None:
+        taps["skips"] = [s.clone() for s in skips]
+    if down_res is not None:
+        if mid_res.shape[0] == 4:  # two-branch (unet_2d_condition.py:478-481)
+            src = [s[[1, 3]] for s in skips]
+            mot = adapter_forward(sd, "controlnet_adapter.", down_res, src)
+            add = []
+            for m in mot:
+                z = torch.zeros_like(m[:1])
+                add.append(torch.cat([z, m[0:1], z, m[1:2]], dim=0))
+        else:                      # (unet_2d_condition.py:482-485)
+            add = adapter_forward(sd, "controlnet_adapter.", down_res, skips)
+        if taps is not None:
+            taps["motion"] = [a.clone() for a in add]
+        skips = [s + a for s, a in zip(skips, add)]
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb)
+    x = transformer2d(sd, "mid_block.attentions.0", x, ehs, spatial, temporal)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb)
+    if mid_res is not None:
+        x = x + mid_res
+    if taps is not None:
+        taps["mid"] = x.clone()
+    for i in range(4):
+        for j in range(3):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, emb)
+            if UP_HAS_ATTN[i]:
+                x = transformer2d(sd, f"up_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal)
+        if i < 3:
+            x = inflated_conv(sd, f"up_blocks.{i}.upsamplers.0.conv", upsample_nearest_2x(x))
+    x = F.silu(F.group_norm(x, 32, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], 1e-5))
+    return inflated_conv(sd, "conv_out", x)
+
+
+# --------------------------------------------------------------------------------------------
+# R16: ControlNetModel.forward (diffusers 0.15.1 -- NOT in the reference tree; parity unpinned).
+# Restated from the published SD-1.5 ControlNet architecture.  It is 2-D:
+# every frame is an independent image, so it reuses the blocks above with f=1, no temporal layers
+# and plain N-key self attention.
+# --------------------------------------------------------------------------------------------
+def controlnet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor, cond: torch.Tensor,
+                       scale: float = 1.0) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    """sample [n,4,h,w], ehs [n,77,768], cond [n,3,8h,8w] -> 12 down residuals + mid residual (4-D)."""
+    n = sample.shape[0]
+    emb = time_embed(sd, "", torch.as_tensor(t).reshape(-1).expand(n))
+    c = F.silu(F.conv2d(cond, sd["controlnet_cond_embedding.conv_in.weight"], sd["controlnet_cond_embedding.conv_in.bias"], padding=1))
+    for i in range(6):
+        c = F.silu(F.conv2d(c, sd[f"controlnet_cond_embedding.blocks.{i}.weight"], sd[f"controlnet_cond_embedding.blocks.{i}.bias"],
+                            padding=1, stride=2 if i % 2 == 1 else 1))
+    c = F.conv2d(c, sd["controlnet_cond_embedding.conv_out.weight"], sd["controlnet_cond_embedding.conv_out.bias"], padding=1)
+    x = (F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1) + c)[:, :, None]  # [n,C,1,h,w]
+    outs = [x]
+    for i in range(4):
+        for j in range(2):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, emb, temporal=False)
+            if DOWN_HAS_ATTN[i]:
+                x = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", x, ehs, None, None, sc_attn=False, has_temp=False)
+            outs.append(x)
+        if i < 3:
+            x = inflated_conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+            outs.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, temporal=False)
+    x = transformer2d(sd, "mid_block.attentions.0", x, ehs, None, None, sc_attn=False, has_temp=False)
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, temporal=False)
+    down = [inflated_conv(sd, f"controlnet_down_blocks.{i}", o, padding=0)[:, :, 0] * scale for i, o in enumerate(outs)]
+    mid = inflated_conv(sd, "controlnet_mid_block", x, padding=0)[:, :, 0] * scale
+    return down, mid
+
+
+# --------------------------------------------------------------------------------------------
+# R17: DDIM (diffusers DDIMScheduler with the SD-1.5 scheduler_config; formula pinned in-tree by
+# util.py:77-87 and p2p/null_text_optimization.py:26-36)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class DDIM:
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.00085
+    beta_end: float = 0.012
+    steps_offset: int = 1
+    num_inference_steps: int = 50
+    alphas_cumprod: torch.Tensor = field(init=False)
+    timesteps: List[int] = field(init=False)
+
+    def __post_init__(self):
+        betas = torch.linspace(self.beta_start ** 0.5, self.beta_end ** 0.5, self.num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.set_timesteps(self.num_inference_steps)
+
+    def set_timesteps(self, n: int):
+        self.num_inference_steps = n
+        ratio = self.num_train_timesteps // n
+        self.timesteps = [int(i * ratio) + self.steps_offset for i in range(n)][::-1]
+
+    def coeffs(self, t: int) -> Tuple[float, float]:
+        """prev = ca * x + cb * eps  (eta = 0, clip_sample False, set_alpha_to_one False)."""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else float(self.alphas_cumprod[0])
+        ca = (a_p / a_t) ** 0.5
+        cb = (1 - a_p) ** 0.5 - (a_p * (1 - a_t) / a_t) ** 0.5
+        return ca, cb
+
+    def step(self, eps: torch.Tensor, t: int, x: torch.Tensor) -> torch.Tensor:
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.alphas_cumprod[0]
+        x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+
+
+# --------------------------------------------------------------------------------------------
+# P1: one denoising step (pipeline_motion_editor.py:603-648)
+# --------------------------------------------------------------------------------------------
+def denoise_step(unet_sd: SD, cn_sd: Optional[SD], ddim: DDIM, latents: torch.Tensor, t: int,
+                 uncond: torch.Tensor, cond: torch.Tensor, ctrl_images: Optional[torch.Tensor],
+                 spatial: Optional[SpatialEditor], temporal: Optional[TemporalEditor],
+                 guidance: float = 7.5, taps: Optional[dict] = None) -> torch.Tensor:
+    """latents [2,4,f,h,w]; uncond [1,77,768] (this step's null embedding); cond [2,77,768];
+    ctrl_images [2f,3,8h,8w] (pipeline :418-459,556-570)."""
+    f = latents.shape[2]
+    x = torch.cat([latents] * 2)                                  # :605
+    emb = torch.cat([uncond.expand(*cond.shape), cond])           # :608-609
+    down = mid = None
+    if cn_sd is not None:
+        ci = x[[1, 3]].permute(0, 2, 1, 3, 4).reshape(2 * f, *x.shape[1:2], *x.shape[3:])  # :613-614
+        pe = emb[[1, 3]].repeat(f, 1, 1)                          # :615,621 (tiles [e1,e3,e1,e3,...])
+        d, m = controlnet_forward(cn_sd, ci, t, pe, ctrl_images)
+        down = [r.reshape(2, f, *r.shape[1:]).permute(0, 2, 1, 3, 4) for r in d]           # :626
+        m = m.reshape(2, f, *m.shape[1:]).permute(0, 2, 1, 3, 4)
+        z = torch.zeros_like(m[:1])
+        mid = torch.cat([z, m[0:1], z, m[1:2]], dim=0)            # :628-629
+        if taps is not None:
+            taps["cn_down"], taps["cn_mid"] = down, mid
+    eps = unet_forward(unet_sd, x, t, emb, down, mid, spatial, temporal, taps)             # :632-640
+    eu, ec = eps.chunk(2)
+    eps = eu + guidance * (ec - eu)                               # :643-645
+    if taps is not None:
+        taps["noise_pred"] = eps
+    return ddim.step(eps, t, latents)                             # :648
