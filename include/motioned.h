@@ -69,7 +69,10 @@ typedef struct me_gemm_args {
   int32_t ldrv, rows_per_vec;
   const void* res;    /* fp16 [M, ldr]: += res[m, n]                           */
   int32_t ldr;
+  const void* res2;   /* second residual, fp16 [M, ldr2]                       */
+  int32_t ldr2;
   int32_t geglu;      /* 1: W rows interleaved (16 a-rows, 16 gate-rows); C gets N/2 columns a*gelu(g) */
+  int32_t act;        /* applied after bias+rowvec, before residuals: 0 none, 1 ReLU, 2 SiLU */
   float alpha;        /* scale applied to the accumulator before the epilogue adds */
 } me_gemm_args;
 
@@ -114,7 +117,8 @@ typedef struct me_attn_args {
   int32_t ldq, ldk, ldv, ldo;
   int32_t heads, dh; /* dh in {40, 80, 160} */
   int32_t n_items, nq, nk, nseg; /* nseg in 1..3 */
-  const int32_t* seg_item; /* device int32 [n_items][nseg]: kv item index of each segment */
+  const int32_t* seg_item; /* device int32 [n_items][nseg]: kv item index of each segment; a negative
+                              entry ends the item's segment list (skipped segments must come last) */
   const int32_t* seg_mode; /* device int32 [n_items][nseg]: ME_SEG_*                       */
   const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL modes)              */
   float scale;

@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
         ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
         ("frames", _i32), ("npix", _i32), ("chunk", _i32),
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
-        ("res", _vp), ("ldr", _i32), ("geglu", _i32), ("alpha", _f32),
+        ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32),
     ]
 
 

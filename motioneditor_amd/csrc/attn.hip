@@ -80,7 +80,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
   }
 
   const int ntk = (a.nk + KT - 1) / KT;
-  const int T = a.nseg * ntk;
+  int nvalid = 0;  // segments before the first negative entry
+  for (int sgi = 0; sgi < a.nseg; ++sgi) {
+    if (a.seg_item[item * a.nseg + sgi] < 0) break;
+    ++nvalid;
+  }
+  const int T = nvalid * ntk;
   const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
   uint4 rk[NLD], rv[NLD];
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  gload(0);
+  if (T > 0) gload(0);
   for (int ti = 0; ti < T; ++ti) {
     __syncthreads();
     sstore(ti);

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
+  const f16* res2 = reinterpret_cast<const f16*>(a.res2);
   f16* C = reinterpret_cast<f16*>(a.C);
   const int nq = (lane >> 4) * 4;
 
@@ -207,9 +208,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
         }
+        if (a.act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else if (a.act == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
         if (res) {
           U64 b;
           b.u = *reinterpret_cast<const uint2*>(res + (long)m * a.ldr + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+        }
+        if (res2) {
+          U64 b;
+          b.u = *reinterpret_cast<const uint2*>(res2 + (long)m * a.ldr2 + n);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
         }
@@ -289,8 +303,10 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   }
   if (a->rowvec && (a->rows_per_vec <= 0 || a->ldrv % 4 || ((uintptr_t)a->rowvec & 7))) { me_set_error("me_gemm: bad rowvec"); return ME_EINVAL; }
   if (a->res && (a->ldr % 4 || ((uintptr_t)a->res & 7))) { me_set_error("me_gemm: bad residual"); return ME_EINVAL; }
+  if (a->res2 && (a->ldr2 % 4 || ((uintptr_t)a->res2 & 7))) { me_set_error("me_gemm: bad second residual"); return ME_EINVAL; }
+  if (a->act < 0 || a->act > 2) { me_set_error("me_gemm: bad activation"); return ME_EINVAL; }
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
-  if (a->geglu && (a->N % 32 || a->rowvec || a->res)) { me_set_error("me_gemm: geglu needs N % 32 == 0 and no rowvec/res"); return ME_EINVAL; }
+  if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act)) { me_set_error("me_gemm: geglu needs N % 32 == 0 and no rowvec/res/act"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->N % 128 == 0 || a->N % 64 != 0) return launch_gemm<128>(a, st);
   return launch_gemm<64>(a, st);

@@ -1,0 +1,393 @@
+"""Host-side launch graphs of the denoising step: UNet3D, ControlAdapter and ControlNet expressed as
+sequences of ``libmotioned`` kernel launches on channels-last fp16 activations.
+
+The reference builds the same graphs out of nn.Modules (models/unet_2d_condition.py:363-546,
+models/unet_2d_blocks.py, models/attention_2d.py, models/resnet_2d.py, models/controlnet_adapter.py);
+this file keeps their dataflow and nothing else: no nn.Module, no autograd, no torch arithmetic.
+Row order everywhere is (batch, frame, pixel), so "(b f) c h w", "(b f) (h w) c" and "(b d) f c"
+are the same buffer.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from .. import ops, segments
+from ..weights import Packed
+
+HEADS = 8
+ADAPTER_CHUNK = 8  # hard-coded num_frames=8 in the reference adapter (controlnet_adapter.py:414,438,472)
+
+
+@dataclass
+class Act:
+    """Activation: rows [(B*f*h*w), C] + its logical shape."""
+    t: torch.Tensor
+    B: int
+    f: int
+    h: int
+    w: int
+
+    @property
+    def N(self) -> int:
+        return self.h * self.w
+
+    @property
+    def C(self) -> int:
+        return self.t.shape[1]
+
+    def like(self, t: torch.Tensor, h: Optional[int] = None, w: Optional[int] = None) -> "Act":
+        return Act(t, self.B, self.f, self.h if h is None else h, self.w if w is None else w)
+
+    def rows_of(self, b: int) -> torch.Tensor:
+        n = self.f * self.N
+        return self.t[b * n:(b + 1) * n]
+
+
+@dataclass
+class AttnCall:
+    """What an attention editor receives instead of pre-gathered (B*H, n, dh) tensors: the un-gathered
+    q/k/v row views plus the geometry needed to pick a key-segment table."""
+    q: torch.Tensor
+    k: torch.Tensor
+    v: torch.Tensor
+    B: int
+    f: int
+    N: int
+    dh: int
+    nk: int          # keys per kv item (N for self, 77 for text)
+    is_cross: bool
+
+    def run(self, seg_item: torch.Tensor, seg_mode: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, n_items=self.B * self.f, nq=self.N, nk=self.nk,
+                             seg_item=seg_item, seg_mode=seg_mode, mask=mask)
+
+
+@dataclass
+class TemporalCall:
+    q: torch.Tensor
+    k: torch.Tensor
+    v: torch.Tensor
+    B: int
+    f: int
+    N: int
+    dh: int
+
+    def run(self, kv_map: Optional[Sequence[int]] = None) -> torch.Tensor:
+        return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=self.f, npix=self.N, kv_map=kv_map)
+
+
+# ---------------------------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------------------------
+def conv3x3(P: Packed, name: str, x: Act, stride: int = 1, ups: int = 0, **epi) -> Act:
+    """InflatedConv3d 3x3 pad 1 (resnet_2d.py:28-36); stride-2 = Downsample2D (:94-125); ups=1 folds
+    Upsample2D's nearest-2x (:77) into the gather."""
+    hv, wv = x.h << ups, x.w << ups
+    ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
+    out = ops.gemm(x.t, P.mat(name + ".weight"), M=x.B * x.f * ho * wo, bias=P.vec(name + ".bias"),
+                   conv=(x.h, x.w, ho, wo, stride, ups), **epi)
+    return x.like(out, ho, wo)
+
+
+def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *, per_frame_stats: bool, eps: float = 1e-5) -> Act:
+    """ResnetBlock2D.forward (resnet_2d.py:199-249).  GroupNorm statistics span all frames of a batch row
+    for the 3-D UNet (5-D GroupNorm, :202,230) and one image for the 2-D ControlNet."""
+    rpg = x.N if per_frame_stats else x.f * x.N
+    cout = P.vec(p + ".conv1.bias").shape[0]
+    tv = temb[:, temb_off:temb_off + cout]
+    rows_per_vec = x.t.shape[0] if temb.shape[0] == 1 else x.f * x.N
+    has_t1 = P.has(p + ".temp_conv1.weight") and not P.is_zero(p + ".temp_conv1.weight", p + ".temp_conv1.bias")
+    has_t2 = P.has(p + ".temp_conv2.weight") and not P.is_zero(p + ".temp_conv2.weight", p + ".temp_conv2.bias")
+
+    h = ops.groupnorm(x.t, P.vec(p + ".norm1.weight"), P.vec(p + ".norm1.bias"), rows_per_group=rpg, eps=eps, silu=True)
+    if has_t1:
+        h = conv3x3(P, p + ".conv1", x.like(h)).t
+        # h + temp_conv1(h) + temb  (resnet_2d.py:207-228)
+        h = ops.gemm(h, P.mat(p + ".temp_conv1.weight"), bias=P.vec(p + ".temp_conv1.bias"), tconv=(x.f, x.N, x.f),
+                     rowvec=tv, rows_per_vec=rows_per_vec, res=h)
+    else:
+        h = conv3x3(P, p + ".conv1", x.like(h), rowvec=tv, rows_per_vec=rows_per_vec).t
+    h = ops.groupnorm(h, P.vec(p + ".norm2.weight"), P.vec(p + ".norm2.bias"), rows_per_group=rpg, eps=eps, silu=True)
+    if P.has(p + ".conv_shortcut.weight"):
+        sc = ops.gemm(x.t, P.mat(p + ".conv_shortcut.weight"), bias=P.vec(p + ".conv_shortcut.bias"))
+    else:
+        sc = x.t
+    if has_t2:
+        h = conv3x3(P, p + ".conv2", x.like(h)).t
+        h = ops.gemm(h, P.mat(p + ".temp_conv2.weight"), bias=P.vec(p + ".temp_conv2.bias"), tconv=(x.f, x.N, x.f), res=h, res2=sc)
+    else:
+        h = conv3x3(P, p + ".conv2", x.like(h), res=sc).t
+    return x.like(h)
+
+
+def feed_forward(P: Packed, p: str, n: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """diffusers FeedForward(geglu) + residual: GEGLU fused into the first GEMM's epilogue."""
+    g = ops.gemm(n, P.geglu_mat(p + ".net.0.proj.weight"), bias=P.geglu_vec(p + ".net.0.proj.bias"), geglu=True)
+    return ops.gemm(g, P.mat(p + ".net.2.weight"), bias=P.vec(p + ".net.2.bias"), res=res)
+
+
+def _ln(P: Packed, p: str, x: torch.Tensor) -> torch.Tensor:
+    return ops.layernorm(x, P.vec(p + ".weight"), P.vec(p + ".bias"))
+
+
+def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_seg, *, spatial, temporal, place: str,
+                sc_attn: bool, has_temp: bool) -> Act:
+    """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C]."""
+    t, C = x.t, x.C
+    dh = C // HEADS
+    # --- attn1 (MotionFrameAttention / patched closure, attention_2d.py:705-768, fully_control_utils.py:113-161)
+    qkv = ops.gemm(_ln(P, p + ".norm1", t), P.fused([p + ".attn1.to_q.weight", p + ".attn1.to_k.weight", p + ".attn1.to_v.weight"]))
+    call = AttnCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh, x.N, False)
+    if spatial is not None:
+        a = spatial(call=call, is_cross=False, place_in_unet=place, num_heads=HEADS)
+    elif sc_attn:
+        a = call.run(*segments.prev_cur(x.B, x.f, t.device))
+    else:
+        a = call.run(*segments.self_items(x.B * x.f, t.device))
+    t = ops.gemm(a, P.mat(p + ".attn1.to_out.0.weight"), bias=P.vec(p + ".attn1.to_out.0.bias"), res=t)
+    # --- attn2 (CrossAttention, attention_2d.py:115-201): K/V projected once per text row
+    if text is not None:
+        q = ops.gemm(_ln(P, p + ".norm2", t), P.mat(p + ".attn2.to_q.weight"))
+        kv = ops.gemm(text, P.fused([p + ".attn2.to_k.weight", p + ".attn2.to_v.weight"]))
+        call = AttnCall(q, kv[:, :C], kv[:, C:], x.B, x.f, x.N, dh, 77, True)
+        if spatial is not None:
+            a = spatial(call=call, is_cross=True, place_in_unet=place, num_heads=HEADS, text_seg=text_seg)
+        else:
+            a = call.run(*text_seg)
+        t = ops.gemm(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t)
+    # --- feed-forward (attention_2d.py:531)
+    t = feed_forward(P, p + ".ff", _ln(P, p + ".norm3", t), t)
+    # --- temporal attention over frames, causal (attention_2d.py:534-545)
+    if has_temp:
+        qkv = ops.gemm(_ln(P, p + ".norm_temp", t), P.fused([p + ".attn_temp.to_q.weight", p + ".attn_temp.to_k.weight", p + ".attn_temp.to_v.weight"]))
+        tc = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh)
+        a = temporal(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if temporal is not None else tc.run()
+        t = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
+    return x.like(t)
+
+
+def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, temporal=None, place: str = "", sc_attn: bool = True,
+                  has_temp: bool = True) -> Act:
+    """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out."""
+    n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
+    t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
+    t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
+                    sc_attn=sc_attn, has_temp=has_temp).t
+    return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t))
+
+
+# ---------------------------------------------------------------------------------------------
+# time embedding: sinusoid -> MLP, then EVERY resnet's time_emb_proj in one GEMM
+# ---------------------------------------------------------------------------------------------
+def resnet_names(n_up: bool) -> List[str]:
+    names = [f"down_blocks.{i}.resnets.{j}" for i in range(4) for j in range(2)] + ["mid_block.resnets.0", "mid_block.resnets.1"]
+    if n_up:
+        names += [f"up_blocks.{i}.resnets.{j}" for i in range(4) for j in range(3)]
+    return names
+
+
+def time_embedding(P: Packed, t: float, names: List[str], device):
+    """Timesteps(320, flip_sin_to_cos, shift 0) -> linear_1 -> SiLU -> linear_2 (unet_2d_condition.py:432-438),
+    then SiLU -> concat(time_emb_proj) (resnet_2d.py:211).  One row: every batch entry shares t."""
+    e = ops.timestep_embed(1, 320, t, device)
+    e = ops.gemm(e, P.mat("time_embedding.linear_1.weight"), bias=P.vec("time_embedding.linear_1.bias"), act=2)
+    e = ops.gemm(e, P.mat("time_embedding.linear_2.weight"), bias=P.vec("time_embedding.linear_2.bias"), act=2)  # silu(emb) for the resnets
+    w = P.fused([n + ".time_emb_proj.weight" for n in names])
+    b = P.fused_vec([n + ".time_emb_proj.bias" for n in names])
+    temb = ops.gemm(e, w, bias=b)
+    offs, o = {}, 0
+    for n in names:
+        offs[n] = o
+        o += P.vec(n + ".conv1.bias").shape[0]
+    return temb, offs
+
+
+# ---------------------------------------------------------------------------------------------
+# ControlAdapter (controlnet_adapter.py:437-565)
+# ---------------------------------------------------------------------------------------------
+def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor) -> torch.Tensor:
+    """ResnetBlock.forward (controlnet_adapter.py:497-534).  x: ControlNet residual rows [(b t N), C];
+    src: UNet edit-branch skip rows, same shape.  Returns motion residual rows."""
+    t, C, dev = x.t, x.C, x.t.device
+    dh = C // HEADS
+    nit = x.B * x.f
+    # conv path: TemporalConv(k=3) -> ReLU -> TemporalConv(k=1) -> + x, on independent chunks of 8 frames
+    hc = ops.gemm(t, P.mat(p + ".block1.weight"), bias=P.vec(p + ".block1.bias"), tconv=(x.f, x.N, ADAPTER_CHUNK), act=1)
+    hc = ops.gemm(hc, P.mat(p + ".block2.weight"), bias=P.vec(p + ".block2.bias"), res=t)
+    # sparse-causal self attention inside chunks of 8 frames
+    qkv = ops.gemm(_ln(P, p + ".norm_temp", t), P.fused([p + ".attn_temp.to_q.weight", p + ".attn_temp.to_k.weight", p + ".attn_temp.to_v.weight"]))
+    a = AttnCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh, x.N, False).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev))
+    a = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
+    a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
+    # pose x UNet-feature cross attention, per frame
+    q = ops.gemm(a, P.mat(p + ".attn_pose.to_q.weight"))
+    kv = ops.gemm(src, P.fused([p + ".attn_pose.to_k.weight", p + ".attn_pose.to_v.weight"]))
+    ap = AttnCall(q, kv[:, :C], kv[:, C:], x.B, x.f, x.N, dh, x.N, True).run(*segments.self_items(nit, dev))
+    a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a)
+    a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
+    # causal temporal attention over the TRUE frame count
+    qkv = ops.gemm(_ln(P, p + ".norm_self_temp", a), P.fused([p + ".attn_self_temp.to_q.weight", p + ".attn_self_temp.to_k.weight", p + ".attn_self_temp.to_v.weight"]))
+    at = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh).run()
+    return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc)
+
+
+# ---------------------------------------------------------------------------------------------
+# UNet3D (unet_2d_condition.py:363-546)
+# ---------------------------------------------------------------------------------------------
+DOWN_HAS_ATTN = (True, True, True, False)
+UP_HAS_ATTN = (False, True, True, True)
+
+
+def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
+    """[B, 77, 768] (any float dtype, device) -> fp16 rows [B*77, 768]."""
+    return ehs.to(dtype).reshape(-1, ehs.shape[-1]).contiguous()
+
+
+def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
+                 mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
+                 taps: Optional[dict] = None) -> Act:
+    """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
+    ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
+    Returns eps rows [(B f N), 4] as an Act."""
+    B, _, f, h, w = sample.shape
+    dev = sample.device
+    sample = sample.contiguous().float()
+    temb, toff = time_embedding(P, t, resnet_names(True), dev)
+    text = text_rows(ehs, P.dtype)
+    tseg = segments.cross_text(B, f, dev)
+    kw = dict(spatial=spatial, temporal=temporal)
+
+    x = Act(ops.conv_small(sample, P.mat("conv_in.weight"), P.vec("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
+                           img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
+    skips = [x]
+    for i in range(4):
+        for j in range(2):
+            n = f"down_blocks.{i}.resnets.{j}"
+            x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+            if DOWN_HAS_ATTN[i]:
+                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", **kw)
+            skips.append(x)
+        if i < 3:
+            x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+            skips.append(x)
+    if taps is not None:
+        taps["skips"] = [s.t.clone() for s in skips]
+
+    if down_res is not None:
+        motion = []
+        for i, (s, r) in enumerate(zip(skips, down_res)):
+            if two_branch:   # adapter sees the two edit rows only (unet_2d_condition.py:479-481)
+                n = s.f * s.N
+                src = torch.empty((2 * n, s.C), dtype=P.dtype, device=dev)
+                ops.copy_rows(src[:n], s.rows_of(1))
+                ops.copy_rows(src[n:], s.rows_of(3))
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 2, s.f, s.h, s.w), src))
+            else:            # (unet_2d_condition.py:483-485)
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t))
+        if taps is not None:
+            taps["motion"] = [m.clone() for m in motion]
+        new_skips = []
+        for i, (s, m) in enumerate(zip(skips, motion)):
+            tgt = s
+            if i == len(skips) - 1:  # the last skip is also the mid block's input: keep that one un-modified
+                tgt = s.like(s.t.clone())
+            if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
+                n = s.f * s.N
+                ops.axpy_rows(tgt.rows_of(1), tgt.rows_of(1), m[:n])
+                ops.axpy_rows(tgt.rows_of(3), tgt.rows_of(3), m[n:])
+            else:
+                ops.axpy_rows(tgt.t, tgt.t, m)
+            new_skips.append(tgt)
+        skips = new_skips
+
+    n = "mid_block.resnets.0"
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+    x = transformer2d(P, "mid_block.attentions.0", x, text, tseg, place="mid", **kw)
+    n = "mid_block.resnets.1"
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+    if mid_res is not None:
+        if two_branch:
+            nr = x.f * x.N
+            ops.axpy_rows(x.rows_of(1), x.rows_of(1), mid_res[:nr])
+            ops.axpy_rows(x.rows_of(3), x.rows_of(3), mid_res[nr:])
+        else:
+            ops.axpy_rows(x.t, x.t, mid_res)
+    if taps is not None:
+        taps["mid"] = x.t.clone()
+
+    for i in range(4):
+        for j in range(3):
+            s = skips.pop()
+            cat = torch.empty((x.t.shape[0], x.C + s.C), dtype=P.dtype, device=dev)  # torch.cat([hidden, res], dim=1)
+            ops.copy_rows(cat[:, :x.C], x.t)
+            ops.copy_rows(cat[:, x.C:], s.t)
+            n = f"up_blocks.{i}.resnets.{j}"
+            x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False)
+            if UP_HAS_ATTN[i]:
+                x = transformer2d(P, f"up_blocks.{i}.attentions.{j}", x, text, tseg, place="up", **kw)
+        if i < 3:
+            x = conv3x3(P, f"up_blocks.{i}.upsamplers.0.conv", x, ups=1)
+    y = ops.groupnorm(x.t, P.vec("conv_norm_out.weight"), P.vec("conv_norm_out.bias"), rows_per_group=x.f * x.N, eps=1e-5, silu=True)
+    return conv3x3(P, "conv_out", x.like(y))
+
+
+# ---------------------------------------------------------------------------------------------
+# ControlNet (diffusers 0.15.1 ControlNetModel.forward, called pipeline_motion_editor.py:618-625)
+# ---------------------------------------------------------------------------------------------
+def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int], t: float, prompt: torch.Tensor, cond: torch.Tensor,
+                       scale: float = 1.0):
+    """latents fp32 [nb,4,f,h,w]; lat_index: which latent row each ControlNet batch entry reads (the
+    pipeline feeds rows [1,3] of cat([latents]*2), i.e. the edit latent twice); prompt [n_text,77,768]
+    with the reference's interleave (row r -> text r % n_text); cond fp32/fp16 [(nbc f),3,8h,8w].
+    Returns (12 down residual row tensors [(nbc f N_i), C_i], mid rows), 2-D per-frame semantics."""
+    nb, _, f, h, w = latents.shape
+    nbc = len(lat_index)
+    dev = latents.device
+    nimg = nbc * f
+    latents = latents.contiguous().float()
+    temb, toff = time_embedding(P, t, resnet_names(False), dev)
+    text = text_rows(prompt, P.dtype)
+    tseg = segments.cross_interleaved(nimg, prompt.shape[0], dev)
+
+    # conditioning embedding: 3->16 (direct), then 16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2 (SiLU each), 256->320
+    H8, W8 = cond.shape[-2], cond.shape[-1]
+    cond = cond.contiguous()
+    c = Act(ops.conv_small(cond, P.mat("controlnet_cond_embedding.conv_in.weight"), P.vec("controlnet_cond_embedding.conv_in.bias"),
+                           n_img=nimg, Cin=3, H=H8, Wd=W8, img_stride=3 * H8 * W8, ch_stride=H8 * W8, silu=True), nimg, 1, H8, W8)
+    for i in range(6):
+        c = conv3x3(P, f"controlnet_cond_embedding.blocks.{i}", c, stride=2 if i % 2 == 1 else 1, act=2)
+    # conv_in(sample) per ControlNet batch entry, then + cond embedding in the last cond conv's epilogue
+    x0 = torch.empty((nimg * h * w, 320), dtype=P.dtype, device=dev)
+    for bi, li in enumerate(lat_index):
+        part = ops.conv_small(latents[li], P.mat("conv_in.weight"), P.vec("conv_in.bias"), n_img=f, Cin=4, H=h, Wd=w,
+                              img_stride=h * w, ch_stride=f * h * w)
+        ops.copy_rows(x0[bi * f * h * w:(bi + 1) * f * h * w], part)
+    x = conv3x3(P, "controlnet_cond_embedding.conv_out", c, res=x0)
+    x = Act(x.t, nimg, 1, h, w)
+
+    outs = [x]
+    for i in range(4):
+        for j in range(2):
+            n = f"down_blocks.{i}.resnets.{j}"
+            x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
+            if DOWN_HAS_ATTN[i]:
+                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, sc_attn=False, has_temp=False)
+            outs.append(x)
+        if i < 3:
+            x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+            outs.append(x)
+    n = "mid_block.resnets.0"
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
+    x = transformer2d(P, "mid_block.attentions.0", x, text, tseg, sc_attn=False, has_temp=False)
+    n = "mid_block.resnets.1"
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
+    down = [ops.gemm(o.t, P.mat(f"controlnet_down_blocks.{i}.weight"), bias=P.vec(f"controlnet_down_blocks.{i}.bias"), alpha=1.0)
+            for i, o in enumerate(outs)]
+    mid = ops.gemm(x.t, P.mat("controlnet_mid_block.weight"), bias=P.vec("controlnet_mid_block.bias"))
+    if scale != 1.0:
+        down = [ops.axpy_rows(d, d, d, scale - 1.0) for d in down]
+        mid = ops.axpy_rows(mid, mid, mid, scale - 1.0)
+    return down, mid

@@ -37,7 +37,7 @@ def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
 
 def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
-         res: Optional[torch.Tensor] = None, geglu: bool = False, alpha: float = 1.0,
+         res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
          tconv: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
@@ -82,7 +82,11 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     if res is not None:
         _chk2d(res, "gemm.res")
         a.res, a.ldr = res.data_ptr(), res.stride(0)
+    if res2 is not None:
+        _chk2d(res2, "gemm.res2")
+        a.res2, a.ldr2 = res2.data_ptr(), res2.stride(0)
     a.geglu = 1 if geglu else 0
+    a.act = act
     a.alpha = alpha
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
     return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
@@ -232,4 +236,24 @@ def rows_to_nchw(x: torch.Tensor, n_img: int, Cc: int, npix: int) -> torch.Tenso
     """fp16 rows [(n_img*npix), >=Cc] -> fp32 [n_img, Cc, npix]."""
     out = torch.empty((n_img, Cc, npix), dtype=torch.float32, device=x.device)
     capi.check(capi.lib().me_rows_to_nchw(out.data_ptr(), Cc * npix, npix, x.data_ptr(), x.stride(0), n_img, Cc, npix, _stream()), "me_rows_to_nchw")
+    return out
+
+
+def nchw5_to_rows(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [B, C, f, h, w] (reference layout) -> fp16 rows [(B f h w), C]."""
+    B, Cc, f, h, w = x.shape
+    x = x.contiguous().float()
+    out = torch.empty((B * f * h * w, Cc), dtype=F16, device=x.device)
+    for b in range(B):
+        capi.check(capi.lib().me_nchw_to_rows(out[b * f * h * w:].data_ptr(), out.stride(0), x[b].data_ptr(), h * w, f * h * w, f, Cc, h * w, _stream()),
+                   "me_nchw_to_rows")
+    return out
+
+
+def rows_to_nchw5(rows: torch.Tensor, B: int, Cc: int, f: int, h: int, w: int) -> torch.Tensor:
+    """fp16 rows [(B f h w), >=C] -> fp32 [B, C, f, h, w]."""
+    out = torch.empty((B, Cc, f, h, w), dtype=torch.float32, device=rows.device)
+    for b in range(B):
+        capi.check(capi.lib().me_rows_to_nchw(out[b].data_ptr(), h * w, f * h * w, rows[b * f * h * w:].data_ptr(), rows.stride(0), f, Cc, h * w, _stream()),
+                   "me_rows_to_nchw")
     return out

@@ -1,0 +1,164 @@
+"""Drop-in for the reference ``motion_editor.pipelines.pipeline_motion_editor.MotionEditorPipeline``
+(constructor :70-91, ``__call__`` :505-666).  The denoising loop (:597-654) -- ControlNet on the edit
+rows, one batch-4 UNet3D forward with the content-aware motion adapter and both attention editors,
+classifier-free guidance and the DDIM update -- runs entirely on libmotioned HIP kernels.
+
+Out of scope here: CLIP text encoding, VAE encode/decode, null-text inversion.  With
+no ``text_encoder`` the prompt embeddings are passed as ``text_embeddings=[2,77,768]`` (an extension
+keyword swallowed by the reference's ``**kwargs``); with no ``vae`` use ``output_type="latent"``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from .. import ops
+from ..schedulers import DDIMScheduler
+
+
+@dataclass
+class MotionEditorPipelineOutput:
+    images: torch.Tensor
+
+
+class MotionEditorPipeline:
+    def __init__(self, vae=None, text_encoder=None, tokenizer=None, unet=None, scheduler=None, safety_checker=None, controlnet=None,
+                 feature_extractor=None):
+        if unet is None:
+            raise ValueError("unet is required")
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
+        self.unet, self.controlnet = unet, controlnet
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        if getattr(self.scheduler.config, "clip_sample", False):  # reference forces clip_sample False (:108-119)
+            self.scheduler.config["clip_sample"] = False
+        self.vae_scale_factor = 8
+        self.device = unet.device
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    # ---- reference :374-387 ----
+    def check_inputs(self, prompt, height, width, callback_steps):
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0)):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    # ---- reference :389-416 ----
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=generator[i], dtype=torch.float32) for i in range(batch_size)], dim=0)
+            else:
+                latents = torch.randn(shape, generator=generator, dtype=torch.float32)
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+        return (latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma).contiguous()
+
+    # ---- reference :418-459 (tensor branch only: the harness passes a tensor skeleton) ----
+    def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, do_classifier_free_guidance):
+        if not isinstance(image, torch.Tensor):
+            raise NotImplementedError("PIL inputs are data-prep (out of scope); pass a float tensor in [0,1]")
+        repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
+        image = image.repeat_interleave(repeat_by, dim=0).to(device=device, dtype=dtype)
+        if do_classifier_free_guidance:
+            image = torch.cat([image] * 2)
+        return image
+
+    def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_cfg, negative_prompt, text_embeddings=None):
+        if text_embeddings is not None:
+            return text_embeddings.to(device)
+        if self.text_encoder is None or self.tokenizer is None:
+            raise ValueError("no text_encoder/tokenizer: pass text_embeddings=[len(prompt),77,768] (CLIP encoding is out of scope)")
+        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt").input_ids
+        return self.text_encoder(ids.to(self.text_encoder.device))[0].to(device)
+
+    def decode_latents(self, latents):
+        if self.vae is None:
+            raise ValueError("no vae: call with output_type='latent' (VAE decode is out of scope)")
+        b, c, f, h, w = latents.shape
+        x = (1 / 0.18215) * latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+        video = self.vae.decode(x).sample
+        video = video.reshape(b, f, *video.shape[1:]).permute(0, 2, 1, 3, 4)
+        return ((video / 2 + 0.5).clamp(0, 1)).cpu().float().numpy()
+
+    @torch.no_grad()
+    def denoise_step(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
+                     guidance_scale: float, controlnet_conditioning_scale: float = 1.0, taps: Optional[dict] = None) -> torch.Tensor:
+        """One iteration of the reference loop body (:603-648).  latents fp32 [2,4,f,h,w] = [recon, edit];
+        text_embeddings_input [4,77,768] = [uncond, uncond, cond_recon, cond_edit]."""
+        nb = latents.shape[0]
+        x4 = torch.cat([latents] * 2)                                     # :605 (scale_model_input is the identity for DDIM)
+        down = mid = None
+        two = False
+        if self.controlnet is not None and images is not None:
+            prompt = text_embeddings_input[[1, 3]]                         # :615; .repeat(f,1,1) on "(b f)" rows -> row r reads r % 2 (:621)
+            down, mid = self.controlnet.forward_rows(x4, [1, 3], t, prompt, images, controlnet_conditioning_scale)   # :613-625
+            two = True                                                     # mid residual scattered as [0, m0, 0, m1] (:628-629)
+            if taps is not None:
+                taps["cn_down"], taps["cn_mid"] = [d.clone() for d in down], mid.clone()
+        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps)   # :632-640
+        if taps is not None:
+            taps["eps_rows"] = eps.t.clone()
+        ca, cb = self.scheduler.coeffs(int(t))
+        return ops.cfg_ddim(latents, eps.t, guidance=guidance_scale, ca=ca, cb=cb)         # :643-648
+
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5, negative_prompt=None, num_videos_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "tensor",
+                 return_dict: bool = True, callback: Optional[Callable] = None, callback_steps: Optional[int] = 1,
+                 uncond_embeddings: torch.Tensor = None, null_uncond_ratio: float = 1.0, skeleton=None,
+                 controlnet_conditioning_scale: Union[float, List[float]] = 1.0, num_images_per_prompt: Optional[int] = 1,
+                 source_masks=None, target_masks=None, rectangle_source_masks=None, background_latents=None, **kwargs):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0")
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        device = self._execution_device
+        do_cfg = guidance_scale > 1.0
+        if not do_cfg or batch_size != 2:
+            raise NotImplementedError("the two-branch hot path needs guidance_scale > 1 and prompts = [source, target] (inference.py:296-323)")
+        with_uncond = do_cfg if uncond_embeddings is None else False
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, with_uncond, negative_prompt, kwargs.get("text_embeddings"))
+
+        images = None
+        if self.controlnet is not None:
+            if skeleton is None:
+                raise ValueError("skeleton is required with a ControlNet (pipeline :556)")
+            target = torch.unsqueeze(skeleton[-1], dim=0)                   # :556
+            images = self.prepare_image(target, width, height, 1 * num_images_per_prompt, num_images_per_prompt, device, torch.float32, do_cfg)
+            images = images.reshape(-1, *images.shape[2:]).contiguous()    # "b f c h w -> (b f) c h w" (:570)
+
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = self.scheduler.timesteps
+        latents = self.prepare_latents(batch_size * num_videos_per_prompt, self.unet.in_channels, video_length, height, width,
+                                       torch.float32, device, generator, latents)
+        if uncond_embeddings is not None:
+            assert len(timesteps) == 50 or len(uncond_embeddings) >= len(timesteps)   # :601-602 (start_time = 50)
+        for i, t in enumerate(timesteps):
+            if uncond_embeddings is not None:
+                emb = torch.cat([uncond_embeddings[i].to(device).expand(*text_embeddings.shape), text_embeddings])   # :608-609
+            else:
+                emb = text_embeddings
+            latents = self.denoise_step(latents, t, emb, images, guidance_scale, 1.0)   # the loop hard-codes scale 1.0 (:616)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        if output_type == "latent":
+            out = latents
+        else:
+            out = self.decode_latents(latents)
+            if output_type == "tensor":
+                out = torch.from_numpy(out)
+        return MotionEditorPipelineOutput(images=out) if return_dict else out

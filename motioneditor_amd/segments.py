@@ -1,0 +1,73 @@
+"""Key-segment tables for the fused attention kernel (``me_attn``): for every query item (one frame
+of one batch row) the kv items it attends and how.  Tables are tiny int32 device tensors, built once
+per (pattern, shape) and cached -- the editors' gating is a pure function of (step, layer), so the
+same tables are replayed every step.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+from .capi import SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_PLAIN
+
+_cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _mk(key, rows_item, rows_mode, device):
+    hit = _cache.get((key, str(device)))
+    if hit is None:
+        hit = (torch.tensor(rows_item, dtype=torch.int32, device=device), torch.tensor(rows_mode, dtype=torch.int32, device=device))
+        _cache[(key, str(device))] = hit
+    return hit
+
+
+def self_items(n_items: int, device):
+    """every item attends itself (ControlNet attn1, adapter attn_pose)."""
+    return _mk(("self", n_items), [[i] for i in range(n_items)], [[SEG_PLAIN]] * n_items, device)
+
+
+def cross_text(B: int, f: int, device):
+    """item (b, fr) attends text row b -- K/V projected once per b, not per frame (attention_2d.py:343)."""
+    return _mk(("cross", B, f), [[i // f] for i in range(B * f)], [[SEG_PLAIN]] * (B * f), device)
+
+
+def cross_interleaved(n_items: int, n_text: int, device):
+    """ControlNet prompt quirk: embeds.repeat(f,1,1) on "(b f)" rows -> row r reads text r % 2
+    (pipeline_motion_editor.py:615,621)."""
+    return _mk(("crossil", n_items, n_text), [[i % n_text] for i in range(n_items)], [[SEG_PLAIN]] * n_items, device)
+
+
+def prev_cur(B: int, f: int, device):
+    """MotionFrameAttention: keys = [frame max(i-1,0) | frame i] (attention_2d.py:732-740)."""
+    rows = [[b * f + max(i - 1, 0), b * f + i] for b in range(B) for i in range(f)]
+    return _mk(("prevcur", B, f), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+
+
+def first_prev_chunked(B: int, f: int, chunk: int, device):
+    """Adapter sparse-causal attention on independent chunks of `chunk` frames:
+    keys = [first frame of chunk | previous frame in chunk] (controlnet_adapter.py:352-361,414,472)."""
+    rows = []
+    for b in range(B):
+        for i in range(f):
+            c0 = i - i % chunk
+            rows.append([b * f + c0, b * f + c0 + max(i % chunk - 1, 0)])
+    return _mk(("firstprev", B, f, chunk), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+
+
+def edited_spatial(f: int, device):
+    """FullySelfAttentionControlMask on batch 4 = [u.rec, u.edit, c.rec, c.edit] (fully_control.py:425-447):
+    recon rows keep [prev | cur]; edit rows attend [src prev (fg/bg dual, mask frame max(head-1,0)) |
+    src cur (dual, mask frame head) | own cur]; the edit branch's prev-frame K/V are dropped
+    (k[:, 3N:], fully_control.py:383)."""
+    rows, modes = [], []
+    for b in range(4):
+        for i in range(f):
+            if b % 2 == 0:
+                rows.append([b * f + max(i - 1, 0), b * f + i, -1])
+                modes.append([SEG_PLAIN, SEG_PLAIN, SEG_PLAIN])
+            else:
+                s = (b - 1) * f
+                rows.append([s + max(i - 1, 0), s + i, b * f + i])
+                modes.append([SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
+    return _mk(("edited", f), rows, modes, device)

@@ -1,0 +1,117 @@
+"""Weight packer: reference state-dict (reference key schema, ``SURVEY.md §8b``) -> device-resident
+fp16 tensors in the layouts the kernels consume.
+
+  Linear  [N, K]            -> [N, 1, K]
+  Conv2d  [Co, Ci, 3, 3]    -> [Co, 9, Ci]   (tap = ky*3 + kx, channels-last K runs)
+  Conv2d  [Co, Ci, 1, 1]    -> [Co, 1, Ci]
+  Conv1d  [Co, Ci, k]       -> [Co, k, Ci]   (TemporalConv, k in {1, 3})
+  GEGLU   [8C, C] (+bias)   -> rows interleaved in blocks of 16 value rows / 16 gate rows
+  q|k|v (or k|v)            -> one fused [3C, 1, K] projection
+  all ResnetBlock2D.time_emb_proj -> one [sum(Cout), 1, 1280] projection
+
+Accepts numpy arrays or torch tensors (any float dtype) as values -- e.g. a real
+``diffusion_pytorch_model.safetensors`` state dict, an accelerate checkpoint, or
+``synth.synth_state_dict`` output.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Mapping, Optional
+
+import numpy as np
+import torch
+
+
+def _t(v) -> torch.Tensor:
+    if isinstance(v, np.ndarray):
+        return torch.from_numpy(v)
+    return v.detach().cpu()
+
+
+class Packed:
+    """name -> device fp16 tensor, packed lazily from the host state dict."""
+
+    def __init__(self, state: Mapping[str, object], device, prefix: str = "", dtype=torch.float16):
+        self.state = state
+        self.dtype = dtype  # fp16 on the GPU; tests/emu_ops.py checks the launch graphs in fp32 on CPU
+        self.device = torch.device(device)
+        self.prefix = prefix
+        self.cache: Dict[str, torch.Tensor] = {}
+
+    def has(self, name: str) -> bool:
+        return (self.prefix + name) in self.state
+
+    def raw(self, name: str) -> torch.Tensor:
+        return _t(self.state[self.prefix + name]).float()
+
+    def _put(self, key: str, t: torch.Tensor) -> torch.Tensor:
+        d = t.to(self.dtype).contiguous().to(self.device)
+        self.cache[key] = d
+        return d
+
+    def vec(self, name: str) -> torch.Tensor:
+        """bias / norm parameter as fp16 [n]."""
+        k = "vec:" + name
+        return self.cache.get(k) if k in self.cache else self._put(k, self.raw(name).reshape(-1))
+
+    @staticmethod
+    def _as_taps(w: torch.Tensor) -> torch.Tensor:
+        if w.dim() == 2:      # Linear
+            return w[:, None, :]
+        if w.dim() == 4:      # Conv2d [Co, Ci, kh, kw] -> [Co, kh*kw, Ci]
+            co, ci, kh, kw = w.shape
+            return w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+        if w.dim() == 3:      # Conv1d [Co, Ci, k] -> [Co, k, Ci]
+            return w.permute(0, 2, 1)
+        raise ValueError(f"unsupported weight rank {w.dim()}")
+
+    def mat(self, name: str) -> torch.Tensor:
+        k = "mat:" + name
+        return self.cache.get(k) if k in self.cache else self._put(k, self._as_taps(self.raw(name)))
+
+    def fused(self, names: Iterable[str]) -> torch.Tensor:
+        """Row-concatenation of several projections that share an input (q|k|v, k|v)."""
+        names = list(names)
+        k = "fused:" + "|".join(names)
+        if k in self.cache:
+            return self.cache[k]
+        return self._put(k, torch.cat([self._as_taps(self.raw(n)) for n in names], dim=0))
+
+    def fused_vec(self, names: Iterable[str]) -> torch.Tensor:
+        names = list(names)
+        k = "fvec:" + "|".join(names)
+        if k in self.cache:
+            return self.cache[k]
+        return self._put(k, torch.cat([self.raw(n).reshape(-1) for n in names]))
+
+    @staticmethod
+    def _geglu_perm(n_out: int) -> torch.Tensor:
+        """packed row p = q*32 + r  <-  value row q*16 + r (r < 16) | gate row n_out + q*16 + (r-16)."""
+        q = torch.arange(n_out // 16)
+        val = (q[:, None] * 16 + torch.arange(16)[None]).reshape(-1, 16)
+        gate = val + n_out
+        return torch.cat([val, gate], dim=1).reshape(-1)
+
+    def geglu_mat(self, name: str) -> torch.Tensor:
+        k = "geglu:" + name
+        if k in self.cache:
+            return self.cache[k]
+        w = self.raw(name)
+        return self._put(k, w[self._geglu_perm(w.shape[0] // 2)][:, None, :])
+
+    def geglu_vec(self, name: str) -> torch.Tensor:
+        k = "gegluv:" + name
+        if k in self.cache:
+            return self.cache[k]
+        b = self.raw(name)
+        return self._put(k, b[self._geglu_perm(b.shape[0] // 2)])
+
+    def is_zero(self, *names: str) -> bool:
+        """True when every named tensor is exactly zero (the reference zero-initialises TemporalConv
+        and never trains it, resnet_2d.py:15-16: its branch can be skipped for real checkpoints)."""
+        k = "zero:" + "|".join(names)
+        if k not in self.cache:
+            self.cache[k] = all(bool((self.raw(n) == 0).all()) for n in names)  # type: ignore[assignment]
+        return bool(self.cache[k])
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.cache.values() if isinstance(t, torch.Tensor))

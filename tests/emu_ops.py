@@ -1,0 +1,214 @@
+"""TEST INFRASTRUCTURE: a torch-CPU fp32 emulation of every ``motioneditor_amd.ops`` entry point, with
+the exact argument conventions of the C ABI (packed [N, taps, K] weights, key-segment tables, GEGLU
+row interleave, ...).  Two uses:
+  * ``-m "not gpu"`` tests monkeypatch it under ``models.graph`` to check the host launch graphs,
+    weight packing, segment tables and editors against the oracle WITHOUT a GPU;
+  * ``-m gpu`` tests use the same functions as the per-kernel fp32 reference for the HIP kernels.
+It is never imported by the product package.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV = 0, 1, 2
+
+
+def _f(t):
+    return None if t is None else t.float()
+
+
+def empty(rows, cols, like):
+    return torch.empty((rows, cols), dtype=like.dtype, device=like.device)
+
+
+def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=None, res2=None, geglu=False, act=0, alpha=1.0,
+         conv=None, tconv=None):
+    N, taps, K = w.shape
+    xf, wf = x.float()[:, :K], w.float()
+    if conv is not None:
+        Hin, Win, Hout, Wout, stride, ups = conv
+        n_img = x.shape[0] // (Hin * Win)
+        img = xf.reshape(n_img, Hin, Win, K).permute(0, 3, 1, 2)
+        if ups:
+            img = img.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        wk = wf.reshape(N, 3, 3, K).permute(0, 3, 1, 2)
+        y = F.conv2d(img, wk, None, stride=stride, padding=1)
+        assert y.shape[2] == Hout and y.shape[3] == Wout
+        acc = y.permute(0, 2, 3, 1).reshape(-1, N)
+    elif tconv is not None:
+        frames, npix, chunk = tconv
+        nb = x.shape[0] // (frames * npix)
+        t = xf.reshape(nb, frames // chunk, chunk, npix, K).permute(0, 1, 3, 4, 2).reshape(-1, K, chunk)   # (b ch p) c t
+        y = F.conv1d(t, wf.permute(0, 2, 1), None, padding=1)
+        acc = y.reshape(nb, frames // chunk, npix, N, chunk).permute(0, 1, 4, 2, 3).reshape(-1, N)
+    else:
+        acc = xf @ wf[:, 0].t()
+    if M is None:
+        M = acc.shape[0]
+    acc = acc[:M] * alpha
+    if geglu:
+        if bias is not None:
+            acc = acc + bias.float()
+        q = acc.reshape(M, N // 32, 2, 16)
+        val = q[:, :, 0] * F.gelu(q[:, :, 1])
+        y = val.reshape(M, N // 2)
+    else:
+        y = acc
+        if bias is not None:
+            y = y + bias.float()
+        if rowvec is not None:
+            idx = torch.arange(M) // rows_per_vec
+            y = y + rowvec.float()[idx][:, :N]
+        if act == 1:
+            y = F.relu(y)
+        elif act == 2:
+            y = F.silu(y)
+        if res is not None:
+            y = y + res.float()[:M, :N]
+        if res2 is not None:
+            y = y + res2.float()[:M, :N]
+    y = y.to(x.dtype)
+    if out is not None:
+        out[:M, :y.shape[1]] = y
+        return out[:M, :y.shape[1]]
+    return y
+
+
+def conv_small(inp, w, bias, *, n_img, Cin, H, Wd, img_stride, ch_stride, frames=0, frame_stride=0, silu=False):
+    flat = inp.reshape(-1).float()
+    imgs = []
+    for i in range(n_img):
+        base = (i // frames) * img_stride + (i % frames) * frame_stride if frames > 0 else i * img_stride
+        imgs.append(torch.stack([flat[base + c * ch_stride: base + c * ch_stride + H * Wd].reshape(H, Wd) for c in range(Cin)]))
+    x = torch.stack(imgs)
+    Cout = w.shape[0]
+    y = F.conv2d(x, w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), _f(bias), padding=1)
+    if silu:
+        y = F.silu(y)
+    return y.permute(0, 2, 3, 1).reshape(-1, Cout).to(w.dtype)
+
+
+def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, out=None):
+    scale = dh ** -0.5 if scale is None else scale
+    C = heads * dh
+    qf, kf, vf = q.float()[:, :C], k.float()[:, :C], v.float()[:, :C]
+    res = torch.empty((n_items * nq, C), dtype=torch.float32)
+    si, sm = seg_item.tolist(), seg_mode.tolist()
+    mk = _f(mask)
+    for it in range(n_items):
+        qi = qf[it * nq:(it + 1) * nq].reshape(nq, heads, dh).permute(1, 0, 2)   # [H, nq, dh]
+        logits, vals = [], []
+        for s, kit in enumerate(si[it]):
+            if kit < 0:
+                break
+            ks = kf[kit * nk:(kit + 1) * nk].reshape(nk, heads, dh).permute(1, 0, 2)
+            vs = vf[kit * nk:(kit + 1) * nk].reshape(nk, heads, dh).permute(1, 0, 2)
+            sc = torch.einsum("hqd,hkd->hqk", qi, ks) * scale
+            mode = sm[it][s]
+            if mode == SEG_PLAIN:
+                logits.append(sc)
+                vals.append(vs)
+            else:
+                planes = torch.tensor([(h if mode == SEG_DUAL_CUR else max(h - 1, 0)) for h in range(heads)])
+                m = mk[planes][:, None, :]                     # [H, 1, nk]
+                logits += [sc * m, sc * (1 - m)]
+                vals += [vs, vs]
+        p = torch.cat(logits, dim=-1).softmax(dim=-1)
+        o = torch.einsum("hqk,hkd->hqd", p, torch.cat(vals, dim=1))
+        res[it * nq:(it + 1) * nq] = o.permute(1, 0, 2).reshape(nq, C)
+    res = res.to(q.dtype)
+    if out is not None:
+        out[:, :C] = res
+        return out
+    return res
+
+
+def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, scale=None):
+    scale = dh ** -0.5 if scale is None else scale
+    C = heads * dh
+    km = list(kv_map) if kv_map is not None else list(range(batch))
+
+    def shp(t):  # rows (b f p) -> [b, p, H, f, dh]
+        return t.float()[:, :C].reshape(batch, frames, npix, heads, dh).permute(0, 2, 3, 1, 4)
+
+    qq, kk, vv = shp(q), shp(k)[km], shp(v)[km]
+    s = torch.einsum("bphid,bphjd->bphij", qq, kk) * scale
+    s = s + (1.0 - torch.tril(torch.ones(frames, frames))) * -10000.0
+    o = torch.einsum("bphij,bphjd->bphid", s.softmax(-1), vv)
+    return o.permute(0, 3, 1, 2, 4).reshape(batch * frames * npix, C).to(q.dtype)
+
+
+def groupnorm(x, gamma, beta, *, rows_per_group, eps, silu, groups=32, out=None):
+    rows, C = x.shape
+    t = x.float().reshape(rows // rows_per_group, rows_per_group, groups, C // groups)
+    mean = t.mean(dim=(1, 3), keepdim=True)
+    var = t.var(dim=(1, 3), unbiased=False, keepdim=True)
+    y = ((t - mean) / torch.sqrt(var + eps)).reshape(rows, C) * gamma.float() + beta.float()
+    if silu:
+        y = F.silu(y)
+    return y.to(x.dtype)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    return F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(x.dtype)
+
+
+def axpy_rows(y, x, a_, alpha=1.0):
+    y.copy_((x.float() + alpha * a_.float()).to(y.dtype))
+    return y
+
+
+def copy_rows(y, x):
+    y.copy_(x)
+    return y
+
+
+def silu(x):
+    return F.silu(x.float()).to(x.dtype)
+
+
+def relu(x):
+    return F.relu(x.float()).to(x.dtype)
+
+
+_EMU_DTYPE = torch.float32
+
+
+def timestep_embed(rows, dim, t, device):
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    ang = float(t) * freqs
+    return torch.cat([torch.cos(ang), torch.sin(ang)])[None].repeat(rows, 1).to(_EMU_DTYPE)
+
+
+def cfg_ddim(latents, eps_rows, *, guidance, ca, cb):
+    nb, C, f, h, w = latents.shape
+    e = eps_rows.float()[:, :C].reshape(2 * nb, f, h * w, C).permute(0, 3, 1, 2).reshape(2 * nb, C, f, h, w)
+    eu, ec = e[:nb], e[nb:]
+    return ca * latents + cb * (eu + guidance * (ec - eu))
+
+
+def nchw5_to_rows(x):
+    B, C, f, h, w = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(B * f * h * w, C).to(_EMU_DTYPE).contiguous()
+
+
+def rows_to_nchw5(rows, B, C, f, h, w):
+    return rows.float()[:, :C].reshape(B, f, h, w, C).permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rows_to_nchw(x, n_img, C, npix):
+    return x.float()[:, :C].reshape(n_img, npix, C).permute(0, 2, 1).contiguous()
+
+
+def nchw_to_rows(x, n_img, C, npix, img_stride, ch_stride):
+    flat = x.reshape(-1).float()
+    out = torch.empty((n_img * npix, C), dtype=_EMU_DTYPE)
+    for i in range(n_img):
+        for c in range(C):
+            out[i * npix:(i + 1) * npix, c] = flat[i * img_stride + c * ch_stride: i * img_stride + c * ch_stride + npix]
+    return out

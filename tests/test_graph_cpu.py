@@ -1,0 +1,58 @@
+"""CPU checks of the HOST logic (launch graphs, weight packing, key-segment tables, editors): the
+product graph code runs with tests/emu_ops.py (fp32 torch emulation of the C ABI) patched in place of
+the HIP ops, and must reproduce the reference's golden outputs.  No GPU, no product fallback."""
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from conftest import GOLD, max_rel
+from motioneditor_amd import synth
+from motioneditor_amd.attn_control import (FullySelfAttentionControlMask, TemporalSelfAttentionControl,
+                                           regiter_fully_attention_editor_diffusers, regiter_temporal_attention_editor_diffusers)
+from motioneditor_amd.models import graph
+from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    monkeypatch.setattr(graph, "ops", emu_ops)
+    import motioneditor_amd.models.unet_2d_condition as u
+    monkeypatch.setattr(u, "ops", emu_ops)
+    return emu_ops
+
+
+def test_unet_single_branch_matches_reference_golden(emu, unet_sd_np):
+    g = np.load(GOLD / "unet_single.npz")
+    c = synth.make_case_inputs("single", B=2, f=8, h=16, w=16)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    out = unet(c["sample"], c["t"], c["ehs"]).sample
+    assert out.shape == (2, 4, 8, 16, 16)
+    assert max_rel(out, torch.from_numpy(g["out"])) < 2e-4
+
+
+@pytest.mark.parametrize("tag,step", [("inactive", 0), ("active", 4)])
+def test_unet_two_branch_with_editors_matches_reference_golden(emu, unet_sd_np, tag, step):
+    g = np.load(GOLD / f"unet_two_{tag}.npz")
+    c = synth.make_case_inputs("two", B=4, f=16, h=16, w=16)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+
+    class Holder:
+        pass
+
+    pipe = Holder()
+    pipe.unet = unet
+    ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
+    regiter_temporal_attention_editor_diffusers(pipe, ted)
+    sed = FullySelfAttentionControlMask(start_step=4, start_layer=10, source_masks=c["source_masks"])
+    regiter_fully_attention_editor_diffusers(pipe, sed)
+    assert ted.num_att_layers == 16 and sed.num_att_layers == 32
+    ted.cur_step = sed.cur_step = step
+    taps = {}
+    out = unet(c["sample"], c["t"], c["ehs"], down_block_additional_residuals=c["down_res"], mid_block_additional_residual=c["mid_res"], taps=taps).sample
+    # counters advanced exactly one step, like the reference's (fully_control_utils.py:38-46)
+    assert (ted.cur_step, ted.cur_att_layer, sed.cur_step, sed.cur_att_layer) == (step + 1, 0, step + 1, 0)
+    assert max_rel(out, torch.from_numpy(g["out"])) < 2e-4
+    # per-stage checksums for bisecting (abs-mean of each skip / motion residual)
+    for i, s in enumerate(taps["skips"]):
+        assert abs(float(s.abs().mean()) - g["skip_stats"][i, 1]) < 1e-3 * g["skip_stats"][i, 1]
