@@ -31,6 +31,26 @@ def _chk2d(t: torch.Tensor, name: str) -> None:
         raise ValueError(f"{name}: expected a CUDA fp16 2-D tensor with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
 
 
+# ---- optional per-launch profiling (bench.py): HIP events on the launch stream around each kernel call ----
+PROFILE = None  # None = off; else a list receiving (family, algorithmic_flops, algorithmic_bytes, start_event, end_event)
+
+
+def _pb():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _pe(e0, family: str, flops: float, nbytes: float) -> None:
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((family, flops, nbytes, e0, e1))
+
+
 def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((rows, cols), dtype=F16, device=like.device)
 
@@ -88,7 +108,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.geglu = 1 if geglu else 0
     a.act = act
     a.alpha = alpha
+    e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
+    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out))
     return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
 
 
@@ -128,7 +150,17 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
     a.n_items, a.nq, a.nk, a.nseg = n_items, nq, nk, seg_item.shape[1]
     a.seg_item, a.seg_mode, a.mask = seg_item.data_ptr(), seg_mode.data_ptr(), _p(mask)
     a.scale = dh ** -0.5 if scale is None else scale
+    e0 = _pb()
     capi.check(capi.lib().me_attn(C.byref(a), _stream()), "me_attn")
+    if e0 is not None:
+        # reference-semantics key count: a dual (fg|bg) segment is 2*nk materialised keys (fully_control.py:381-413)
+        from . import segments
+        units = segments.KEY_UNITS.get(seg_item.data_ptr())
+        if units is None:
+            sm, si = seg_mode.tolist(), seg_item.tolist()
+            units = sum((2 if m != 0 else 1) for ri, rm in zip(si, sm) for i_, m in zip(ri, rm) if i_ >= 0)
+        keys = nk * units
+        _pe(e0, f"attn_dh{dh}", 4.0 * heads * nq * keys * dh, 2.0 * 4 * n_items * nq * heads * dh)
     return out
 
 
@@ -145,7 +177,9 @@ def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hea
     for i in range(8):
         a.kv_map[i] = km[i] if i < len(km) else 0
     a.scale = dh ** -0.5 if scale is None else scale
+    e0 = _pb()
     capi.check(capi.lib().me_tattn(C.byref(a), _stream()), "me_tattn")
+    _pe(e0, "tattn", 4.0 * batch * npix * heads * frames * frames * dh, 2.0 * 4 * batch * frames * npix * heads * dh)
     return out
 
 
@@ -167,7 +201,9 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_
     a.X, a.Y, a.gamma, a.beta, a.stats = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr()
     a.rows, a.rows_per_group, a.C, a.ldx, a.ldy = rows, rows_per_group, Cc, x.stride(0), out.stride(0)
     a.groups, a.eps, a.silu = groups, eps, 1 if silu else 0
+    e0 = _pb()
     capi.check(capi.lib().me_groupnorm(C.byref(a), _stream()), "me_groupnorm")
+    _pe(e0, "groupnorm", 8.0 * rows * Cc, 4.0 * rows * Cc)
     return out
 
 
@@ -177,7 +213,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     a = LayerNormArgs()
     a.X, a.Y, a.gamma, a.beta = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr()
     a.rows, a.C, a.ldx, a.ldy, a.eps = x.shape[0], x.shape[1], x.stride(0), out.stride(0), eps
+    e0 = _pb()
     capi.check(capi.lib().me_layernorm(C.byref(a), _stream()), "me_layernorm")
+    _pe(e0, "layernorm", 8.0 * x.shape[0] * x.shape[1], 4.0 * x.shape[0] * x.shape[1])
     return out
 
 

@@ -1,0 +1,83 @@
+"""No-GPU checks: the C-ABI library builds for gfx950, loads, and exports every symbol include/motioned.h
+declares; argument validation that needs no device; oracle vs the reference golden vectors."""
+import ctypes
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, max_rel
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from motioneditor_amd import build, capi
+    build.build_lib(verbose=False)
+    header = (ROOT / "include" / "motioned.h").read_text()
+    declared = set(re.findall(r"\b(me_[a-z0-9_]+)\s*\(", header))
+    declared = {d for d in declared if not d.endswith("_args")}
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = ctypes.CDLL(str(capi.LIB_PATH))
+    for name in declared:
+        getattr(L, name)
+    assert capi.lib().me_abi_version() == 1
+
+
+def test_argument_validation_returns_einval_without_a_device():
+    from motioneditor_amd import capi
+    L = capi.lib()
+    a = capi.GemmArgs()
+    assert L.me_gemm(ctypes.byref(a), None) == capi.ME_EINVAL and b"null" in L.me_last_error()
+    a.X = a.W = a.C = 4096
+    a.M, a.N, a.K, a.ldx, a.ldc = 8, 8, 12, 16, 8
+    assert L.me_gemm(ctypes.byref(a), None) == capi.ME_EINVAL and b"multiples" in L.me_last_error()
+    t = capi.AttnArgs()
+    t.Q = t.K = t.V = t.O = t.seg_item = t.seg_mode = 4096
+    t.n_items, t.nq, t.nk, t.heads, t.nseg, t.dh = 1, 1, 1, 8, 1, 64
+    t.ldq = t.ldk = t.ldv = t.ldo = 512
+    assert L.me_attn(ctypes.byref(t), None) == capi.ME_EINVAL and b"head dim" in L.me_last_error()
+    with pytest.raises(ValueError):
+        capi.check(capi.ME_EINVAL, "x")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from motioneditor_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(capi.MotionedError):
+        capi.lib()
+
+
+def test_schema_matches_reference_key_dump():
+    from motioneditor_amd import synth
+    ref = {}
+    for line in (GOLD / "unet_keys.txt").read_text().splitlines():
+        k, *shape = line.split()
+        ref[k] = tuple(int(s) for s in shape)
+    assert ref == dict(synth.unet_schema())
+    assert sum(int(np.prod(s)) for s in synth.controlnet_schema().values()) == 361279120
+
+
+def test_oracle_ddim_matches_reference_prev_step_vectors():
+    from oracle import ref_cpu
+    g = np.load(GOLD / "ddim.npz")
+    d = ref_cpu.DDIM()
+    assert d.timesteps == g["timesteps"].tolist()
+    x, e = torch.from_numpy(g["x"]), torch.from_numpy(g["eps"])
+    for t in (981, 501, 21, 1):
+        assert max_rel(d.step(e, t, x), torch.from_numpy(g[f"prev_{t}"])) < 1e-5
+        ca, cb = d.coeffs(t)
+        assert max_rel(ca * x + cb * e, torch.from_numpy(g[f"prev_{t}"])) < 1e-4
+
+
+def test_oracle_unet_matches_reference_golden(unet_sd_torch):
+    """The CPU restatement against the output of the reference's own UNet2DConditionModel (single-branch case;
+    the two-branch + editor cases are pinned at fixture-generation time and re-checked through the
+    launch-graph tests)."""
+    from motioneditor_amd import synth
+    from oracle import ref_cpu
+    g = np.load(GOLD / "unet_single.npz")
+    c = synth.make_case_inputs("single", B=2, f=8, h=16, w=16)
+    with torch.no_grad():
+        out = ref_cpu.unet_forward(unet_sd_torch, c["sample"], c["t"], c["ehs"])
+    assert max_rel(out, torch.from_numpy(g["out"])) < 2e-4

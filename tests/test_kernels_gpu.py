@@ -1,0 +1,268 @@
+"""Per-kernel parity on a real MI355X: every libmotioned entry point (through the C ABI / ctypes) against
+the fp32 torch emulation in tests/emu_ops.py on the same seeded fp16 inputs.
+
+Tolerance (fp16 storage, fp32 accumulate): rel-L2 <= 2e-3 per kernel and
+max-abs error <= 2e-2 x mean-abs of the reference."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as emu
+
+pytestmark = pytest.mark.gpu
+
+REL_L2 = 2e-3
+MAX_REL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; the HIP library is the only compute path")
+    from motioneditor_amd import capi, ops as _ops
+    capi.lib()  # fails loudly when libmotioned.so is missing
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16)
+
+
+def check(got, want, name="", rel=REL_L2, mx=MAX_REL):
+    got, want = got.detach().float().cpu().double(), want.detach().float().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert torch.isfinite(got).all(), name
+    r = float((got - want).norm() / want.norm().clamp_min(1e-30))
+    m = float((got - want).abs().max() / want.abs().mean().clamp_min(1e-30))
+    assert r <= rel and m <= mx, f"{name}: rel-L2 {r:.3e} (<= {rel}), max/mean {m:.3e} (<= {mx})"
+
+
+def cu(t):
+    return t.cuda() if t is not None else None
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (77 * 2, 640, 768), (1000, 1280, 1280), (37, 4, 320), (520, 960, 64), (8, 64, 8)])
+def test_gemm_dense_plain(ops, M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+    check(ops.gemm(cu(x), cu(w)), emu.gemm(x, w), f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_dense_epilogue_all(ops):
+    M, N, K = 520, 320, 640
+    x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+    bias, res, res2 = rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    rowvec = rnd(4, 2048, seed=6)[:, 128:128 + N]
+    for act in (0, 1, 2):
+        got = ops.gemm(cu(x), cu(w), bias=cu(bias), rowvec=cu(rnd(4, 2048, seed=6))[:, 128:128 + N], rows_per_vec=130, res=cu(res), res2=cu(res2), act=act, alpha=0.5)
+        want = emu.gemm(x, w, bias=bias, rowvec=rowvec, rows_per_vec=130, res=res, res2=res2, act=act, alpha=0.5)
+        check(got, want, f"gemm epilogue act={act}")
+
+
+def test_gemm_inplace_residual_and_strided_views(ops):
+    M, C = 260, 320
+    x, w = rnd(M, C, seed=1), rnd(C, 1, C, seed=2, scale=C ** -0.5)
+    t = rnd(M, C, seed=3)
+    tg = cu(t).clone()
+    ops.gemm(cu(x), cu(w), res=tg, out=tg)            # out aliases res
+    check(tg, emu.gemm(x, w, res=t), "gemm in-place residual")
+    big = rnd(M, 3 * C, seed=4)                         # strided X view (ldx = 3C) and strided out
+    outbuf = torch.zeros(M, 2 * C, dtype=torch.float16, device="cuda")
+    ops.gemm(cu(big)[:, C:2 * C], cu(w), out=outbuf[:, C:])
+    check(outbuf[:, C:], emu.gemm(big[:, C:2 * C], w), "gemm strided")
+    assert float(outbuf[:, :C].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C,M", [(320, 300), (640, 130), (1280, 64)])
+def test_gemm_geglu(ops, C, M):
+    from motioneditor_amd.weights import Packed
+    W = (torch.randn(8 * C, C, generator=torch.Generator().manual_seed(1)) * C ** -0.5)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(2)) * 0.1
+    P = Packed({"w": W, "b": b}, "cuda")
+    x = rnd(M, C, seed=3)
+    got = ops.gemm(cu(x), P.geglu_mat("w"), bias=P.geglu_vec("b"), geglu=True)
+    h = x.float() @ W.half().float().t() + b.half().float()
+    want = h[:, :4 * C] * torch.nn.functional.gelu(h[:, 4 * C:])
+    check(got, want, f"geglu C={C}")
+    Pc = Packed({"w": W, "b": b}, "cpu")
+    check(got, emu.gemm(x, Pc.geglu_mat("w"), bias=Pc.geglu_vec("b"), geglu=True), "geglu vs emu packing")
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,stride,ups,nimg", [(320, 320, 8, 8, 1, 0, 5), (320, 640, 8, 8, 2, 0, 3), (640, 640, 4, 4, 1, 1, 3), (16, 32, 16, 16, 2, 0, 2),
+                                                          (96, 96, 8, 8, 1, 0, 2), (320, 4, 8, 8, 1, 0, 4), (1280, 1280, 2, 2, 1, 0, 8), (1280, 1280, 1, 1, 1, 0, 16),
+                                                          (2560, 1280, 2, 2, 1, 0, 4), (640, 320, 16, 12, 1, 0, 2)])
+def test_gemm_conv3x3(ops, Cin, Cout, H, W, stride, ups, nimg):
+    x = rnd(nimg * H * W, Cin, seed=1)
+    w = rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=3)
+    hv, wv = H << ups, W << ups
+    ho, wo = (hv - 1) // stride + 1, (wv - 1) // stride + 1
+    conv = (H, W, ho, wo, stride, ups)
+    got = ops.gemm(cu(x), cu(w), M=nimg * ho * wo, bias=cu(bias), conv=conv)
+    check(got, emu.gemm(x, w, M=nimg * ho * wo, bias=bias, conv=conv), f"conv {Cin}->{Cout} {H}x{W} s{stride} u{ups}")
+
+
+@pytest.mark.parametrize("C,frames,npix,chunk,nb", [(320, 16, 4, 16, 2), (320, 16, 9, 8, 2), (640, 24, 4, 8, 1), (1280, 8, 1, 8, 4)])
+def test_gemm_tconv(ops, C, frames, npix, chunk, nb):
+    x = rnd(nb * frames * npix, C, seed=1)
+    w = rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
+    bias, res = rnd(C, seed=3), rnd(nb * frames * npix, C, seed=4)
+    got = ops.gemm(cu(x), cu(w), bias=cu(bias), tconv=(frames, npix, chunk), res=cu(res))
+    check(got, emu.gemm(x, w, bias=bias, tconv=(frames, npix, chunk), res=res), f"tconv C={C} f={frames} chunk={chunk}")
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    x, w = cu(rnd(16, 12)), cu(rnd(8, 1, 12))
+    with pytest.raises(ValueError):
+        ops.gemm(x, w)  # K = 12 is not a multiple of 8
+
+
+# ------------------------------------------------------------------ conv_small
+def test_conv_small_5d_latents_and_images(ops):
+    B, f, h, w = 2, 3, 6, 5
+    lat = torch.randn(B, 4, f, h, w, generator=torch.Generator().manual_seed(1))
+    W = rnd(320, 9, 4, seed=2, scale=1 / 6)
+    b = rnd(320, seed=3)
+    kw = dict(n_img=B * f, Cin=4, H=h, Wd=w, img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w)
+    check(ops.conv_small(cu(lat), cu(W), cu(b), **kw), emu.conv_small(lat, W, b, **kw), "conv_in 5-D")
+    img = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(4))
+    W = rnd(16, 9, 3, seed=5, scale=1 / 5)
+    kw = dict(n_img=4, Cin=3, H=16, Wd=16, img_stride=3 * 256, ch_stride=256, silu=True)
+    check(ops.conv_small(cu(img), cu(W), cu(rnd(16, seed=6)), **kw), emu.conv_small(img, W, rnd(16, seed=6), **kw), "cond conv_in")
+
+
+# ------------------------------------------------------------------ attention
+def seg(rows, modes):
+    return torch.tensor(rows, dtype=torch.int32), torch.tensor(modes, dtype=torch.int32)
+
+
+@pytest.mark.parametrize("dh", [40, 80, 160])
+@pytest.mark.parametrize("nq", [1, 16, 64, 100, 256])
+def test_attention_prev_cur(ops, dh, nq):
+    from motioneditor_amd import segments
+    B, f, C = 2, 3, 8 * dh
+    qkv = rnd(B * f * nq, 3 * C, seed=1)
+    si, sm = segments.prev_cur(B, f, "cpu")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=nq, nk=nq)
+    got = ops.attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), **args)
+    want = emu.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, **args)
+    check(got, want, f"attn prev|cur dh={dh} nq={nq}")
+
+
+@pytest.mark.parametrize("dh,nq", [(40, 64), (80, 16), (160, 4), (40, 256)])
+def test_attention_cross_text_77_keys(ops, dh, nq):
+    from motioneditor_amd import segments
+    B, f, C = 4, 2, 8 * dh
+    q, kv = rnd(B * f * nq, C, seed=1), rnd(B * 77, 2 * C, seed=2)
+    si, sm = segments.cross_text(B, f, "cpu")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=nq, nk=77)
+    got = ops.attention(cu(q), cu(kv)[:, :C], cu(kv)[:, C:], seg_item=cu(si), seg_mode=cu(sm), **args)
+    check(got, emu.attention(q, kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, **args), f"attn cross dh={dh}")
+
+
+@pytest.mark.parametrize("dh,N,binary", [(40, 64, True), (80, 16, True), (40, 256, True), (40, 64, False), (80, 144, True)])
+def test_attention_edited_dual_mask_5N_keys(ops, dh, N, binary):
+    """The spatial editor's masked attention: recon rows [prev|cur], edit rows [src prev dual | src cur dual | own cur]
+    with head-indexed mask planes (fully_control.py:372-447)."""
+    from motioneditor_amd import segments
+    f, C = 8, 8 * dh
+    qkv = rnd(4 * f * N, 3 * C, seed=1)
+    g = torch.Generator().manual_seed(7)
+    mask = (torch.rand(8, N, generator=g) > 0.5).half() if binary else torch.rand(8, N, generator=g).half()
+    si, sm = segments.edited_spatial(f, "cpu")
+    args = dict(heads=8, dh=dh, n_items=4 * f, nq=N, nk=N)
+    got = ops.attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), mask=cu(mask), **args)
+    want = emu.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, mask=mask, **args)
+    check(got, want, f"attn edited dh={dh} N={N} binary={binary}")
+
+
+def test_attention_large_logits_online_softmax_rescale(ops):
+    """Force the running max to jump late (a spiked key in the LAST tile) so the rescale path matters."""
+    dh, nq, nk, C = 40, 64, 300, 320
+    q, k, v = rnd(nq, C, seed=1), rnd(nk, C, seed=2), rnd(nk, C, seed=3)
+    k[-3] = q[5] * 6.0
+    k[10] = q[7] * 4.0
+    si, sm = seg([[0]], [[0]])
+    args = dict(heads=8, dh=dh, n_items=1, nq=nq, nk=nk)
+    check(ops.attention(cu(q), cu(k), cu(v), seg_item=cu(si), seg_mode=cu(sm), **args), emu.attention(q, k, v, seg_item=si, seg_mode=sm, **args), "attn spike")
+
+
+def test_attention_adapter_chunked_first_prev(ops):
+    from motioneditor_amd import segments
+    dh, N, B, f = 80, 16, 2, 16
+    C = 8 * dh
+    qkv = rnd(B * f * N, 3 * C, seed=1)
+    si, sm = segments.first_prev_chunked(B, f, 8, "cpu")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=N, nk=N)
+    got = ops.attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), **args)
+    check(got, emu.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, **args), "attn first|prev chunk 8")
+
+
+# ------------------------------------------------------------------ temporal attention
+@pytest.mark.parametrize("F,dh,npix,kv_map", [(8, 40, 5, None), (16, 80, 3, [0, 0, 2, 2]), (24, 40, 4, [0, 0, 2, 2]), (24, 160, 1, None), (48, 40, 2, None)])
+def test_temporal_attention(ops, F, dh, npix, kv_map):
+    B, C = 4, 8 * dh
+    qkv = rnd(B * F * npix, 3 * C, seed=1)
+    args = dict(heads=8, dh=dh, batch=B, frames=F, npix=npix, kv_map=kv_map)
+    got = ops.temporal_attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], **args)
+    check(got, emu.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], **args), f"tattn F={F} dh={dh}")
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("C,rows,rpg,silu", [(320, 4 * 16 * 64, 16 * 64, True), (640, 96, 8, False), (960, 2 * 300, 300, True), (1280, 64, 16, True),
+                                             (1920, 128, 64, True), (2560, 8 * 33, 33, True), (320, 6 * 1000, 1000, False)])
+def test_groupnorm(ops, C, rows, rpg, silu):
+    x = (rnd(rows, C, seed=1) * 2 + 0.7).half()
+    gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
+    got = ops.groupnorm(cu(x), cu(gm), cu(bt), rows_per_group=rpg, eps=1e-5, silu=silu)
+    check(got, emu.groupnorm(x, gm, bt, rows_per_group=rpg, eps=1e-5, silu=silu), f"groupnorm C={C}")
+
+
+@pytest.mark.parametrize("C,rows", [(320, 1000), (640, 77), (1280, 130)])
+def test_layernorm(ops, C, rows):
+    x = (rnd(rows, C, seed=1) * 3 - 0.4).half()
+    gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
+    check(ops.layernorm(cu(x), cu(gm), cu(bt)), emu.layernorm(x, gm, bt), f"layernorm C={C}")
+
+
+# ------------------------------------------------------------------ element-wise
+def test_elementwise_family(ops):
+    x, a = rnd(300, 640, seed=1), rnd(300, 640, seed=2)
+    y = cu(x).clone()
+    ops.axpy_rows(y[100:200], y[100:200], cu(a)[:100], 0.5)
+    want = x.clone().float()
+    want[100:200] += 0.5 * a[:100].float()
+    check(y, want, "axpy_rows")
+    dst = torch.zeros(300, 1280, dtype=torch.float16, device="cuda")
+    ops.copy_rows(dst[:, 640:], cu(x))
+    assert torch.equal(dst[:, 640:].cpu(), x) and float(dst[:, :640].abs().max()) == 0
+    check(ops.silu(cu(x)), emu.silu(x), "silu")
+    check(ops.relu(cu(x)), emu.relu(x), "relu")
+    check(ops.timestep_embed(3, 320, 981.0, "cuda"), emu.timestep_embed(3, 320, 981.0, "cpu"), "timestep_embed", rel=2e-3)
+    lat = torch.randn(2, 4, 3, 5, 7, generator=torch.Generator().manual_seed(3))
+    eps = rnd(4 * 3 * 35, 4, seed=4)
+    check(ops.cfg_ddim(cu(lat), cu(eps), guidance=7.5, ca=1.01, cb=-0.07), emu.cfg_ddim(lat, eps, guidance=7.5, ca=1.01, cb=-0.07), "cfg_ddim", rel=1e-5, mx=1e-4)
+    t5 = torch.randn(2, 8, 3, 4, 5, generator=torch.Generator().manual_seed(5))
+    rows = ops.nchw5_to_rows(cu(t5))
+    check(rows, emu.nchw5_to_rows(t5), "nchw5_to_rows")
+    back = ops.rows_to_nchw5(rows, 2, 8, 3, 4, 5)
+    check(back, t5.half().float(), "rows_to_nchw5", rel=1e-6, mx=1e-6)
+
+
+def test_ddim_matches_reference_golden(ops):
+    """me_cfg_ddim + DDIMScheduler coefficients against the reference's own prev_step vectors
+    (tests/golden/ddim.npz, p2p/null_text_optimization.py:26-36)."""
+    from conftest import GOLD
+    from motioneditor_amd.schedulers import DDIMScheduler
+    g = np.load(GOLD / "ddim.npz")
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert s.timesteps == g["timesteps"].tolist()
+    x = torch.from_numpy(g["x"]).reshape(2, 4, 1, 8, 8)
+    e = torch.from_numpy(g["eps"]).reshape(2, 4, 1, 8, 8)
+    for t in (981, 501, 21, 1):
+        out = s.step(cu(e), t, cu(x)).prev_sample
+        check(out, torch.from_numpy(g[f"prev_{t}"]).reshape(2, 4, 1, 8, 8), f"ddim t={t}", rel=1e-3, mx=5e-3)  # eps passes through fp16 rows

