@@ -64,13 +64,12 @@ def make_pipeline(device, usd, csd, masks):
 
 def cpu_baseline(usd, csd, budget_s=25.0):
     """CPU oracle (oracle/ref_cpu.py, fp32 torch) on a bounded sample: ONE full two-branch step with editors
-    active at 8 frames x 128^2 (16x16 latents), all host cores; scaled to the bench workload by the
+    active at 8 frames x 64^2 (8x8 latents), torch's default thread count; scaled to the bench workload by the
     reference-semantics FLOP ratio."""
     from oracle import ref_cpu
     from motioneditor_amd import synth
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    f, h, w = 8, 16, 16
+    cores = torch.get_num_threads()   # torch's default (physical cores); forcing every SMT thread made it 20x slower
+    f, h, w = 8, 8, 8
     x = build_inputs(f, h, w)
     to = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}  # noqa: E731
     u, c = to(usd), to(csd)

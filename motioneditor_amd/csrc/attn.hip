@@ -277,6 +277,7 @@ int launch_attn(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 64 * QT;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL((attn_kernel<DH, QT>), dim3((unsigned)total), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }

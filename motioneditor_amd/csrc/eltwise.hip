@@ -163,6 +163,7 @@ extern "C" int me_conv_small(const me_conv_small_args* a, void* stream) {
   if (!a || !a->in || !a->W || !a->out) { me_set_error("me_conv_small: null pointer"); return ME_EINVAL; }
   if (a->Cin <= 0 || a->Cin > 8 || a->Cout % 8 || a->n_img <= 0 || a->H <= 0 || a->Wd <= 0) { me_set_error("me_conv_small: bad geometry"); return ME_EINVAL; }
   const long total = (long)a->n_img * a->H * a->Wd * (a->Cout / 8);
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
   ME_CHECK_LAUNCH("me_conv_small")
 }
@@ -170,6 +171,7 @@ extern "C" int me_conv_small(const me_conv_small_args* a, void* stream) {
 extern "C" int me_axpy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, const void* A, int32_t lda, int64_t rows, int32_t cols, float alpha,
                             void* stream) {
   if (!Y || !X || !A || rows <= 0 || cols <= 0 || cols % 4 || ldy % 4 || ldx % 4 || lda % 4) { me_set_error("me_axpy_rows: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(axpy_rows_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
                      reinterpret_cast<const f16*>(X), ldx, reinterpret_cast<const f16*>(A), lda, (long)rows, cols, alpha);
   ME_CHECK_LAUNCH("me_axpy_rows")
@@ -177,6 +179,7 @@ extern "C" int me_axpy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, co
 
 extern "C" int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream) {
   if (!Y || !X || rows <= 0 || cols <= 0 || cols % 8 || ldy % 8 || ldx % 8) { me_set_error("me_copy_rows: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
                      reinterpret_cast<const f16*>(X), ldx, (long)rows, cols);
   ME_CHECK_LAUNCH("me_copy_rows")
@@ -184,6 +187,7 @@ extern "C" int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, in
 
 extern "C" int me_silu(void* Y, const void* X, int64_t n, void* stream) {
   if (!Y || !X || n <= 0 || (((uintptr_t)Y | (uintptr_t)X) & 15)) { me_set_error("me_silu: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(unary_kernel<0>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y),
                      reinterpret_cast<const f16*>(X), (long)n);
   ME_CHECK_LAUNCH("me_silu")
@@ -191,6 +195,7 @@ extern "C" int me_silu(void* Y, const void* X, int64_t n, void* stream) {
 
 extern "C" int me_relu(void* Y, const void* X, int64_t n, void* stream) {
   if (!Y || !X || n <= 0 || (((uintptr_t)Y | (uintptr_t)X) & 15)) { me_set_error("me_relu: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(unary_kernel<1>, dim3(grid_for((n + 7) / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y),
                      reinterpret_cast<const f16*>(X), (long)n);
   ME_CHECK_LAUNCH("me_relu")
@@ -198,6 +203,7 @@ extern "C" int me_relu(void* Y, const void* X, int64_t n, void* stream) {
 
 extern "C" int me_timestep_embed(void* out, int32_t rows, int32_t dim, float t, void* stream) {
   if (!out || rows <= 0 || dim <= 0 || dim % 2) { me_set_error("me_timestep_embed: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(timestep_embed_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(out), rows,
                      dim, t);
   ME_CHECK_LAUNCH("me_timestep_embed")
@@ -207,6 +213,7 @@ extern "C" int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps,
                            float guidance, float ca, float cb, void* stream) {
   if (!lat_out || !lat_in || !eps || nb <= 0 || C <= 0 || frames <= 0 || npix <= 0 || lde < C) { me_set_error("me_cfg_ddim: bad arguments"); return ME_EINVAL; }
   const long total = (long)nb * C * frames * npix;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lat_out, lat_in,
                      reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, guidance, ca, cb);
   ME_CHECK_LAUNCH("me_cfg_ddim")
@@ -216,6 +223,7 @@ extern "C" int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img
                                void* stream) {
   if (!Y || !X || n_img <= 0 || C <= 0 || npix <= 0 || ldy < C) { me_set_error("me_nchw_to_rows: bad arguments"); return ME_EINVAL; }
   const long total = (long)n_img * npix * C;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(nchw_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy, X,
                      (long)img_stride, (long)ch_stride, n_img, C, npix);
   ME_CHECK_LAUNCH("me_nchw_to_rows")
@@ -225,6 +233,7 @@ extern "C" int me_rows_to_nchw(float* Y, int64_t img_stride, int64_t ch_stride, 
                                void* stream) {
   if (!Y || !X || n_img <= 0 || C <= 0 || npix <= 0 || ldx < C) { me_set_error("me_rows_to_nchw: bad arguments"); return ME_EINVAL; }
   const long total = (long)n_img * npix * C;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(rows_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Y, (long)img_stride,
                      (long)ch_stride, reinterpret_cast<const f16*>(X), ldx, n_img, C, npix);
   ME_CHECK_LAUNCH("me_rows_to_nchw")

@@ -280,6 +280,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
     attr_set = true;
   }
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(gemm_kernel<BN>, dim3(nbm * nbn), dim3(256), lds, st, *a);
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");

@@ -168,6 +168,7 @@ extern "C" int me_groupnorm(const me_groupnorm_args* a, void* stream) {
   int chunk_rows = (a->rows_per_group + chunks - 1) / chunks;
   if (chunk_rows < 8) chunk_rows = 8;
   chunks = (a->rows_per_group + chunk_rows - 1) / chunk_rows;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), a->stats, a->rows_per_group,
                      chunk_rows, a->C, a->ldx, a->groups);
   const long nvec = (long)a->rows * (a->C / 8);
@@ -191,6 +192,7 @@ extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {
   f16* Y = reinterpret_cast<f16*>(a->Y);
   const f16* gm = reinterpret_cast<const f16*>(a->gamma);
   const f16* bt = reinterpret_cast<const f16*>(a->beta);
+  (void)hipGetLastError();
   if (nv == 1) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);

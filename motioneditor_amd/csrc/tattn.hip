@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const me_tattn_args a) {
 template <int F>
 int launch_tattn(const me_tattn_args* a, hipStream_t st) {
   const long total = (long)a->batch * a->npix * a->heads * F;
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(tattn_kernel<F>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }

@@ -154,18 +154,22 @@ def test_properties_at_larger_size(unet):
 
     o1, _ = run(c["sample"], c["down_res"])
     o2, _ = run(c["sample"], c["down_res"])
-    assert torch.equal(o1, o2) or rel_l2(o1, o2) < 1e-4   # GroupNorm statistics use float atomics
+    # run-to-run: GroupNorm statistics are accumulated with float atomics, so the fp32 sums differ in the last
+    # bits between runs and fp16 roundings downstream flip -- the spread equals the fp16 noise floor (~1e-3)
+    noise = rel_l2(o1, o2)
+    record("run_to_run", noise)
+    assert noise < 3e-3
     s2 = c["sample"].clone()
     s2[1] += 0.5                                          # perturb the uncond EDIT row only
     o3, _ = run(s2, c["down_res"])
-    assert rel_l2(o3[0], o1[0]) < 1e-4 and rel_l2(o3[2], o1[2]) < 1e-4   # recon rows unchanged
-    assert rel_l2(o3[1], o1[1]) > 1e-2                                    # edit row changed
+    assert rel_l2(o3[0], o1[0]) < 3e-3 and rel_l2(o3[2], o1[2]) < 3e-3   # recon rows unchanged (to the noise floor)
+    assert rel_l2(o3[1], o1[1]) > 3e-2                                    # edit row changed
     d2 = [d.clone() for d in c["down_res"]]
     d2[0][:, :, 9] += 1.0
     _, t4 = run(c["sample"], d2)
     _, t1 = run(c["sample"], c["down_res"])
     m1 = t1["motion"][0].float().reshape(2, 16, 32 * 32, 320)
     m4 = t4["motion"][0].float().reshape(2, 16, 32 * 32, 320)
-    assert float((m1[:, :8] - m4[:, :8]).abs().max()) < 1e-2            # frames 0-7: other chunk + causal -> untouched
-    assert float((m1[:, 9:] - m4[:, 9:]).abs().max()) > 1e-2
+    assert rel_l2(m4[:, :8], m1[:, :8]) < 3e-3            # frames 0-7: other chunk + causal -> untouched
+    assert rel_l2(m4[:, 9:], m1[:, 9:]) > 3e-2            # frame 9 itself, later frames of its chunk, and causal look-back
     unet.spatial_editor = unet.temporal_editor = None
