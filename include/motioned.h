@@ -108,6 +108,7 @@ int me_conv_small(const me_conv_small_args* a, void* stream);
 #define ME_SEG_PLAIN 0     /* weight exp(s)                                                            */
 #define ME_SEG_DUAL_CUR 1  /* weight exp(m*s) + exp((1-m)*s), m = mask[head][key]                      */
 #define ME_SEG_DUAL_PREV 2 /* same with m = mask[max(head-1,0)][key]                                   */
+#define ME_SEG_DUAL_BIN 3  /* DUAL with a BINARY mask: weight exp(s) + 1 for either mask value (no mask read) */
 
 typedef struct me_attn_args {
   const void* Q;  /* fp16 rows (item*nq + q), cols head*dh + d */

@@ -52,6 +52,8 @@ class FullySelfAttentionControlMask(MutualSelfAttentionControl):
         self.rectangle_source_masks = None
         self.source_masks = source_masks.permute(0, 2, 1, 3, 4)  # "b f c h w -> b c f h w" (:368)
         self._planes = {}
+        m = self.source_masks.detach().float()
+        self.binary_masks = bool(((m == 0) | (m == 1)).all())   # man.mask PNGs are 0/255 -> 0/1 (data/dataset.py)
 
     def mask_planes(self, N: int, device) -> torch.Tensor:
         """fp16 [8, N]: masks nearest-resized to (8, sqrt N, sqrt N) (reference :376-390).  Plane p is used
@@ -73,4 +75,4 @@ class FullySelfAttentionControlMask(MutualSelfAttentionControl):
             raise ValueError("edited attention expects batch 4 = [uncond.rec, uncond.edit, cond.rec, cond.edit] (reference :439-441)")
         if (num_heads * call.f) % 8:
             raise ValueError("heads * frames must be divisible by 8 (reference :377)")
-        return call.run(*segments.edited_spatial(call.f, call.q.device), mask=self.mask_planes(call.N, call.q.device))
+        return call.run(*segments.edited_spatial(call.f, call.q.device, self.binary_masks), mask=self.mask_planes(call.N, call.q.device))

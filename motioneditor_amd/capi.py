@@ -13,7 +13,7 @@ LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
-SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV = 0, 1, 2
+SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
 _i32, _i64, _f32, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

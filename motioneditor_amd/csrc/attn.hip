@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
-      const int key = idx / CH, cc = idx - key * CH;
-      const bool ok = idx < KT * CH && key0 + key < a.nk;
+      const int cc = idx / KT, key = idx - cc * KT;   // a wave = 64 consecutive keys of ONE 16-byte chunk column:
+      const bool ok = idx < KT * CH && key0 + key < a.nk;  // its transposed b16 stores hit 32 distinct LDS banks
       const long row = (long)kit * a.nk + key0 + key;
       rk[i] = ok ? ldg128(K + row * a.ldk + h * DH + cc * 8) : zero128();
       rv[i] = ok ? ldg128(V + row * a.ldv + h * DH + cc * 8) : zero128();
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
     for (int i = 0; i < NLD; ++i) {
       const int idx = tid + 256 * i;
       if (idx < KT * CH) {
-        const int key = idx / CH, cc = idx - key * CH;
+        const int cc = idx / KT, key = idx - cc * KT;
         *reinterpret_cast<uint4*>(sK + key * KLD + cc * 8) = rk[i];
         U128 u;
         u.u = rv[i];
@@ -167,52 +167,82 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
     }
 
     // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
+    // exp2 with log2(e)*scale folded into one FMA per element; key-tail masking only on a partial tile
+    const bool full = (kt + 1) * KT <= a.nk;
     f16x8 pf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      float x1[4][4], x2[4][4];
-      float mx = NEG_BIG;
+      if (!full) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + t * 16 + r >= a.nk) s[qt][t][r] = NEG_BIG;   // raw logit; c < 1 keeps NEG_BIG * c finite
+      }
+      float p[4][4];
+      float psum = 0.f, alpha;
       if (mode == ME_SEG_PLAIN) {
+        float mr = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
+        mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        const float mnew = fmaxf(mrun[qt], mr * c);
+        alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = kbase + t * 16 + r < a.nk;
-            x1[t][r] = ok ? s[qt][t][r] * c : NEG_BIG;
-            mx = fmaxf(mx, x1[t][r]);
+            p[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][r], c, -mnew));
+            psum += p[t][r];
+          }
+      } else if (mode == ME_SEG_DUAL_BIN) {
+        // binary mask: exactly one of the (fg, bg) copies keeps the key and the other is a zero vector with
+        // logit 0, both with the same V -> weight exp(s) + exp(0) whatever the mask bit says
+        float mr = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
+        mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        const float mnew = fmaxf(mrun[qt], fmaxf(mr * c, 0.f));
+        alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        const float e0 = __builtin_amdgcn_exp2f(-mnew);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            p[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][r], c, -mnew)) + e0;
+            if (!full && kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
+            psum += p[t][r];
           }
       } else {
+        float x1[4][4], x2[4][4];
+        float mx = NEG_BIG;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           U64 mk;
           mk.u = *reinterpret_cast<const uint2*>(sM + t * 16 + g * 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool ok = kbase + t * 16 + r < a.nk;
             const float sc = s[qt][t][r] * c;
-            const float fg = sc * (float)mk.e[r];
-            x1[t][r] = ok ? fg : NEG_BIG;
-            x2[t][r] = ok ? sc - fg : NEG_BIG;
+            const bool ok = sc > 0.5f * NEG_BIG * c;      // masked tail keys keep BOTH copies at -big
+            const float fgv = sc * (float)mk.e[r];
+            x1[t][r] = ok ? fgv : sc;
+            x2[t][r] = ok ? sc - fgv : sc;
             mx = fmaxf(mx, fmaxf(x1[t][r], x2[t][r]));
           }
         }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(mrun[qt], mx);
-      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-      mrun[qt] = mnew;
-      float psum = 0.f;
-      float p[4][4];
-      if (mode == ME_SEG_PLAIN) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p[t][r] = __builtin_amdgcn_exp2f(x1[t][r] - mnew);
-            psum += p[t][r];
-          }
-      } else {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun[qt], mx);
+        alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -10,17 +10,25 @@
 // built from v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as MFMA operand A and the ACTIVATION
 // fragment as operand B, so a lane ends up holding 4 consecutive output channels of one output row
 // (8-byte stores, bias/GEGLU epilogue without cross-lane traffic).
-// Staging: global -> registers (16-byte loads, zero-filled for padding taps / tails) -> LDS with
-// 16 bytes of row padding, double-buffered: the next K-slab's global loads are in flight while the
-// current slab feeds the MFMAs; one barrier per slab.
+//
+// Staging (STAGE_GLDS, default): global_load_lds_dwordx4 -- each wave instruction DMAs 8 rows x 128 B
+// straight into LDS (no VGPR round trip, no ds_write).  The LDS image is lane-linear, so the
+// bank-conflict fix is an XOR swizzle applied on the per-lane SOURCE chunk and again on the
+// ds_read_b128 address (chunk ^= (row >> 1) & 7): every 16-lane group of a fragment read then hits
+// 16 distinct 16-byte slots.  Padding taps / tails read a 16-byte zero buffer.  Two LDS buffers:
+// the next K-slab's DMA is in flight while the current slab feeds the MFMAs; one barrier per slab.
+// STAGE_REG keeps the first implementation (global -> VGPR -> padded LDS) for A/B runs.
 #include "me_common.h"
 #include "../../include/motioned.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 64;
-constexpr int LDS_LD = BK + 8;  // halves; 144-byte rows keep ds_read_b128 16-byte aligned
+constexpr int STAGE_REG = 0, STAGE_GLDS = 1;
+
+__device__ uint4 g_zero16;  // zero-initialised: source of every padded 16-byte chunk in the GLDS path
 
 struct RowInfo {
   // CONV3: base = img * Hin * Win, y0 = oy*stride - 1, x0 = ox*stride - 1
@@ -64,125 +72,21 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
     if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) return -1;
     return r.base + (iy >> a.ups) * a.Win + (ix >> a.ups);
   }
-  // TCONV
-  const int dt = tap - 1;
+  const int dt = tap - 1;  // TCONV
   const int fc = r.y0 + dt;
   if (fc < 0 || fc >= a.chunk) return -1;
   return r.base + dt * a.npix;
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
-  constexpr int WN = BN / 2;     // per-wave N extent
-  constexpr int NT = WN / 16;    // 16-wide n tiles per wave
-  constexpr int MT = 4;          // 16-wide m tiles per wave (64 rows)
-  constexpr int WROWS = BN / 32; // W rows staged per thread
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  f16* sX = reinterpret_cast<f16*>(smem);         // [2][BM][LDS_LD]
-  f16* sW = sX + 2 * BM * LDS_LD;                 // [2][BN][LDS_LD]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nbn = (a.N + BN - 1) / BN;
-  const int nbm = (a.M + BM - 1) / BM;
-  const int w = xcd_remap(blockIdx.x, nbm * nbn);
-  const int tile_n = w % nbn, tile_m = w / nbn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
-  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
-
-  const int taps = a.gather == ME_GATHER_CONV3 ? 9 : (a.gather == ME_GATHER_TCONV ? 3 : 1);
-  const int nkc = (a.K + BK - 1) / BK;
-  const int nit = taps * nkc;
-
-  // staging assignment: thread -> (row = tid/8 + 32*i, 16-byte chunk = tid%8)
-  const int srow = tid >> 3;
-  const int scol = (tid & 7) * 8;  // halves
-
-  RowInfo rinfo[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + 32 * i);
-
-  uint4 rx[4], rw[WROWS];
-  long xoff[4];  // element offset of the source row for the current tap, or -1
-  int cur_tap = -1;
-
-  auto gload = [&](int it) {
-    const int tap = it / nkc;
-    const int c = (it - tap * nkc) * BK + scol;
-    if (tap != cur_tap) {
-      cur_tap = tap;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = src_row(a, rinfo[i], tap);
-        xoff[i] = s < 0 ? -1L : (long)s * a.ldx;
-      }
-    }
-    const bool kok = c < a.K;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i) {
-      const int n = n0 + srow + 32 * i;
-      rw[i] = (kok && n < a.N) ? ldg128(W + ((long)n * taps + tap) * a.K + c) : zero128();
-    }
-  };
-  auto sstore = [&](int buf) {
-    f16* dx = sX + buf * BM * LDS_LD;
-    f16* dw = sW + buf * BN * LDS_LD;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + 32 * i) * LDS_LD + scol) = rx[i];
-#pragma unroll
-    for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + 32 * i) * LDS_LD + scol) = rw[i];
-  };
-
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  gload(0);
-  sstore(0);
-  __syncthreads();
-
-  const int frow = lane & 15;
-  const int fk = (lane >> 4) * 8;
-
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nit) gload(it + 1);
-    const f16* bx = sX + buf * BM * LDS_LD + (wm * 64 + frow) * LDS_LD + fk;
-    const f16* bw = sW + buf * BN * LDS_LD + (wn * WN + frow) * LDS_LD + fk;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      f16x8 fx[MT], fw[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) fx[i] = *reinterpret_cast<const f16x8*>(bx + i * 16 * LDS_LD + ks * 32);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const f16x8*>(bw + j * 16 * LDS_LD + ks * 32);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(fw[j], fx[i], acc[j][i]);
-    }
-    if (it + 1 < nit) sstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile ----
+// lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i]
+template <int NT, int MT, int WN>
+__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn, int lane) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
   const f16* res2 = reinterpret_cast<const f16*>(a.res2);
   f16* C = reinterpret_cast<f16*>(a.C);
   const int nq = (lane >> 4) * 4;
-
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -264,16 +168,197 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
   }
 }
 
+template <int BN, int STAGE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
+  constexpr int WN = BN / 2;      // per-wave N extent
+  constexpr int NT = WN / 16;     // 16-wide n tiles per wave
+  constexpr int MT = 4;           // 16-wide m tiles per wave (64 rows)
+  constexpr int WROWS = BN / 32;  // W rows staged per thread
+  constexpr int LD = STAGE == STAGE_GLDS ? BK : BK + 8;  // LDS row stride in halves
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f16* sX = reinterpret_cast<f16*>(smem);  // [2][BM][LD]
+  f16* sW = sX + 2 * BM * LD;              // [2][BN][LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM;
+  const int w = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tile_n = w % nbn, tile_m = w / nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
+  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
+
+  const int taps = a.gather == ME_GATHER_CONV3 ? 9 : (a.gather == ME_GATHER_TCONV ? 3 : 1);
+  const int nkc = (a.K + BK - 1) / BK;
+  const int nit = taps * nkc;
+
+  // staging assignment
+  //   REG : thread -> rows tid/8 + 32*i, 16-byte chunk tid%8
+  //   GLDS: wave instruction q = wave + 4*i covers rows 8q..8q+7; lane -> row 8q + lane/8, LDS chunk slot lane%8,
+  //         which holds source chunk (lane%8) ^ swz, swz = (row >> 1) & 7 = (4*(wave&1) + (lane>>4)) & 7 for every i
+  int srow, scol;
+  if (STAGE == STAGE_GLDS) {
+    srow = wave * 8 + (lane >> 3);
+    scol = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  } else {
+    srow = tid >> 3;
+    scol = (tid & 7) * 8;
+  }
+
+  RowInfo rinfo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + 32 * i);
+
+  long xoff[4];  // element offset of the source row for the current tap, or -1
+  int cur_tap = -1;
+  auto set_tap = [&](int tap) {
+    if (tap != cur_tap) {
+      cur_tap = tap;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = src_row(a, rinfo[i], tap);
+        xoff[i] = s < 0 ? -1L : (long)s * a.ldx;
+      }
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fg = lane >> 4;
+
+  auto compute = [&](int buf) {
+    const f16* bx = sX + buf * BM * LD;
+    const f16* bw = sW + buf * BN * LD;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      f16x8 fx[MT], fw[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        const int ch = STAGE == STAGE_GLDS ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
+        fx[i] = *reinterpret_cast<const f16x8*>(bx + row * LD + ch * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + frow;
+        const int ch = STAGE == STAGE_GLDS ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
+        fw[j] = *reinterpret_cast<const f16x8*>(bw + row * LD + ch * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(fw[j], fx[i], acc[j][i]);
+    }
+  };
+
+  if constexpr (STAGE == STAGE_GLDS) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const f16* zsrc = reinterpret_cast<const f16*>(&g_zero16);
+    auto gload = [&](int it, int buf) {
+      const int tap = it / nkc;
+      const int c = (it - tap * nkc) * BK + scol;
+      set_tap(tap);
+      const bool kok = c < a.K;
+      char* dx = reinterpret_cast<char*>(sX + buf * BM * LD) + wave * 1024;
+      char* dw = reinterpret_cast<char*>(sW + buf * BN * LD) + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f16* src = (kok && xoff[i] >= 0) ? X + xoff[i] + c : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dx + i * 4096), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < WROWS; ++i) {
+        const int n = n0 + srow + 32 * i;
+        const f16* src = (kok && n < a.N) ? W + ((long)n * taps + tap) * a.K + c : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dw + i * 4096), 16, 0, 0);
+      }
+    };
+    gload(0, 0);
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int buf = it & 1;
+      if (it + 1 < nit) gload(it + 1, buf ^ 1);
+      compute(buf);
+      __syncthreads();  // LDS-DMA pending -> the compiler drains vmcnt(0) here: next slab landed, this slab free
+    }
+  } else {
+    uint4 rx[4], rw[WROWS];
+    auto gload = [&](int it) {
+      const int tap = it / nkc;
+      const int c = (it - tap * nkc) * BK + scol;
+      set_tap(tap);
+      const bool kok = c < a.K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
+#pragma unroll
+      for (int i = 0; i < WROWS; ++i) {
+        const int n = n0 + srow + 32 * i;
+        rw[i] = (kok && n < a.N) ? ldg128(W + ((long)n * taps + tap) * a.K + c) : zero128();
+      }
+    };
+    auto sstore = [&](int buf) {
+      f16* dx = sX + buf * BM * LD;
+      f16* dw = sW + buf * BN * LD;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + 32 * i) * LD + scol) = rx[i];
+#pragma unroll
+      for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + 32 * i) * LD + scol) = rw[i];
+    };
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int buf = it & 1;
+      if (it + 1 < nit) gload(it + 1);
+      compute(buf);
+      if (it + 1 < nit) sstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane);
+}
+
+int stage_impl() {
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("ME_GEMM_STAGE");
+    impl = (e && e[0] == 'r') ? STAGE_REG : STAGE_GLDS;  // ME_GEMM_STAGE=reg selects the register-staged kernel
+  }
+  return impl;
+}
+
+bool tile160() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ME_GEMM_TILE160");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
 }  // namespace
 
 extern "C" void me_set_error(const char* msg);
 
-template <int BN>
+template <int BN, int STAGE>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(f16);
+  const size_t lds = (size_t)2 * (BM + BN) * (STAGE == STAGE_GLDS ? BK : BK + 8) * sizeof(f16);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return ME_EHIP;
     }
@@ -281,7 +366,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   }
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL(gemm_kernel<BN>, dim3(nbm * nbn), dim3(256), lds, st, *a);
+  hipLaunchKernelGGL((gemm_kernel<BN, STAGE>), dim3(nbm * nbn), dim3(256), lds, st, *a);
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");
     return ME_EHIP;
@@ -309,6 +394,12 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
   if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act)) { me_set_error("me_gemm: geglu needs N % 32 == 0 and no rowvec/res/act"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (a->N % 128 == 0 || a->N % 64 != 0) return launch_gemm<128>(a, st);
-  return launch_gemm<64>(a, st);
+  // N tile: every channel count of the model (320 ... 10240) is a multiple of 160 -> exact 128x160 tiles;
+  // GEGLU needs whole (value, gate) 32-row pairs per wave -> 128; leftovers (4, 16, 32, 96, 256) -> 128 / 64 with a tail
+  const bool wide = a->N % 128 == 0 || a->N % 64 != 0;
+  if (stage_impl() == STAGE_GLDS) {
+    if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<160, STAGE_GLDS>(a, st);
+    return wide ? launch_gemm<128, STAGE_GLDS>(a, st) : launch_gemm<64, STAGE_GLDS>(a, st);
+  }
+  return wide ? launch_gemm<128, STAGE_REG>(a, st) : launch_gemm<64, STAGE_REG>(a, st);
 }

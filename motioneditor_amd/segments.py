@@ -9,7 +9,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .capi import SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_PLAIN
+from .capi import SEG_DUAL_BIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_PLAIN
 
 _cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 KEY_UNITS: Dict[int, int] = {}  # seg_item.data_ptr() -> sum over items of (1 per plain, 2 per dual segment); FLOP accounting only
@@ -57,11 +57,13 @@ def first_prev_chunked(B: int, f: int, chunk: int, device):
     return _mk(("firstprev", B, f, chunk), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
 
 
-def edited_spatial(f: int, device):
+def edited_spatial(f: int, device, binary_mask: bool = False):
     """FullySelfAttentionControlMask on batch 4 = [u.rec, u.edit, c.rec, c.edit] (fully_control.py:425-447):
     recon rows keep [prev | cur]; edit rows attend [src prev (fg/bg dual, mask frame max(head-1,0)) |
     src cur (dual, mask frame head) | own cur]; the edit branch's prev-frame K/V are dropped
-    (k[:, 3N:], fully_control.py:383)."""
+    (k[:, 3N:], fully_control.py:383).  With a binary mask (the reference's man.mask PNGs are 0/255) the
+    fg/bg pair of every source key weighs exp(s) + exp(0) whichever way the bit points, so the kernel's
+    DUAL_BIN mode needs no mask read."""
     rows, modes = [], []
     for b in range(4):
         for i in range(f):
@@ -71,5 +73,5 @@ def edited_spatial(f: int, device):
             else:
                 s = (b - 1) * f
                 rows.append([s + max(i - 1, 0), s + i, b * f + i])
-                modes.append([SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
-    return _mk(("edited", f), rows, modes, device)
+                modes.append([SEG_DUAL_BIN, SEG_DUAL_BIN, SEG_PLAIN] if binary_mask else [SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
+    return _mk(("edited", f, binary_mask), rows, modes, device)

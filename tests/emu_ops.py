@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 import torch.nn.functional as F
 
-SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV = 0, 1, 2
+SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
 
 def _f(t):
@@ -112,6 +112,9 @@ def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=N
             if mode == SEG_PLAIN:
                 logits.append(sc)
                 vals.append(vs)
+            elif mode == SEG_DUAL_BIN:   # binary mask: one copy keeps the key, the other is a zero vector (logit 0)
+                logits += [sc, torch.zeros_like(sc)]
+                vals += [vs, vs]
             else:
                 planes = torch.tensor([(h if mode == SEG_DUAL_CUR else max(h - 1, 0)) for h in range(heads)])
                 m = mk[planes][:, None, :]                     # [H, 1, nk]

@@ -179,6 +179,21 @@ def test_attention_edited_dual_mask_5N_keys(ops, dh, N, binary):
     check(got, want, f"attn edited dh={dh} N={N} binary={binary}")
 
 
+@pytest.mark.parametrize("dh,N", [(40, 64), (80, 100), (40, 256)])
+def test_attention_edited_binary_fast_path_equals_general_dual(ops, dh, N):
+    """DUAL_BIN (no mask read) must equal the general dual-mask formula for any BINARY mask."""
+    from motioneditor_amd import segments
+    f, C = 8, 8 * dh
+    qkv = rnd(4 * f * N, 3 * C, seed=1)
+    mask = (torch.rand(8, N, generator=torch.Generator().manual_seed(7)) > 0.4).half()
+    si, sm = segments.edited_spatial(f, "cpu", binary_mask=True)
+    sg, smg = segments.edited_spatial(f, "cpu", binary_mask=False)
+    args = dict(heads=8, dh=dh, n_items=4 * f, nq=N, nk=N)
+    got = ops.attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), mask=cu(mask), **args)
+    want = emu.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=sg, seg_mode=smg, mask=mask, **args)
+    check(got, want, f"attn edited binary fast path dh={dh} N={N}")
+
+
 def test_attention_large_logits_online_softmax_rescale(ops):
     """Force the running max to jump late (a spiked key in the LAST tile) so the rescale path matters."""
     dh, nq, nk, C = 40, 64, 300, 320

@@ -1,0 +1,106 @@
+"""Kernel micro-benchmarks on the GPU box: python tools/kbench.py [gemm] [attn] [misc]
+Times representative config-3 (24f x 512^2, B=4) launches with HIP events (median of N reps)."""
+import sys
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from motioneditor_amd import ops, segments  # noqa: E402
+
+dev = "cuda"
+REPS = 7
+
+
+def timeit(fn):
+    fn(); fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(REPS):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def rnd(*s):
+    return (torch.randn(*s, device=dev) * 0.5).half()
+
+
+def bench_gemm():
+    B, f = 4, 24
+    L = [(64, 320), (32, 640), (16, 1280), (8, 1280)]
+    rows = []
+    for li, (hw, C) in enumerate(L):
+        M = B * f * hw * hw
+        rows += [(f"L{li} qkv", M, 3 * C, C, None, None, False), (f"L{li} out", M, C, C, None, None, False),
+                 (f"L{li} ff1 geglu", M, 8 * C, C, None, None, True), (f"L{li} ff2", M, C, 4 * C, None, None, False),
+                 (f"L{li} conv3x3", M, C, C, (hw, hw, hw, hw, 1, 0), None, False), (f"L{li} tconv", M, C, C, None, (f, hw * hw, f), False)]
+    rows += [("L0 conv 960->320", B * f * 4096, 320, 960, (64, 64, 64, 64, 1, 0), None, False),
+             ("L1 conv 1920->640", B * f * 1024, 640, 1920, (32, 32, 32, 32, 1, 0), None, False),
+             ("L0 conv_out 320->4", B * f * 4096, 4, 320, (64, 64, 64, 64, 1, 0), None, False),
+             ("cond 16->16 @512", 48 * 512 * 512, 16, 16, (512, 512, 512, 512, 1, 0), None, False),
+             ("cond 96->256 s2", 48 * 64 * 64, 256, 96, (128, 128, 64, 64, 2, 0), None, False)]
+    print(f"{'gemm':24s} {'M':>8s} {'N':>6s} {'K':>6s} {'ms':>8s} {'TF/s':>7s}")
+    tot = 0
+    for name, M, N, K, conv, tconv, geglu in rows:
+        taps = 9 if conv else (3 if tconv else 1)
+        rows_in = M if not conv else (M // (conv[2] * conv[3])) * conv[0] * conv[1]
+        x, w = rnd(rows_in, K), rnd(N, taps, K)
+        ms = timeit(lambda: ops.gemm(x, w, M=M, conv=conv, tconv=tconv, geglu=geglu))
+        tot += ms
+        print(f"{name:24s} {M:8d} {N:6d} {K*taps:6d} {ms:8.3f} {2.0*M*N*K*taps/ms/1e9:7.1f}")
+        del x, w
+    print("sum ms", round(tot, 2))
+
+
+def bench_attn():
+    B, f = 4, 24
+    print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
+    for name, dh, N, seg, items, mask in [("L0 prev|cur", 40, 4096, "pc", B * f, False), ("L0 edited", 40, 4096, "ed", B * f, True),
+                                          ("L0 self (cn)", 40, 4096, "self", 2 * f, False), ("L0 cross 77", 40, 4096, "cross", B * f, False),
+                                          ("L1 prev|cur", 80, 1024, "pc", B * f, False), ("L1 edited", 80, 1024, "ed", B * f, True),
+                                          ("L2 prev|cur", 160, 256, "pc", B * f, False)]:
+        C = 8 * dh
+        nk = 77 if seg == "cross" else N
+        q = rnd(items * N, 3 * C)
+        kv = rnd(B * 77, 2 * C) if seg == "cross" else None
+        si, sm = {"pc": lambda: segments.prev_cur(B, f, dev), "ed": lambda: segments.edited_spatial(f, dev),
+                  "self": lambda: segments.self_items(items, dev), "cross": lambda: segments.cross_text(B, f, dev)}[seg]()
+        mk = (torch.rand(8, N, device=dev) > 0.5).half() if mask else None
+        if seg == "cross":
+            fn = lambda: ops.attention(q[:, :C], kv[:, :C], kv[:, C:], heads=8, dh=dh, n_items=items, nq=N, nk=nk, seg_item=si, seg_mode=sm)
+        else:
+            fn = lambda: ops.attention(q[:, :C], q[:, C:2 * C], q[:, 2 * C:], heads=8, dh=dh, n_items=items, nq=N, nk=nk, seg_item=si, seg_mode=sm, mask=mk)
+        ms = timeit(fn)
+        units = segments.KEY_UNITS[si.data_ptr()]
+        print(f"{name:28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
+        del q
+
+
+def bench_misc():
+    B, f = 4, 24
+    for C, hw in [(320, 64), (640, 32), (1280, 16)]:
+        M = B * f * hw * hw
+        x = rnd(M, 3 * C)
+        ms = timeit(lambda: ops.temporal_attention(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], heads=8, dh=C // 8, batch=B, frames=f, npix=hw * hw))
+        print(f"tattn C={C} {ms:.3f} ms  {8.0*M*C/ms/1e6:.0f} GB/s")
+        y, g, b = rnd(M, C), rnd(C), rnd(C)
+        ms = timeit(lambda: ops.groupnorm(y, g, b, rows_per_group=f * hw * hw, eps=1e-5, silu=True))
+        print(f"groupnorm C={C} {ms:.3f} ms  {4.0*M*C/ms/1e6:.0f} GB/s (algorithmic)")
+        ms = timeit(lambda: ops.layernorm(y, g, b))
+        print(f"layernorm C={C} {ms:.3f} ms  {4.0*M*C/ms/1e6:.0f} GB/s")
+        del x, y
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["gemm", "attn", "misc"]
+    if "gemm" in what:
+        bench_gemm()
+    if "attn" in what:
+        bench_attn()
+    if "misc" in what:
+        bench_misc()
