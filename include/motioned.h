@@ -121,8 +121,9 @@ typedef struct me_attn_args {
   const int32_t* seg_item; /* device int32 [n_items][nseg]: kv item index of each segment; a negative
                               entry ends the item's segment list (skipped segments must come last) */
   const int32_t* seg_mode; /* device int32 [n_items][nseg]: ME_SEG_*                       */
-  const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL modes)              */
+  const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL_CUR / DUAL_PREV)     */
   float scale;
+  int32_t general_dual;    /* 1 when any seg_mode is DUAL_CUR / DUAL_PREV (selects the kernel built with that path) */
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);

@@ -45,7 +45,7 @@ class AttnArgs(C.Structure):
         ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32),
         ("heads", _i32), ("dh", _i32),
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
-        ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32),
+        ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
     ]
 
 

@@ -20,6 +20,7 @@
 //                   MFMA k-slot (g, j) carries key kk*32 + (j>>2)*16 + g*4 + (j&3) for BOTH operands.
 #include "me_common.h"
 #include "../../include/motioned.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,8 +28,8 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: conflict-free ds_read_b64)
 
-template <int DH, int QT>
-__global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
+template <int DH, int QT, bool GD, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int CH = DH / 8;
   constexpr int D32 = (DH + 31) / 32;
   constexpr int DT = (DH + 15) / 16;
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
             if (!full && kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
             psum += p[t][r];
           }
-      } else {
+      } else if constexpr (GD) {
+        // general (non-binary) masks: both copies' logits are needed.  Compiled only into the GD instantiation
         float x1[4][4], x2[4][4];
         float mx = NEG_BIG;
 #pragma unroll
@@ -302,14 +304,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const me_attn_args a) {
   }
 }
 
-template <int DH, int QT>
+template <int DH, int QT, bool GD, int MINW>
 int launch_attn(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 64 * QT;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((attn_kernel<DH, QT>), dim3((unsigned)total), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW>), dim3((unsigned)total), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
+}
+
+int variant() {   // ME_ATTN_VARIANT=1: one 16-query tile per wave (fewer registers, more waves per SIMD) -- A/B knob
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("ME_ATTN_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 }  // namespace
@@ -324,9 +335,17 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   switch (a->dh) {
-    case 40: rc = launch_attn<40, 2>(a, st); break;
-    case 80: rc = launch_attn<80, 2>(a, st); break;
-    case 160: rc = launch_attn<160, 1>(a, st); break;
+    case 40:
+      if (a->general_dual) rc = launch_attn<40, 2, true, 2>(a, st);
+      else if (variant() == 1) rc = launch_attn<40, 1, false, 4>(a, st);
+      else rc = launch_attn<40, 2, false, 3>(a, st);
+      break;
+    case 80:
+      if (a->general_dual) rc = launch_attn<80, 2, true, 2>(a, st);
+      else if (variant() == 1) rc = launch_attn<80, 1, false, 3>(a, st);
+      else rc = launch_attn<80, 2, false, 2>(a, st);
+      break;
+    case 160: rc = a->general_dual ? launch_attn<160, 1, true, 2>(a, st) : launch_attn<160, 1, false, 2>(a, st); break;
     default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
   }
   if (rc != ME_OK) me_set_error("me_attn: kernel launch failed");

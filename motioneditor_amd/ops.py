@@ -150,11 +150,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
     a.n_items, a.nq, a.nk, a.nseg = n_items, nq, nk, seg_item.shape[1]
     a.seg_item, a.seg_mode, a.mask = seg_item.data_ptr(), seg_mode.data_ptr(), _p(mask)
     a.scale = dh ** -0.5 if scale is None else scale
+    from . import segments
+    gd = segments.GENERAL_DUAL.get(seg_mode.data_ptr())
+    if gd is None:   # table not built (and kept alive) by segments.py: inspect it, never cache a transient pointer
+        gd = bool(((seg_mode == 1) | (seg_mode == 2)).any().item())
+    a.general_dual = 1 if gd else 0
     e0 = _pb()
     capi.check(capi.lib().me_attn(C.byref(a), _stream()), "me_attn")
     if e0 is not None:
         # reference-semantics key count: a dual (fg|bg) segment is 2*nk materialised keys (fully_control.py:381-413)
-        from . import segments
         units = segments.KEY_UNITS.get(seg_item.data_ptr())
         if units is None:
             sm, si = seg_mode.tolist(), seg_item.tolist()
