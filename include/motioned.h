@@ -82,7 +82,8 @@ int me_gemm(const me_gemm_args* a, void* stream);
  * conv_in of the UNet / ControlNet on fp32 latents in the REFERENCE layout, and the first conv of
  * controlnet_cond_embedding.  Replaces InflatedConv3d conv_in (unet_2d_condition.py:160,451).
  * in : fp32, element (img, c, y, x) at  in[img*img_stride + c*ch_stride + y*Win + x]
- * out: fp16 channels-last [n_img*H*W, Cout]; W fp16 [Cout][9][Cin]; 3x3 pad 1 stride 1.
+ * out: fp16 channels-last [n_img*H*W, Cout]; W, bias fp32, W [Cout][9][Cin] (read through the scalar
+ * cache); C_in in {3, 4}; 3x3 pad 1 stride 1.
  */
 typedef struct me_conv_small_args {
   const void* in;

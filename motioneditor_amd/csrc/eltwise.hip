@@ -5,14 +5,14 @@
 
 namespace {
 
-// one thread = one output pixel x 8 consecutive output channels
-__global__ __launch_bounds__(256) void conv_small_kernel(const me_conv_small_args a) {
-  const int cgs = a.Cout / 8;
-  const long total = (long)a.n_img * a.H * a.Wd * cgs;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int cgi = (int)(idx % cgs);
-  const long pix = idx / cgs;
+// Direct 3x3 conv for C_in <= 8.  One thread = one output pixel; blockIdx.y picks a slice of output
+// channels.  The 9*C_in inputs sit in registers; weights/bias are fp32 and indexed only by wave-uniform
+// values, so they arrive through the scalar cache (s_load) and feed v_fma as SGPR operands.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_small_kernel(const me_conv_small_args a, int co_per_block) {
+  const long npix = (long)a.n_img * a.H * a.Wd;
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
   const int x = (int)(pix % a.Wd);
   const int y = (int)((pix / a.Wd) % a.H);
   const int img = (int)(pix / ((long)a.Wd * a.H));
@@ -20,26 +20,40 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const me_conv_small_arg
   if (a.frames > 0) base = (long)(img / a.frames) * a.img_stride + (long)(img % a.frames) * a.frame_stride;
   else base = (long)img * a.img_stride;
 
-  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
-  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
-  float acc[8];
+  float in[9][CIN];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = bias ? (float)bias[cgi * 8 + e] : 0.f;
-
   for (int tap = 0; tap < 9; ++tap) {
     const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-    if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.Wd) continue;
-    for (int ci = 0; ci < a.Cin; ++ci) {
-      const long off = base + (long)ci * a.ch_stride + (long)iy * a.Wd + ix;
-      const float v = a.in_is_f16 ? (float)reinterpret_cast<const f16*>(a.in)[off] : reinterpret_cast<const float*>(a.in)[off];
+    const bool ok = iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += v * (float)W[((long)(cgi * 8 + e) * 9 + tap) * a.Cin + ci];
+    for (int ci = 0; ci < CIN; ++ci) {
+      const long off = base + (long)ci * a.ch_stride + (long)iy * a.Wd + ix;
+      float v = 0.f;
+      if (ok) v = a.in_is_f16 ? (float)reinterpret_cast<const f16*>(a.in)[off] : reinterpret_cast<const float*>(a.in)[off];
+      in[tap][ci] = v;
     }
   }
-  U128 o;
+  const float* __restrict__ W = reinterpret_cast<const float*>(a.W);
+  const float* __restrict__ bias = reinterpret_cast<const float*>(a.bias);
+  f16* out = reinterpret_cast<f16*>(a.out) + pix * a.Cout;
+  const int c0 = blockIdx.y * co_per_block;
+  for (int cb = c0; cb < c0 + co_per_block && cb < a.Cout; cb += 8) {
+    float acc[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o.e[e] = (f16)(a.silu ? silu_f(acc[e]) : acc[e]);
-  *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(a.out) + pix * a.Cout + cgi * 8) = o.u;
+    for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[cb + e] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* w = W + (long)(cb + e) * 9 * CIN;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) acc[e] = __builtin_fmaf(in[tap][ci], w[tap * CIN + ci], acc[e]);
+    }
+    U128 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = (f16)(a.silu ? silu_f(acc[e]) : acc[e]);
+    *reinterpret_cast<uint4*>(out + cb) = o.u;
+  }
 }
 
 // Y = X + alpha * A over a [rows, cols] view, 4 halves per thread
@@ -161,10 +175,13 @@ extern "C" void me_set_error(const char* msg);
 
 extern "C" int me_conv_small(const me_conv_small_args* a, void* stream) {
   if (!a || !a->in || !a->W || !a->out) { me_set_error("me_conv_small: null pointer"); return ME_EINVAL; }
-  if (a->Cin <= 0 || a->Cin > 8 || a->Cout % 8 || a->n_img <= 0 || a->H <= 0 || a->Wd <= 0) { me_set_error("me_conv_small: bad geometry"); return ME_EINVAL; }
-  const long total = (long)a->n_img * a->H * a->Wd * (a->Cout / 8);
+  if ((a->Cin != 3 && a->Cin != 4) || a->Cout % 8 || a->n_img <= 0 || a->H <= 0 || a->Wd <= 0) { me_set_error("me_conv_small: C_in must be 3 or 4, C_out a multiple of 8"); return ME_EINVAL; }
+  const long npix = (long)a->n_img * a->H * a->Wd;
+  const int co_per_block = a->Cout > 80 ? 80 : a->Cout;   // wide outputs: slices of 80 channels per block row
+  const dim3 grid((unsigned)((npix + 255) / 256), (unsigned)((a->Cout + co_per_block - 1) / co_per_block));
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a);
+  if (a->Cin == 3) hipLaunchKernelGGL(conv_small_kernel<3>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a, co_per_block);
+  else hipLaunchKernelGGL(conv_small_kernel<4>, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), *a, co_per_block);
   ME_CHECK_LAUNCH("me_conv_small")
 }
 

@@ -260,7 +260,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     tseg = segments.cross_text(B, f, dev)
     kw = dict(spatial=spatial, temporal=temporal)
 
-    x = Act(ops.conv_small(sample, P.mat("conv_in.weight"), P.vec("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
+    x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
                            img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
     skips = [x]
     for i in range(4):
@@ -355,14 +355,14 @@ def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int
     # conditioning embedding: 3->16 (direct), then 16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2 (SiLU each), 256->320
     H8, W8 = cond.shape[-2], cond.shape[-1]
     cond = cond.contiguous()
-    c = Act(ops.conv_small(cond, P.mat("controlnet_cond_embedding.conv_in.weight"), P.vec("controlnet_cond_embedding.conv_in.bias"),
+    c = Act(ops.conv_small(cond, P.mat32("controlnet_cond_embedding.conv_in.weight"), P.vec32("controlnet_cond_embedding.conv_in.bias"),
                            n_img=nimg, Cin=3, H=H8, Wd=W8, img_stride=3 * H8 * W8, ch_stride=H8 * W8, silu=True), nimg, 1, H8, W8)
     for i in range(6):
         c = conv3x3(P, f"controlnet_cond_embedding.blocks.{i}", c, stride=2 if i % 2 == 1 else 1, act=2)
     # conv_in(sample) per ControlNet batch entry, then + cond embedding in the last cond conv's epilogue
     x0 = torch.empty((nimg * h * w, 320), dtype=P.dtype, device=dev)
     for bi, li in enumerate(lat_index):
-        part = ops.conv_small(latents[li], P.mat("conv_in.weight"), P.vec("conv_in.bias"), n_img=f, Cin=4, H=h, Wd=w,
+        part = ops.conv_small(latents[li], P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=f, Cin=4, H=h, Wd=w,
                               img_stride=h * w, ch_stride=f * h * w)
         ops.copy_rows(x0[bi * f * h * w:(bi + 1) * f * h * w], part)
     x = conv3x3(P, "controlnet_cond_embedding.conv_out", c, res=x0)

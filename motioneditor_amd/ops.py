@@ -116,6 +116,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
 
 def conv_small(inp: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n_img: int, Cin: int, H: int, Wd: int,
                img_stride: int, ch_stride: int, frames: int = 0, frame_stride: int = 0, silu: bool = False) -> torch.Tensor:
+    if w.dtype != torch.float32 or (bias is not None and bias.dtype != torch.float32):
+        raise ValueError("conv_small: weights and bias must be fp32")
     Cout = w.shape[0]
     out = torch.empty((n_img * H * Wd, Cout), dtype=F16, device=inp.device)
     a = ConvSmallArgs()

@@ -68,6 +68,19 @@ class Packed:
         k = "mat:" + name
         return self.cache.get(k) if k in self.cache else self._put(k, self._as_taps(self.raw(name)))
 
+    def mat32(self, name: str) -> torch.Tensor:
+        """fp32 [N, taps, K] (conv_small reads its tiny weights through the scalar cache)."""
+        k = "mat32:" + name
+        if k not in self.cache:
+            self.cache[k] = self._as_taps(self.raw(name)).contiguous().to(self.device)
+        return self.cache[k]
+
+    def vec32(self, name: str) -> torch.Tensor:
+        k = "vec32:" + name
+        if k not in self.cache:
+            self.cache[k] = self.raw(name).reshape(-1).contiguous().to(self.device)
+        return self.cache[k]
+
     def fused(self, names: Iterable[str]) -> torch.Tensor:
         """Row-concatenation of several projections that share an input (q|k|v, k|v)."""
         names = list(names)

@@ -89,7 +89,7 @@ def conv_small(inp, w, bias, *, n_img, Cin, H, Wd, img_stride, ch_stride, frames
     y = F.conv2d(x, w.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), _f(bias), padding=1)
     if silu:
         y = F.silu(y)
-    return y.permute(0, 2, 3, 1).reshape(-1, Cout).to(w.dtype)
+    return y.permute(0, 2, 3, 1).reshape(-1, Cout).to(_EMU_DTYPE if w.dtype == torch.float32 else w.dtype)
 
 
 def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, out=None):

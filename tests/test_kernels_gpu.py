@@ -124,14 +124,14 @@ def test_gemm_rejects_bad_arguments(ops):
 def test_conv_small_5d_latents_and_images(ops):
     B, f, h, w = 2, 3, 6, 5
     lat = torch.randn(B, 4, f, h, w, generator=torch.Generator().manual_seed(1))
-    W = rnd(320, 9, 4, seed=2, scale=1 / 6)
-    b = rnd(320, seed=3)
+    W = rnd(320, 9, 4, seed=2, scale=1 / 6).float()
+    b = rnd(320, seed=3).float()
     kw = dict(n_img=B * f, Cin=4, H=h, Wd=w, img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w)
     check(ops.conv_small(cu(lat), cu(W), cu(b), **kw), emu.conv_small(lat, W, b, **kw), "conv_in 5-D")
     img = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(4))
-    W = rnd(16, 9, 3, seed=5, scale=1 / 5)
+    W = rnd(16, 9, 3, seed=5, scale=1 / 5).float()
     kw = dict(n_img=4, Cin=3, H=16, Wd=16, img_stride=3 * 256, ch_stride=256, silu=True)
-    check(ops.conv_small(cu(img), cu(W), cu(rnd(16, seed=6)), **kw), emu.conv_small(img, W, rnd(16, seed=6), **kw), "cond conv_in")
+    check(ops.conv_small(cu(img), cu(W), cu(rnd(16, seed=6).float()), **kw), emu.conv_small(img, W, rnd(16, seed=6), **kw), "cond conv_in")
 
 
 # ------------------------------------------------------------------ attention
