@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,12 +169,21 @@ def main():
                "achieved_tflops_whole_step": round(step_tflop(f, h, w) * args.steps / dt * (1 if world == 1 else 1), 1)}
         if prof:
             fam = {}
-            for name, fl, by, e0, e1 in prof:
+            shapes = {}
+            for name, fl, by, e0, e1, detail in prof:
                 d = fam.setdefault(name, [0.0, 0.0, 0.0, 0])
                 d[0] += e0.elapsed_time(e1) * 1e-3
                 d[1] += fl
                 d[2] += by
                 d[3] += 1
+                if detail:
+                    sd = shapes.setdefault(detail, [0.0, 0.0, 0])
+                    sd[0] += e0.elapsed_time(e1) * 1e-3
+                    sd[1] += fl
+                    sd[2] += 1
+            if args.shapes:
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:40]:
+                    print(f"[shape] {k:44s} {v[0] / args.steps * 1e3:8.2f} ms/step {v[2] // args.steps:4d} launches {v[1] / v[0] / 1e12:7.1f} TF/s", file=sys.stderr)
             tot = sum(v[0] for v in fam.values())
             dom = max(fam, key=lambda k: fam[k][0])
             tsec, fl, by, n = fam[dom]

@@ -28,7 +28,7 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: conflict-free ds_read_b64)
 
-template <int DH, int QT, bool GD, int MINW>
+template <int DH, int QT, bool GD, int MINW, int NBUF>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int CH = DH / 8;
   constexpr int D32 = (DH + 31) / 32;
@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int BQ = 64 * QT;
   constexpr int NLD = (KT * CH + 255) / 256;
 
-  __shared__ __attribute__((aligned(16))) f16 sK[KT * KLD];
-  __shared__ __attribute__((aligned(16))) f16 sVt[DT * 16 * VLD];
-  __shared__ __attribute__((aligned(16))) f16 sM[KT];
+  // two LDS stages: tile t+1 is stored while tile t is consumed -> one barrier per tile
+  __shared__ __attribute__((aligned(16))) f16 sKb[NBUF][KT * KLD];
+  __shared__ __attribute__((aligned(16))) f16 sVtb[NBUF][DT * 16 * VLD];
+  __shared__ __attribute__((aligned(16))) f16 sMb[NBUF][KT];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   f16* __restrict__ O = reinterpret_cast<f16*>(a.O);
 
   // zero the LDS padding that staging never writes (K columns >= DH, V^T rows >= DH)
-  for (int i = tid; i < KT * KLD; i += 256) sK[i] = (f16)0.f;
-  for (int i = tid; i < DT * 16 * VLD; i += 256) sVt[i] = (f16)0.f;
+  for (int i = tid; i < NBUF * KT * KLD; i += 256) (&sKb[0][0])[i] = (f16)0.f;
+  for (int i = tid; i < NBUF * DT * 16 * VLD; i += 256) (&sVtb[0][0])[i] = (f16)0.f;
 
   // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
   f16x8 fq[QT][D32];
@@ -105,6 +106,9 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     }
   };
   auto sstore = [&](int ti) {
+    f16* sK = sKb[ti & (NBUF - 1)];
+    f16* sVt = sVtb[ti & (NBUF - 1)];
+    f16* sM = sMb[ti & (NBUF - 1)];
     const int seg = ti / ntk, kt = ti - seg * ntk;
     const int mode = a.seg_mode[item * a.nseg + seg];
 #pragma unroll
@@ -140,12 +144,17 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  if (T > 0) gload(0);
+  __syncthreads();  // LDS zero-fill visible before the first stage is written
+  if (T > 0) {
+    gload(0);
+    sstore(0);
+    if (T > 1) gload(1);
+  }
+  __syncthreads();
   for (int ti = 0; ti < T; ++ti) {
-    __syncthreads();
-    sstore(ti);
-    __syncthreads();
-    if (ti + 1 < T) gload(ti + 1);
+    const f16* sK = sKb[ti & (NBUF - 1)];
+    const f16* sVt = sVtb[ti & (NBUF - 1)];
+    const f16* sM = sMb[ti & (NBUF - 1)];
 
     const int seg = ti / ntk, kt = ti - seg * ntk;
     const int mode = a.seg_mode[item * a.nseg + seg];
@@ -282,6 +291,13 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.h, pf[qt][kk], o[qt][dt]);
       }
     }
+    // stage tile ti+1 into the other buffer (every wave finished reading it one barrier ago), prefetch ti+2
+    if (ti + 1 < T) {
+      if (NBUF == 1) __syncthreads();  // single stage: everyone must be done reading it first
+      sstore(ti + 1);
+      if (ti + 2 < T) gload(ti + 2);
+    }
+    __syncthreads();
   }
 
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] / l ----
@@ -304,13 +320,13 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   }
 }
 
-template <int DH, int QT, bool GD, int MINW>
+template <int DH, int QT, bool GD, int MINW, int NBUF>
 int launch_attn(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 64 * QT;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW>), dim3((unsigned)total), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW, NBUF>), dim3((unsigned)total), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }
 
@@ -336,16 +352,16 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   int rc;
   switch (a->dh) {
     case 40:
-      if (a->general_dual) rc = launch_attn<40, 2, true, 2>(a, st);
-      else if (variant() == 1) rc = launch_attn<40, 1, false, 4>(a, st);
-      else rc = launch_attn<40, 2, false, 3>(a, st);
+      if (a->general_dual) rc = launch_attn<40, 2, true, 2, 1>(a, st);
+      else if (variant() == 1) rc = launch_attn<40, 1, false, 4, 2>(a, st);
+      else rc = launch_attn<40, 2, false, 3, 2>(a, st);
       break;
     case 80:
-      if (a->general_dual) rc = launch_attn<80, 2, true, 2>(a, st);
-      else if (variant() == 1) rc = launch_attn<80, 1, false, 3>(a, st);
-      else rc = launch_attn<80, 2, false, 2>(a, st);
+      if (a->general_dual) rc = launch_attn<80, 2, true, 2, 1>(a, st);
+      else if (variant() == 1) rc = launch_attn<80, 1, false, 3, 2>(a, st);
+      else rc = launch_attn<80, 2, false, 2, 2>(a, st);
       break;
-    case 160: rc = a->general_dual ? launch_attn<160, 1, true, 2>(a, st) : launch_attn<160, 1, false, 2>(a, st); break;
+    case 160: rc = a->general_dual ? launch_attn<160, 1, true, 2, 1>(a, st) : launch_attn<160, 1, false, 2, 1>(a, st); break;
     default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
   }
   if (rc != ME_OK) me_set_error("me_attn: kernel launch failed");

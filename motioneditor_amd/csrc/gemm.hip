@@ -78,9 +78,11 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
   return r.base + dt * a.npix;
 }
 
-// lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i]
+// lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
+// sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
+// tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
 template <int NT, int MT, int WN>
-__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn, int lane, f16* sC, int CLD) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
@@ -134,7 +136,8 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
         U64 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o.e[r] = (f16)v[r];
-        *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
+        if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (n - n0)) = o.u;
+        else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
       }
     } else {
       // packed rows: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns
@@ -161,8 +164,9 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
         }
         U64 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o.e[r] = (f16)(va[r] * gelu_erf_f(vg[r]));
-        *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
+        for (int r = 0; r < 4; ++r) o.e[r] = (f16)(va[r] * gelu_erf_fast(vg[r]));
+        if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
+        else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
       }
     }
   }
@@ -328,7 +332,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
     }
   }
 
-  epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane);
+  // ---- epilogue ----
+  const int ncols = a.geglu ? BN / 2 : BN;            // output columns of this block
+  const int Nout = a.geglu ? a.N / 2 : a.N;
+  const bool wide_store = (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);
+  if (!wide_store) {
+    epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane, nullptr, 0);
+    return;
+  }
+  // the K loop ended on a barrier: the staging buffers are free and become the C tile
+  constexpr int CLD = BN + 8;
+  f16* sC = reinterpret_cast<f16*>(smem);
+  epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane, sC, CLD);
+  __syncthreads();
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const int vpr = ncols / 8;                           // 16-byte vectors per row
+  const int nb0 = a.geglu ? n0 / 2 : n0;
+  for (int idx = tid; idx < BM * vpr; idx += 256) {
+    const int row = idx / vpr, c8 = (idx - row * vpr) * 8;
+    const int m = m0 + row, n = nb0 + c8;
+    if (m < a.M && n < Nout) *reinterpret_cast<uint4*>(C + (long)m * a.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CLD + c8);
+  }
 }
 
 int stage_impl() {

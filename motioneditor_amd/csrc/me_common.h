@@ -38,6 +38,20 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
+// exact-erf GELU with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below fp16 resolution):
+// ~14 VALU ops instead of libm erff's ~40 -- the GEGLU epilogue runs it on every feed-forward activation.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+  p = __builtin_fmaf(p, t, 1.421413741f);
+  p = __builtin_fmaf(p, t, -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float erf_abs = 1.0f - p * t * e;
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -43,12 +43,12 @@ def _pb():
     return e
 
 
-def _pe(e0, family: str, flops: float, nbytes: float) -> None:
+def _pe(e0, family: str, flops: float, nbytes: float, detail: str = "") -> None:
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, flops, nbytes, e0, e1))
+    PROFILE.append((family, flops, nbytes, e0, e1, detail))
 
 
 def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
@@ -110,7 +110,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.alpha = alpha
     e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
-    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out))
+    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}")
     return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
 
 

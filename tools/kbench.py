@@ -68,7 +68,7 @@ def bench_attn():
         nk = 77 if seg == "cross" else N
         q = rnd(items * N, 3 * C)
         kv = rnd(B * 77, 2 * C) if seg == "cross" else None
-        si, sm = {"pc": lambda: segments.prev_cur(B, f, dev), "ed": lambda: segments.edited_spatial(f, dev),
+        si, sm = {"pc": lambda: segments.prev_cur(B, f, dev), "ed": lambda: segments.edited_spatial(f, dev, True),
                   "self": lambda: segments.self_items(items, dev), "cross": lambda: segments.cross_text(B, f, dev)}[seg]()
         mk = (torch.rand(8, N, device=dev) > 0.5).half() if mask else None
         if seg == "cross":
