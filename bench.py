@@ -9,9 +9,11 @@ editors ACTIVE (steps >= 4, i.e. 46 of the 50 steps of a run), classifier-free g
 Workload = BASELINE.json configs[2]: 24 frames x 512^2 (64x64 latents), synthetic inputs, seeded random
 weights of the SD-1.5 / ControlNet-openpose / adapter architectures (no checkpoints exist offline).
 
-Multi-GPU (round 1): one process per GPU, each rank denoises its own clip (independent units, no data-path
-collective) -> "scaling": "weak"; value = clips*steps / max-over-ranks time.  Frame sharding with the RCCL
-temporal-K/V all-gather is the next row.
+Multi-GPU (round 1): one process per GPU.  Even N (default `--parallel cfg`): GPUs pair up and split ONE clip along
+the classifier-free-guidance axis (rank 2i: unconditional (recon, edit) pair, rank 2i+1: conditional pair); the only
+data-path exchange is one RCCL all-gather of the 4-channel noise prediction per step; N/2 clips run side by side.
+`--parallel replicas`: every rank denoises its own clip, no collective.  value = clips*steps / max-over-ranks time.
+Frame sharding with the RCCL temporal-K/V all-gather is the next row.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family, HIP-event timed on the launch
 stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
@@ -99,6 +101,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--parallel", choices=["cfg", "replicas"], default="cfg", help="N > 1: CFG-parallel GPU pairs (even N) or independent replicas")
     ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
     args = ap.parse_args()
 
@@ -118,7 +121,14 @@ def main():
     usd = synth.synth_state_dict(synth.unet_schema())
     csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
     f, h, w = args.frames, args.latent, args.latent
-    x = build_inputs(f, h, w, seed=33 + rank)   # every rank its own clip
+    cfg_par = dist_on and args.parallel == "cfg" and world % 2 == 0
+    group = None
+    if cfg_par:
+        pairs = [dist.new_group([2 * i, 2 * i + 1]) for i in range(world // 2)]   # every rank creates every group
+        group = pairs[rank // 2]
+    clip = rank // 2 if cfg_par else rank
+    n_clips = world // 2 if cfg_par else world
+    x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas) or per GPU pair (CFG-parallel)
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"])
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
@@ -128,6 +138,8 @@ def main():
 
     def run_step(i, lat):
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
+        if cfg_par:
+            return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=group)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
     sed.cur_step = ted.cur_step = 4          # editors active: the steady-state step (46 of 50)
@@ -157,16 +169,18 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * args.steps / dt
+        value = n_clips * args.steps / dt
         out = {"metric": "denoise-steps/sec, 24f x 512^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)", "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if (cfg_par and world == 2) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors active), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
                           "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5,
-                          "parallelism": "single GPU" if world == 1 else f"dp{world}: one independent clip per GPU, no data-path collective"},
+                          "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
+                                                                          f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
+                                                                          if cfg_par else f"dp{world}: one independent clip per GPU, no data-path collective")},
                "step_tflop_reference_semantics": round(step_tflop(f, h, w), 2),
-               "achieved_tflops_whole_step": round(step_tflop(f, h, w) * args.steps / dt * (1 if world == 1 else 1), 1)}
+               "achieved_tflops_whole_job": round(step_tflop(f, h, w) * n_clips * args.steps / dt, 1)}
         if prof:
             fam = {}
             shapes = {}

@@ -71,8 +71,9 @@ class FullySelfAttentionControlMask(MutualSelfAttentionControl):
                 attention_mask=None, call=None, text_seg=None, **kwargs):
         if is_cross or self.cur_step not in self.step_idx or self.cur_att_layer // 2 not in self.layer_idx:  # reference :434
             return super().forward(is_cross=is_cross, place_in_unet=place_in_unet, num_heads=num_heads, call=call, text_seg=text_seg)
-        if call.B != 4:
-            raise ValueError("edited attention expects batch 4 = [uncond.rec, uncond.edit, cond.rec, cond.edit] (reference :439-441)")
+        if call.B not in (2, 4):
+            raise ValueError("edited attention expects batch 4 = [uncond.rec, uncond.edit, cond.rec, cond.edit] (reference :439-441) "
+                             "or one (rec, edit) pair on a CFG-parallel rank")
         if (num_heads * call.f) % 8:
             raise ValueError("heads * frames must be divisible by 8 (reference :377)")
-        return call.run(*segments.edited_spatial(call.f, call.q.device, self.binary_masks), mask=self.mask_planes(call.N, call.q.device))
+        return call.run(*segments.edited_spatial(call.f, call.q.device, self.binary_masks, call.B), mask=self.mask_planes(call.N, call.q.device))

@@ -22,6 +22,6 @@ class TemporalSelfAttentionControl(TemporalAttentionBase):
                 attention_mask=None, call=None, **kwargs):
         if is_cross or self.cur_step not in self.step_idx or self.cur_att_layer not in self.layer_idx:  # reference :74
             return super().forward(is_cross=is_cross, place_in_unet=place_in_unet, num_heads=num_heads, call=call)
-        if call.B != 4:
-            raise ValueError("edited temporal attention expects batch 4 (reference :77-85)")
-        return call.run(kv_map=[0, 0, 2, 2])
+        if call.B not in (2, 4):
+            raise ValueError("edited temporal attention expects batch 4 (reference :77-85) or one (rec, edit) pair")
+        return call.run(kv_map=[0, 0, 2, 2][:call.B])

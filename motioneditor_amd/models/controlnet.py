@@ -24,11 +24,11 @@ class ControlNetModel:
     def from_synthetic(cls, device="cuda", seed: int = 33):
         return cls(synth.synth_state_dict(synth.controlnet_schema(), seed, salt="controlnet."), device)
 
-    def forward_rows(self, latents, lat_index, timestep, prompt, cond, conditioning_scale: float = 1.0):
+    def forward_rows(self, latents, lat_index, timestep, prompt, cond, conditioning_scale: float = 1.0, row_offset: int = 0):
         """Fast path used by the pipeline: latents fp32 [nb,4,f,h,w], ControlNet batch entry i reads
         latents[lat_index[i]]; prompt [n_text,77,768] interleaved over rows (row r -> text r % n_text)."""
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
-        return graph.controlnet_forward(self.P, latents.to(self.device), list(lat_index), t, prompt.to(self.device), cond.to(self.device), conditioning_scale)
+        return graph.controlnet_forward(self.P, latents.to(self.device), list(lat_index), t, prompt.to(self.device), cond.to(self.device), conditioning_scale, row_offset)
 
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale: float = 1.0, return_dict: bool = False):
         """diffusers signature: sample [(b f),4,h,w], encoder_hidden_states [(b f),77,768], controlnet_cond [(b f),3,8h,8w]

@@ -255,6 +255,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     B, _, f, h, w = sample.shape
     dev = sample.device
     sample = sample.contiguous().float()
+    edit_rows = [b for b in range(B) if b % 2 == 1]   # batch = (recon, edit) pairs: 4 rows, or 2 on one CFG-parallel rank
     temb, toff = time_embedding(P, t, resnet_names(True), dev)
     text = text_rows(ehs, P.dtype)
     tseg = segments.cross_text(B, f, dev)
@@ -279,12 +280,12 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     if down_res is not None:
         motion = []
         for i, (s, r) in enumerate(zip(skips, down_res)):
-            if two_branch:   # adapter sees the two edit rows only (unet_2d_condition.py:479-481)
+            if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
                 n = s.f * s.N
-                src = torch.empty((2 * n, s.C), dtype=P.dtype, device=dev)
-                ops.copy_rows(src[:n], s.rows_of(1))
-                ops.copy_rows(src[n:], s.rows_of(3))
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 2, s.f, s.h, s.w), src))
+                src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
+                for k, eb in enumerate(edit_rows):
+                    ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, len(edit_rows), s.f, s.h, s.w), src))
             else:            # (unet_2d_condition.py:483-485)
                 motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t))
         if taps is not None:
@@ -296,8 +297,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 tgt = s.like(s.t.clone())
             if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
                 n = s.f * s.N
-                ops.axpy_rows(tgt.rows_of(1), tgt.rows_of(1), m[:n])
-                ops.axpy_rows(tgt.rows_of(3), tgt.rows_of(3), m[n:])
+                for k, eb in enumerate(edit_rows):
+                    ops.axpy_rows(tgt.rows_of(eb), tgt.rows_of(eb), m[k * n:(k + 1) * n])
             else:
                 ops.axpy_rows(tgt.t, tgt.t, m)
             new_skips.append(tgt)
@@ -311,8 +312,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     if mid_res is not None:
         if two_branch:
             nr = x.f * x.N
-            ops.axpy_rows(x.rows_of(1), x.rows_of(1), mid_res[:nr])
-            ops.axpy_rows(x.rows_of(3), x.rows_of(3), mid_res[nr:])
+            for k, eb in enumerate(edit_rows):
+                ops.axpy_rows(x.rows_of(eb), x.rows_of(eb), mid_res[k * nr:(k + 1) * nr])
         else:
             ops.axpy_rows(x.t, x.t, mid_res)
     if taps is not None:
@@ -338,7 +339,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
 # ControlNet (diffusers 0.15.1 ControlNetModel.forward, called pipeline_motion_editor.py:618-625)
 # ---------------------------------------------------------------------------------------------
 def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int], t: float, prompt: torch.Tensor, cond: torch.Tensor,
-                       scale: float = 1.0):
+                       scale: float = 1.0, row_offset: int = 0):
     """latents fp32 [nb,4,f,h,w]; lat_index: which latent row each ControlNet batch entry reads (the
     pipeline feeds rows [1,3] of cat([latents]*2), i.e. the edit latent twice); prompt [n_text,77,768]
     with the reference's interleave (row r -> text r % n_text); cond fp32/fp16 [(nbc f),3,8h,8w].
@@ -350,7 +351,7 @@ def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int
     latents = latents.contiguous().float()
     temb, toff = time_embedding(P, t, resnet_names(False), dev)
     text = text_rows(prompt, P.dtype)
-    tseg = segments.cross_interleaved(nimg, prompt.shape[0], dev)
+    tseg = segments.cross_interleaved(nimg, prompt.shape[0], dev, row_offset)   # row_offset: this rank's first "(b f)" row in the full ControlNet batch
 
     # conditioning embedding: 3->16 (direct), then 16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2 (SiLU each), 256->320
     H8, W8 = cond.shape[-2], cond.shape[-1]

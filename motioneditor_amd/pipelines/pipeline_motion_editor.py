@@ -92,6 +92,33 @@ class MotionEditorPipeline:
         return ((video / 2 + 0.5).clamp(0, 1)).cpu().float().numpy()
 
     @torch.no_grad()
+    def denoise_step_cfg_parallel(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
+                                  guidance_scale: float, group=None, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
+        """The same step split over a 2-rank process group along the classifier-free-guidance axis: rank 0 runs the
+        unconditional (recon, edit) pair, rank 1 the conditional pair.  Nothing couples the two halves inside ControlNet /
+        UNet / adapter / editors (GroupNorm statistics, K/V injection and the adapter all stay inside a pair), so the only
+        exchange is ONE all-gather of the 4-channel noise prediction (RCCL over xGMI on MI355X; 2 x [2,4,f,h,w] fp16) before
+        the fused CFG + DDIM update, which every rank then applies to its own copy of the latents."""
+        import torch.distributed as dist
+        r = dist.get_rank(group)
+        assert dist.get_world_size(group) == 2, "CFG parallelism is a 2-way split"
+        f = latents.shape[2]
+        x2 = latents                                                       # both CFG halves see the same [recon, edit] latents (:605)
+        emb = text_embeddings_input[2 * r:2 * r + 2]
+        down = mid = None
+        two = False
+        if self.controlnet is not None and images is not None:
+            prompt = text_embeddings_input[[1, 3]]                         # the interleave r % 2 needs BOTH prompts on every rank (:615,621)
+            nimg = images.shape[0] // 2
+            down, mid = self.controlnet.forward_rows(x2, [1], t, prompt, images[r * nimg:(r + 1) * nimg], controlnet_conditioning_scale, row_offset=r * f)
+            two = True
+        eps = self.unet.forward_rows(x2, t, emb, down, mid, two).t       # [(2 f N), 4]
+        both = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
+        dist.all_gather(list(both.unbind(0)), eps.contiguous(), group=group)   # rows: [uncond (rec, edit) | cond (rec, edit)]
+        ca, cb = self.scheduler.coeffs(int(t))
+        return ops.cfg_ddim(latents, both.reshape(-1, eps.shape[1]), guidance=guidance_scale, ca=ca, cb=cb)
+
+    @torch.no_grad()
     def denoise_step(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
                      guidance_scale: float, controlnet_conditioning_scale: float = 1.0, taps: Optional[dict] = None) -> torch.Tensor:
         """One iteration of the reference loop body (:603-648).  latents fp32 [2,4,f,h,w] = [recon, edit];

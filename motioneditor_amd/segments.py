@@ -36,10 +36,10 @@ def cross_text(B: int, f: int, device):
     return _mk(("cross", B, f), [[i // f] for i in range(B * f)], [[SEG_PLAIN]] * (B * f), device)
 
 
-def cross_interleaved(n_items: int, n_text: int, device):
+def cross_interleaved(n_items: int, n_text: int, device, row_offset: int = 0):
     """ControlNet prompt quirk: embeds.repeat(f,1,1) on "(b f)" rows -> row r reads text r % 2
-    (pipeline_motion_editor.py:615,621)."""
-    return _mk(("crossil", n_items, n_text), [[i % n_text] for i in range(n_items)], [[SEG_PLAIN]] * n_items, device)
+    (pipeline_motion_editor.py:615,621).  row_offset = index of this tensor's first row in the full batch."""
+    return _mk(("crossil", n_items, n_text, row_offset), [[(i + row_offset) % n_text] for i in range(n_items)], [[SEG_PLAIN]] * n_items, device)
 
 
 def prev_cur(B: int, f: int, device):
@@ -59,15 +59,16 @@ def first_prev_chunked(B: int, f: int, chunk: int, device):
     return _mk(("firstprev", B, f, chunk), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
 
 
-def edited_spatial(f: int, device, binary_mask: bool = False):
-    """FullySelfAttentionControlMask on batch 4 = [u.rec, u.edit, c.rec, c.edit] (fully_control.py:425-447):
+def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4):
+    """FullySelfAttentionControlMask on batch 4 = [u.rec, u.edit, c.rec, c.edit] (fully_control.py:425-447;
+    B = 2 is one (rec, edit) pair, i.e. one classifier-free-guidance half on a CFG-parallel rank):
     recon rows keep [prev | cur]; edit rows attend [src prev (fg/bg dual, mask frame max(head-1,0)) |
     src cur (dual, mask frame head) | own cur]; the edit branch's prev-frame K/V are dropped
     (k[:, 3N:], fully_control.py:383).  With a binary mask (the reference's man.mask PNGs are 0/255) the
     fg/bg pair of every source key weighs exp(s) + exp(0) whichever way the bit points, so the kernel's
     DUAL_BIN mode needs no mask read."""
     rows, modes = [], []
-    for b in range(4):
+    for b in range(B):
         for i in range(f):
             if b % 2 == 0:
                 rows.append([b * f + max(i - 1, 0), b * f + i, -1])
@@ -76,4 +77,4 @@ def edited_spatial(f: int, device, binary_mask: bool = False):
                 s = (b - 1) * f
                 rows.append([s + max(i - 1, 0), s + i, b * f + i])
                 modes.append([SEG_DUAL_BIN, SEG_DUAL_BIN, SEG_PLAIN] if binary_mask else [SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
-    return _mk(("edited", f, binary_mask), rows, modes, device)
+    return _mk(("edited", f, binary_mask, B), rows, modes, device)
