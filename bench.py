@@ -109,12 +109,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     from motioneditor_amd import capi, ops, synth
     capi.lib()  # no HIP library -> hard failure (no fallback path exists)
@@ -175,7 +175,7 @@ def main():
                "higher_is_better": True, "scaling": "strong" if (cfg_par and world == 2) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors active), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
-                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5,
+                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
                           "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
                                                                           f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
                                                                           if cfg_par else f"dp{world}: one independent clip per GPU, no data-path collective")},

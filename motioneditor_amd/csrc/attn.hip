@@ -21,6 +21,7 @@
 #include "me_common.h"
 #include "../../include/motioned.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -151,13 +152,16 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     if (T > 1) gload(1);
   }
   __syncthreads();
-  for (int ti = 0; ti < T; ++ti) {
+  // One KV tile, specialised at compile time on the segment mode and on "tile fully inside nk": the mode / tail
+  // tests are wave-uniform, and leaving them as run-time selects made hipcc if-convert BOTH softmax variants and
+  // 32 tail compares into every tile (11 VALU per MFMA).  A scalar (readfirstlane) dispatch picks the body.
+  auto tile = [&](auto mode_c, auto full_c, int ti) {
+    constexpr int MODE = decltype(mode_c)::value;
+    constexpr bool FULL = decltype(full_c)::value;
     const f16* sK = sKb[ti & (NBUF - 1)];
     const f16* sVt = sVtb[ti & (NBUF - 1)];
     const f16* sM = sMb[ti & (NBUF - 1)];
-
     const int seg = ti / ntk, kt = ti - seg * ntk;
-    const int mode = a.seg_mode[item * a.nseg + seg];
     const int kbase = kt * KT + g * 4;  // + t*16 + r
 
     // ---- S^T = K Q^T ----
@@ -177,12 +181,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     }
 
     // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
-    // exp2 with log2(e)*scale folded into one FMA per element; key-tail masking only on a partial tile
-    const bool full = (kt + 1) * KT <= a.nk;
     f16x8 pf[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      if (!full) {
+      if constexpr (!FULL) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
       }
       float p[4][4];
       float psum = 0.f, alpha;
-      if (mode == ME_SEG_PLAIN) {
+      if constexpr (MODE == ME_SEG_PLAIN || MODE == ME_SEG_DUAL_BIN) {
         float mr = NEG_BIG;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -199,39 +201,23 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
           for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
         mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
         mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
-        const float mnew = fmaxf(mrun[qt], mr * c);
+        // DUAL_BIN (binary mask): one of the (fg, bg) copies keeps the key, the other is a zero vector with logit 0,
+        // both with the same V -> weight exp(s) + exp(0) whatever the mask bit says; the running max includes 0
+        const float mnew = MODE == ME_SEG_PLAIN ? fmaxf(mrun[qt], mr * c) : fmaxf(mrun[qt], fmaxf(mr * c, 0.f));
         alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
         mrun[qt] = mnew;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][r], c, -mnew));
-            psum += p[t][r];
-          }
-      } else if (mode == ME_SEG_DUAL_BIN) {
-        // binary mask: exactly one of the (fg, bg) copies keeps the key and the other is a zero vector with
-        // logit 0, both with the same V -> weight exp(s) + exp(0) whatever the mask bit says
-        float mr = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
-        mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
-        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
-        const float mnew = fmaxf(mrun[qt], fmaxf(mr * c, 0.f));
-        alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-        mrun[qt] = mnew;
-        const float e0 = __builtin_amdgcn_exp2f(-mnew);
+        const float e0 = MODE == ME_SEG_DUAL_BIN ? __builtin_amdgcn_exp2f(-mnew) : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             p[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][r], c, -mnew)) + e0;
-            if (!full && kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
+            if constexpr (!FULL && MODE == ME_SEG_DUAL_BIN) {
+              if (kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
+            }
             psum += p[t][r];
           }
-      } else if constexpr (GD) {
+      } else {
         // general (non-binary) masks: both copies' logits are needed.  Compiled only into the GD instantiation
         float x1[4][4], x2[4][4];
         float mx = NEG_BIG;
@@ -290,6 +276,24 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.h, pf[qt][kk], o[qt][dt]);
       }
+    }
+  };
+  using IC0 = std::integral_constant<int, ME_SEG_PLAIN>;
+  using IC3 = std::integral_constant<int, ME_SEG_DUAL_BIN>;
+  using ICG = std::integral_constant<int, ME_SEG_DUAL_CUR>;
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+
+  for (int ti = 0; ti < T; ++ti) {
+    const int seg = ti / ntk, kt = ti - seg * ntk;
+    const int mode = __builtin_amdgcn_readfirstlane(a.seg_mode[item * a.nseg + seg]);
+    const bool full = (kt + 1) * KT <= a.nk;
+    if (mode == ME_SEG_PLAIN) {
+      if (full) tile(IC0{}, BT{}, ti); else tile(IC0{}, BF{}, ti);
+    } else if (mode == ME_SEG_DUAL_BIN) {
+      if (full) tile(IC3{}, BT{}, ti); else tile(IC3{}, BF{}, ti);
+    } else {
+      if constexpr (GD) tile(ICG{}, BF{}, ti);
     }
     // stage tile ti+1 into the other buffer (every wave finished reading it one barrier ago), prefetch ti+2
     if (ti + 1 < T) {

@@ -208,12 +208,17 @@ def time_embedding(P: Packed, t: float, names: List[str], device):
 # ---------------------------------------------------------------------------------------------
 # ControlAdapter (controlnet_adapter.py:437-565)
 # ---------------------------------------------------------------------------------------------
-def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor) -> torch.Tensor:
+def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int] = None) -> torch.Tensor:
     """ResnetBlock.forward (controlnet_adapter.py:497-534).  x: ControlNet residual rows [(b t N), C];
-    src: UNet edit-branch skip rows, same shape.  Returns motion residual rows."""
+    src: UNet edit-branch skip rows [(nb t N), C].  Returns motion residual rows [(nb t N), C].
+
+    nb > x.B (x.B == 1): the ControlNet residual is SHARED by the nb batch entries (the reference feeds the
+    ControlNet the same edit latent twice, see pipelines.MotionEditorPipeline.dedup_controlnet).  Everything up to
+    the pose cross-attention depends on x only -- temporal convs, sparse-causal self-attention, cross_pose_norm,
+    the pose query projection -- so it is computed once and broadcast."""
     t, C, dev = x.t, x.C, x.t.device
     dh = C // HEADS
-    nit = x.B * x.f
+    nb = x.B if nb is None else nb
     # conv path: TemporalConv(k=3) -> ReLU -> TemporalConv(k=1) -> + x, on independent chunks of 8 frames
     hc = ops.gemm(t, P.mat(p + ".block1.weight"), bias=P.vec(p + ".block1.bias"), tconv=(x.f, x.N, ADAPTER_CHUNK), act=1)
     hc = ops.gemm(hc, P.mat(p + ".block2.weight"), bias=P.vec(p + ".block2.bias"), res=t)
@@ -224,13 +229,17 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor) -> torch.Tensor:
     a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
     # pose x UNet-feature cross attention, per frame
     q = ops.gemm(a, P.mat(p + ".attn_pose.to_q.weight"))
+    if nb != x.B:   # broadcast the x-only part to every batch entry
+        assert x.B == 1
+        rep = lambda z: torch.cat([z] * nb)  # noqa: E731
+        hc, a, q = rep(hc), rep(a), rep(q)
     kv = ops.gemm(src, P.fused([p + ".attn_pose.to_k.weight", p + ".attn_pose.to_v.weight"]))
-    ap = AttnCall(q, kv[:, :C], kv[:, C:], x.B, x.f, x.N, dh, x.N, True).run(*segments.self_items(nit, dev))
+    ap = AttnCall(q, kv[:, :C], kv[:, C:], nb, x.f, x.N, dh, x.N, True).run(*segments.self_items(nb * x.f, dev))
     a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a)
     a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
     # causal temporal attention over the TRUE frame count
     qkv = ops.gemm(_ln(P, p + ".norm_self_temp", a), P.fused([p + ".attn_self_temp.to_q.weight", p + ".attn_self_temp.to_k.weight", p + ".attn_self_temp.to_v.weight"]))
-    at = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh).run()
+    at = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, x.f, x.N, dh).run()
     return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc)
 
 
@@ -285,7 +294,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
                 for k, eb in enumerate(edit_rows):
                     ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, len(edit_rows), s.f, s.h, s.w), src))
+                shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows)))
             else:            # (unet_2d_condition.py:483-485)
                 motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t))
         if taps is not None:
@@ -313,7 +323,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
         if two_branch:
             nr = x.f * x.N
             for k, eb in enumerate(edit_rows):
-                ops.axpy_rows(x.rows_of(eb), x.rows_of(eb), mid_res[k * nr:(k + 1) * nr])
+                mk = mid_res[:nr] if mid_res.shape[0] == nr else mid_res[k * nr:(k + 1) * nr]   # shared or per-entry residual
+                ops.axpy_rows(x.rows_of(eb), x.rows_of(eb), mk)
         else:
             ops.axpy_rows(x.t, x.t, mid_res)
     if taps is not None:

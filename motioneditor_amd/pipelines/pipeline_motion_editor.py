@@ -35,6 +35,11 @@ class MotionEditorPipeline:
             self.scheduler.config["clip_sample"] = False
         self.vae_scale_factor = 8
         self.device = unet.device
+        # The reference feeds ControlNet rows [1, 3] of cat([latents]*2) -- the SAME edit latent twice -- with prompts
+        # tiled as row r -> text r % 2 (pipeline :613-621).  For an even frame count both batch entries therefore see
+        # identical latents, images and prompt pattern and produce identical residuals: compute one, use it twice.
+        # Set False to execute the redundant second entry exactly as the reference does.
+        self.dedup_controlnet = True
 
     @property
     def _execution_device(self):
@@ -129,7 +134,12 @@ class MotionEditorPipeline:
         two = False
         if self.controlnet is not None and images is not None:
             prompt = text_embeddings_input[[1, 3]]                         # :615; .repeat(f,1,1) on "(b f)" rows -> row r reads r % 2 (:621)
-            down, mid = self.controlnet.forward_rows(x4, [1, 3], t, prompt, images, controlnet_conditioning_scale)   # :613-625
+            f = latents.shape[2]
+            if self.dedup_controlnet and f % 2 == 0:
+                # one entry; the UNet graph broadcasts it to both edit rows (and shares the adapter's x-only half)
+                down, mid = self.controlnet.forward_rows(x4, [1], t, prompt, images[:images.shape[0] // 2], controlnet_conditioning_scale)
+            else:
+                down, mid = self.controlnet.forward_rows(x4, [1, 3], t, prompt, images, controlnet_conditioning_scale)   # :613-625
             two = True                                                     # mid residual scattered as [0, m0, 0, m1] (:628-629)
             if taps is not None:
                 taps["cn_down"], taps["cn_mid"] = [d.clone() for d in down], mid.clone()

@@ -122,6 +122,10 @@ def test_denoise_step_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch
     # ControlNet residuals (rows -> reference layout)
     for i, (d, od) in enumerate(zip(taps["cn_down"], otaps["cn_down"])):
         od_rows = od.permute(0, 2, 3, 4, 1).reshape(-1, od.shape[1])
+        if d.shape[0] * 2 == od_rows.shape[0]:   # pipeline.dedup_controlnet: the two reference entries are identical (even f)
+            half = od_rows.shape[0] // 2
+            assert rel_l2(od_rows[half:], od_rows[:half]) < 1e-6
+            od_rows = od_rows[:half]
         ei = rel_l2(d, od_rows)
         record(f"step{step}_cn_down{i}", ei)
         assert ei <= 2e-2, (i, ei)
