@@ -37,6 +37,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int KLD = D32 * 32 + 8;
   constexpr int BQ = 64 * QT;
   constexpr int NLD = (KT * CH + 255) / 256;
+  // V^T has padding rows when dh is not a multiple of 16 (40 -> 48, 80 -> 96): make the first one all ones, so the
+  // PV MFMA accumulates the softmax denominator in accumulator row DH for free (no VALU row sums, and the sum is
+  // taken over exactly the fp16-rounded P that multiplies V)
+  constexpr bool ONES = DT * 16 > DH;
 
   // two LDS stages: tile t+1 is stored while tile t is consumed -> one barrier per tile
   __shared__ __attribute__((aligned(16))) f16 sKb[NBUF][KT * KLD];
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 
   // zero the LDS padding that staging never writes (K columns >= DH, V^T rows >= DH)
   for (int i = tid; i < NBUF * KT * KLD; i += 256) (&sKb[0][0])[i] = (f16)0.f;
-  for (int i = tid; i < NBUF * DT * 16 * VLD; i += 256) (&sVtb[0][0])[i] = (f16)0.f;
+  for (int i = tid; i < NBUF * DT * 16 * VLD; i += 256) (&sVtb[0][0])[i] = (ONES && (i % (DT * 16 * VLD)) / VLD == DH) ? (f16)1.f : (f16)0.f;
 
   // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
   f16x8 fq[QT][D32];
@@ -199,8 +203,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
-        mr = fmaxf(mr, __shfl_xor(mr, 16, 64));
-        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        mr = xor32_max(xor16_max(mr));
         // DUAL_BIN (binary mask): one of the (fg, bg) copies keeps the key, the other is a zero vector with logit 0,
         // both with the same V -> weight exp(s) + exp(0) whatever the mask bit says; the running max includes 0
         const float mnew = MODE == ME_SEG_PLAIN ? fmaxf(mrun[qt], mr * c) : fmaxf(mrun[qt], fmaxf(mr * c, 0.f));
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
             if constexpr (!FULL && MODE == ME_SEG_DUAL_BIN) {
               if (kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
             }
-            psum += p[t][r];
+            if constexpr (!ONES) psum += p[t][r];
           }
       } else {
         // general (non-binary) masks: both copies' logits are needed.  Compiled only into the GD instantiation
@@ -235,8 +238,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
             mx = fmaxf(mx, fmaxf(x1[t][r], x2[t][r]));
           }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor32_max(xor16_max(mx));
         const float mnew = fmaxf(mrun[qt], mx);
         alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
         mrun[qt] = mnew;
@@ -245,12 +247,15 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             p[t][r] = __builtin_amdgcn_exp2f(x1[t][r] - mnew) + __builtin_amdgcn_exp2f(x2[t][r] - mnew);
-            psum += p[t][r];
+            if constexpr (!ONES) psum += p[t][r];
           }
       }
-      lrun[qt] = lrun[qt] * alpha + psum;
+      if constexpr (!ONES) lrun[qt] = lrun[qt] * alpha + psum;
+      // rescale only when some query of the wave saw its running max move (exact: alpha == 1 otherwise)
+      if (__builtin_amdgcn_readfirstlane(__any(alpha != 1.0f))) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f16x8 f;
@@ -307,9 +312,12 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] / l ----
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    float l = lrun[qt];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if constexpr (ONES) {   // denominator sits in accumulator row DH: tile DH/16, lanes g == (DH%16)/4, reg (DH%16)%4
+      l = __shfl(o[qt][DH / 16][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
+    } else {
+      l = xor32_sum(xor16_sum(lrun[qt]));
+    }
     const float inv = 1.0f / l;
     if (qrow[qt] < 0) continue;
 #pragma unroll

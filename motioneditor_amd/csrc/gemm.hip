@@ -24,7 +24,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int STAGE_REG = 0, STAGE_GLDS = 1;
 
@@ -172,12 +171,16 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
   }
 }
 
-template <int BN, int STAGE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
+// BM = 128 (4 waves, 2 blocks/CU) or 256 (8 waves, 1 block/CU).  The 256 x 320 tile halves the L2 -> LDS fill per
+// FLOP (142 vs 71 flop/byte of staged operands): the 128-row tiles measured fill-bound at ~8 TB/s for K <= 640.
+template <int BM, int BN, int STAGE>
+__global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
+  constexpr int NTHR = BM * 2;    // 64 rows x 2 wave columns per 64 threads
+  constexpr int RSTR = NTHR / 8;  // row stride between a thread's staged rows
   constexpr int WN = BN / 2;      // per-wave N extent
   constexpr int NT = WN / 16;     // 16-wide n tiles per wave
   constexpr int MT = 4;           // 16-wide m tiles per wave (64 rows)
-  constexpr int WROWS = BN / 32;  // W rows staged per thread
+  constexpr int WROWS = BN / RSTR;  // W rows staged per thread
   constexpr int LD = STAGE == STAGE_GLDS ? BK : BK + 8;  // LDS row stride in halves
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
 
   RowInfo rinfo[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + 32 * i);
+  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + RSTR * i);
 
   long xoff[4];  // element offset of the source row for the current tap, or -1
   int cur_tap = -1;
@@ -280,13 +283,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f16* src = (kok && xoff[i] >= 0) ? X + xoff[i] + c : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dx + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dx + i * (RSTR * 128)), 16, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < WROWS; ++i) {
-        const int n = n0 + srow + 32 * i;
+        const int n = n0 + srow + RSTR * i;
         const f16* src = (kok && n < a.N) ? W + ((long)n * taps + tap) * a.K + c : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dw + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dw + i * (RSTR * 128)), 16, 0, 0);
       }
     };
     gload(0, 0);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
       for (int i = 0; i < 4; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
 #pragma unroll
       for (int i = 0; i < WROWS; ++i) {
-        const int n = n0 + srow + 32 * i;
+        const int n = n0 + srow + RSTR * i;
         rw[i] = (kok && n < a.N) ? ldg128(W + ((long)n * taps + tap) * a.K + c) : zero128();
       }
     };
@@ -316,9 +319,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
       f16* dx = sX + buf * BM * LD;
       f16* dw = sW + buf * BN * LD;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + 32 * i) * LD + scol) = rx[i];
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + RSTR * i) * LD + scol) = rx[i];
 #pragma unroll
-      for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + 32 * i) * LD + scol) = rw[i];
+      for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + RSTR * i) * LD + scol) = rw[i];
     };
     gload(0);
     sstore(0);
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
   // ---- epilogue ----
   const int ncols = a.geglu ? BN / 2 : BN;            // output columns of this block
   const int Nout = a.geglu ? a.N / 2 : a.N;
-  const bool wide_store = (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);
+  constexpr bool CFITS = (size_t)BM * (BN + 8) <= (size_t)2 * (BM + BN) * LD;   // the C tile fits the staging buffers
+  const bool wide_store = CFITS && (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);
   if (!wide_store) {
     epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane, nullptr, 0);
     return;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const me_gemm_args a) {
   f16* C = reinterpret_cast<f16*>(a.C);
   const int vpr = ncols / 8;                           // 16-byte vectors per row
   const int nb0 = a.geglu ? n0 / 2 : n0;
-  for (int idx = tid; idx < BM * vpr; idx += 256) {
+  for (int idx = tid; idx < BM * vpr; idx += NTHR) {
     const int row = idx / vpr, c8 = (idx - row * vpr) * 8;
     const int m = m0 + row, n = nb0 + c8;
     if (m < a.M && n < Nout) *reinterpret_cast<uint4*>(C + (long)m * a.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CLD + c8);
@@ -364,6 +368,15 @@ int stage_impl() {
   return impl;
 }
 
+long big_min_blocks() {   // ME_GEMM_BIG_MIN: smallest grid (in 256x320 blocks) that gets the big tile; 0 disables nothing, huge disables it
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("ME_GEMM_BIG_MIN");
+    v = e ? atol(e) : 512;
+  }
+  return v;
+}
+
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -377,12 +390,12 @@ bool tile160() {
 
 extern "C" void me_set_error(const char* msg);
 
-template <int BN, int STAGE>
+template <int BM, int BN, int STAGE>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * (STAGE == STAGE_GLDS ? BK : BK + 8) * sizeof(f16);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BN, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return ME_EHIP;
     }
@@ -390,7 +403,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   }
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((gemm_kernel<BN, STAGE>), dim3(nbm * nbn), dim3(256), lds, st, *a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE>), dim3(nbm * nbn), dim3(BM * 2), lds, st, *a);
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");
     return ME_EHIP;
@@ -422,8 +435,11 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   // GEGLU needs whole (value, gate) 32-row pairs per wave -> 128; leftovers (4, 16, 32, 96, 256) -> 128 / 64 with a tail
   const bool wide = a->N % 128 == 0 || a->N % 64 != 0;
   if (stage_impl() == STAGE_GLDS) {
-    if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<160, STAGE_GLDS>(a, st);
-    return wide ? launch_gemm<128, STAGE_GLDS>(a, st) : launch_gemm<64, STAGE_GLDS>(a, st);
+    // big tile when the grid still fills the chip: every model width is a multiple of 320
+    const long big_blocks = (long)((a->M + 255) / 256) * (a->N / 320);
+    if (a->N % 320 == 0 && big_blocks >= big_min_blocks()) return launch_gemm<256, 320, STAGE_GLDS>(a, st);
+    if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<128, 160, STAGE_GLDS>(a, st);
+    return wide ? launch_gemm<128, 128, STAGE_GLDS>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
   }
-  return wide ? launch_gemm<128, STAGE_REG>(a, st) : launch_gemm<64, STAGE_REG>(a, st);
+  return wide ? launch_gemm<128, 128, STAGE_REG>(a, st) : launch_gemm<128, 64, STAGE_REG>(a, st);
 }

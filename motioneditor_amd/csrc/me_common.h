@@ -63,6 +63,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Cross-lane exchange with lane ^ 32 / lane ^ 16 as VALU permlane swaps (gfx950) instead of ds_bpermute
+// (an LDS round trip): v_permlane32_swap(x, x) leaves {x[l], x[l^32]} in the two results for every lane,
+// v_permlane16_swap(x, x) the same for 16-lane rows.
+__device__ __forceinline__ float xor32_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // Bijective XCD-aware remap of a 1-D block id: hardware places block b on XCD b % 8; give each
 // XCD a contiguous run of work items so neighbouring tiles share one L2.
 __device__ __forceinline__ int xcd_remap(int bid, int total) {
