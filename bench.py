@@ -201,8 +201,13 @@ def main():
             tot = sum(v[0] for v in fam.values())
             dom = max(fam, key=lambda k: fam[k][0])
             tsec, fl, by, n = fam[dom]
+            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_summary.py), same workload only
+            pmc = ROOT / "profiles" / "pmc_traffic.json"
+            if pmc.exists() and (f, h, w) == (24, 64, 64):
+                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                               "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None if traffic is None else round(traffic),
+                               "algorithmic_bytes_per_launch": round(by / n),
                                "launches_per_step": n // args.steps, "avg_launch_ms": round(tsec / n * 1e3, 4),
                                "share_of_gpu_time": round(tsec / tot, 3)}
             out["kernel_families"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,

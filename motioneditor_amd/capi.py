@@ -110,6 +110,10 @@ def lib() -> C.CDLL:
             raise MotionedError(
                 f"{LIB_PATH} is missing: the HIP library is the only compute path of motioneditor_amd "
                 "(no CPU / PyTorch fallback). Build it with `python -m motioneditor_amd.build`.")
+        # PyTorch-ROCm bundles its own libamdhip64; libmotioned must bind to THAT runtime instance (it launches on
+        # torch's streams and torch's allocations).  Loading the .so before torch would pull /opt/rocm's copy in first
+        # and every launch would then fail with hipErrorNoDevice -- so make sure torch is loaded first.
+        import torch  # noqa: F401
         L = C.CDLL(str(LIB_PATH))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

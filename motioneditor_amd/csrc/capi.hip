@@ -1,6 +1,7 @@
 // Library-level entry points of libmotioned.so: ABI version, last-error string, device probe.
 #include "me_common.h"
 #include "../../include/motioned.h"
+#include <stdio.h>
 #include <string.h>
 
 namespace {
@@ -10,6 +11,11 @@ thread_local char g_err[512] = "";
 extern "C" void me_set_error(const char* msg) {
   strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
   g_err[sizeof(g_err) - 1] = 0;
+}
+
+// "<what>: <hipGetErrorName>: <hipGetErrorString>"
+extern "C" void me_set_hip_error(const char* what, int err) {
+  snprintf(g_err, sizeof(g_err), "%s: %s: %s", what ? what : "", hipGetErrorName((hipError_t)err), hipGetErrorString((hipError_t)err));
 }
 
 extern "C" int me_abi_version(void) { return ME_ABI_VERSION; }

@@ -166,10 +166,15 @@ inline unsigned grid_for(long n, long cap = 16384) {
 
 extern "C" void me_set_error(const char* msg);
 
+extern "C" void me_set_hip_error(const char* what, int err);
+
 #define ME_CHECK_LAUNCH(name)                                         \
-  if (hipGetLastError() != hipSuccess) {                              \
-    me_set_error(name ": kernel launch failed");                      \
-    return ME_EHIP;                                                   \
+  {                                                                   \
+    const hipError_t e_ = hipGetLastError();                          \
+    if (e_ != hipSuccess) {                                           \
+      me_set_hip_error(name ": kernel launch failed", (int)e_);       \
+      return ME_EHIP;                                                 \
+    }                                                                 \
   }                                                                   \
   return ME_OK;
 
