@@ -21,6 +21,11 @@ class ControlNetModel:
             raise KeyError(f"state dict lacks {len(missing)} ControlNet keys, e.g. {missing[:3]}")
 
     @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", **kwargs):
+        from .. import checkpoint
+        return cls(checkpoint.load_controlnet_state_dict(pretrained_model_name_or_path, subfolder), device)
+
+    @classmethod
     def from_synthetic(cls, device="cuda", seed: int = 33):
         return cls(synth.synth_state_dict(synth.controlnet_schema(), seed, salt="controlnet."), device)
 

@@ -46,6 +46,19 @@ class UNet2DConditionModel:
     def from_synthetic(cls, device="cuda", seed: int = 33):
         return cls(synth.synth_state_dict(synth.unet_schema(), seed), device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, use_sc_attn=True, use_st_attn=False, st_attn_idx=None,
+                        resume_from_checkpoint=None, adapter_weight_path=None, device="cuda", **kwargs):
+        """Reference signature (models/unet_2d_condition.py:548-796) for local directories: 2-D SD-1.5 weights are inflated,
+        modules the reference adds keep their constructor init (see checkpoint.inflate)."""
+        if not use_sc_attn or use_st_attn:
+            raise NotImplementedError("only the shipped configuration use_sc_attn=True, use_st_attn=False is on the hot path (eval-motion.yaml:44-46)")
+        from .. import checkpoint
+        sd, info = checkpoint.load_unet_state_dict(pretrained_model_name_or_path, subfolder, resume_from_checkpoint, adapter_weight_path)
+        m = cls(sd, device)
+        m.loading_info = info
+        return m
+
     def _residual_rows(self, res, two_branch_hint: bool):
         """Accept the reference layout (5-D [b, C, f, h, w]) or ready channels-last rows."""
         if res is None:
