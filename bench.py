@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--parallel", choices=["cfg", "replicas"], default="cfg", help="N > 1: CFG-parallel GPU pairs (even N) or independent replicas")
+    ap.add_argument("--parallel", choices=["cfg", "replicas", "frames"], default="cfg",
+                    help="N > 1: CFG-parallel GPU pairs (even N), independent replicas, or ONE clip with its frames sharded over all N ranks")
     ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
     args = ap.parse_args()
 
@@ -126,18 +127,29 @@ def main():
     if cfg_par:
         pairs = [dist.new_group([2 * i, 2 * i + 1]) for i in range(world // 2)]   # every rank creates every group
         group = pairs[rank // 2]
-    clip = rank // 2 if cfg_par else rank
-    n_clips = world // 2 if cfg_par else world
-    x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas) or per GPU pair (CFG-parallel)
+    frame_par = dist_on and args.parallel == "frames"
+    shard = None
+    if frame_par:
+        from motioneditor_amd import parallel
+        shard = parallel.FrameShard(f)               # f / world frames per rank
+    clip = 0 if frame_par else (rank // 2 if cfg_par else rank)
+    n_clips = 1 if frame_par else (world // 2 if cfg_par else world)
+    x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (CFG-parallel) or for all ranks (frames)
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"])
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
+    if frame_par:   # this rank's frames only
+        lo, hi = shard.frame0, shard.frame0 + shard.f_loc
+        images = images[lo:hi].contiguous()
+        lat = lat[:, :, lo:hi].contiguous()
     cond = x["cond"].to(device)
     unc = [u.to(device) for u in x["uncond"]]
     ts = pipe.scheduler.timesteps
 
     def run_step(i, lat):
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
+        if frame_par:
+            return pipe.denoise_step_frame_sharded(lat, ts[i], emb, images, 7.5, shard)
         if cfg_par:
             return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=group)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
@@ -172,13 +184,15 @@ def main():
         value = n_clips * args.steps / dt
         out = {"metric": "denoise-steps/sec, 24f x 512^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)", "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "strong" if (cfg_par and world == 2) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors active), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
                           "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
                           "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
                                                                           f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
-                                                                          if cfg_par else f"dp{world}: one independent clip per GPU, no data-path collective")},
+                                                                          if cfg_par else (f"frames{world}: one clip, {f // world} frames per GPU; RCCL all-gather of K|V (attn1, adapter, temporal attention), "
+                                                                                           f"TemporalConv halos, GroupNorm-statistic all-reduce" if frame_par
+                                                                                           else f"dp{world}: one independent clip per GPU, no data-path collective"))},
                "step_tflop_reference_semantics": round(step_tflop(f, h, w), 2),
                "achieved_tflops_whole_job": round(step_tflop(f, h, w) * n_clips * args.steps / dt, 1)}
         if prof:

@@ -61,8 +61,12 @@ typedef struct me_gemm_args {
   int32_t gather;     /* ME_GATHER_*                                           */
   /* CONV3: M = n_img * Hout * Wout */
   int32_t Hin, Win, Hout, Wout, stride, ups;
-  /* TCONV: row m = ((b * frames + fr) * npix + p) */
+  /* TCONV: row m = ((b * frames + fr) * npix + p).  Frame-sharded operation: this rank holds
+   * `frames` consecutive frames starting at global frame `frame0` of `frames_total`; taps that leave the local
+   * range read the one-frame halos the host appended to X at rows halo_prev / halo_next (+ b*npix + p).
+   * frames_total == 0 means unsharded (frame0 = 0, frames_total = frames, no halos). */
   int32_t frames, npix, chunk;
+  int32_t frame0, frames_total, halo_prev, halo_next;
   /* epilogue (all optional, applied in this order) */
   const void* bias;   /* fp16 [N]                                              */
   const void* rowvec; /* fp16: += rowvec[(m / rows_per_vec) * ldrv + n]        */
@@ -143,9 +147,13 @@ typedef struct me_tattn_args {
   void* O;
   int32_t ldq, ldk, ldv, ldo;
   int32_t heads, dh;
-  int32_t batch, frames, npix; /* frames in {8,16,24,32,40,48} */
+  int32_t batch, frames, npix; /* frames (of K/V) in {8,16,24,32,40,48} */
   int32_t kv_map[8];           /* batch <= 8 */
   float scale;
+  /* frame sharding: Q/O hold q_frames local frames starting at global frame q_frame0 (0, 0 = all frames);
+   * K/V is the all-gather of kv_parts equal frame shards, part-major: row of (b, global frame j, p) =
+   * ((j / fpp) * batch + b) * fpp * npix + (j % fpp) * npix + p with fpp = frames / kv_parts (0 or 1 = one part) */
+  int32_t q_frames, q_frame0, kv_parts;
 } me_tattn_args;
 
 int me_tattn(const me_tattn_args* a, void* stream);
@@ -169,6 +177,11 @@ typedef struct me_groupnorm_args {
 } me_groupnorm_args;
 
 int me_groupnorm(const me_groupnorm_args* a, void* stream);
+/* The two halves of me_groupnorm, for frame-sharded runs: stats zeroes a->stats and accumulates this rank's
+ * (sum, sum of squares); the host all-reduces a->stats over the ranks; apply normalises with the GLOBAL element
+ * count rows_per_group_total * (C / groups). */
+int me_groupnorm_stats(const me_groupnorm_args* a, void* stream);
+int me_groupnorm_apply(const me_groupnorm_args* a, int64_t rows_per_group_total, void* stream);
 
 /* ---- LayerNorm over the channel axis (nn.LayerNorm, eps 1e-5; attention_2d.py:443-463) ------ */
 typedef struct me_layernorm_args {

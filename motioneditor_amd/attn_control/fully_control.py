@@ -76,4 +76,4 @@ class FullySelfAttentionControlMask(MutualSelfAttentionControl):
                              "or one (rec, edit) pair on a CFG-parallel rank")
         if (num_heads * call.f) % 8:
             raise ValueError("heads * frames must be divisible by 8 (reference :377)")
-        return call.run(*segments.edited_spatial(call.f, call.q.device, self.binary_masks, call.B), mask=self.mask_planes(call.N, call.q.device))
+        return call.run(*segments.edited_spatial(call.f, call.q.device, self.binary_masks, call.B, getattr(call, "shard", None)), mask=self.mask_planes(call.N, call.q.device))

@@ -41,7 +41,7 @@ class MutualAttentionBase:
             raise ValueError("motioneditor_amd editors are driven by the UNet graph with call=AttnCall(...)")
         if is_cross:
             return call.run(*text_seg)
-        return call.run(*segments.prev_cur(call.B, call.f, call.q.device))
+        return call.run(*segments.prev_cur(call.B, call.f, call.q.device, getattr(call, "shard", None)))
 
     def reset(self):
         self.cur_step = 0

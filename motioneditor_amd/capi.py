@@ -25,6 +25,7 @@ class GemmArgs(C.Structure):
         ("ldx", _i32), ("ldc", _i32), ("gather", _i32),
         ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
         ("frames", _i32), ("npix", _i32), ("chunk", _i32),
+        ("frame0", _i32), ("frames_total", _i32), ("halo_prev", _i32), ("halo_next", _i32),
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
         ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32),
     ]
@@ -56,6 +57,7 @@ class TAttnArgs(C.Structure):
         ("heads", _i32), ("dh", _i32),
         ("batch", _i32), ("frames", _i32), ("npix", _i32),
         ("kv_map", _i32 * 8), ("scale", _f32),
+        ("q_frames", _i32), ("q_frame0", _i32), ("kv_parts", _i32),
     ]
 
 
@@ -84,6 +86,8 @@ SYMBOLS = {
     "me_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "me_tattn": (C.c_int, [C.POINTER(TAttnArgs), _vp]),
     "me_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "me_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "me_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), _i64, _vp]),
     "me_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), _vp]),
     "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),

@@ -54,8 +54,9 @@ __device__ __forceinline__ RowInfo make_row(const me_gemm_args& a, int m) {
     r.y0 = oy * a.stride - 1;
     r.x0 = ox * a.stride - 1;
   } else if (a.gather == ME_GATHER_TCONV) {
-    const int fr = (m / a.npix) % a.frames;
-    r.y0 = fr % a.chunk;
+    const int bf = m / a.npix;
+    r.y0 = bf % a.frames;                                  // local frame
+    r.x0 = (bf / a.frames) * a.npix + (m - bf * a.npix);   // b * npix + p: offset inside a halo block
   }
   return r;
 }
@@ -71,10 +72,14 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
     if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) return -1;
     return r.base + (iy >> a.ups) * a.Win + (ix >> a.ups);
   }
-  const int dt = tap - 1;  // TCONV
-  const int fc = r.y0 + dt;
-  if (fc < 0 || fc >= a.chunk) return -1;
-  return r.base + dt * a.npix;
+  const int dt = tap - 1;  // TCONV over global frames: same chunk, inside the clip
+  const int ftot = a.frames_total > 0 ? a.frames_total : a.frames;
+  const int gf = a.frame0 + r.y0, gs = gf + dt;
+  if (gs < 0 || gs >= ftot || gs / a.chunk != gf / a.chunk) return -1;
+  const int ls = r.y0 + dt;
+  if (ls >= 0 && ls < a.frames) return r.base + dt * a.npix;
+  const int hb = ls < 0 ? a.halo_prev : a.halo_next;    // neighbour rank's boundary frame
+  return hb < 0 ? -1 : hb + r.x0;
 }
 
 // lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
@@ -422,7 +427,9 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
         a->M % (a->Hout * a->Wout)) { me_set_error("me_gemm: bad conv geometry"); return ME_EINVAL; }
   }
   if (a->gather == ME_GATHER_TCONV) {
-    if (a->frames <= 0 || a->npix <= 0 || a->chunk <= 0 || a->frames % a->chunk || a->M % (a->frames * a->npix)) { me_set_error("me_gemm: bad tconv geometry"); return ME_EINVAL; }
+    const int ftot = a->frames_total > 0 ? a->frames_total : a->frames;
+    if (a->frames <= 0 || a->npix <= 0 || a->chunk <= 0 || ftot % a->chunk || a->M % (a->frames * a->npix) || a->frame0 < 0 ||
+        a->frame0 + a->frames > ftot) { me_set_error("me_gemm: bad tconv geometry"); return ME_EINVAL; }
   }
   if (a->rowvec && (a->rows_per_vec <= 0 || a->ldrv % 4 || ((uintptr_t)a->rowvec & 7))) { me_set_error("me_gemm: bad rowvec"); return ME_EINVAL; }
   if (a->res && (a->ldr % 4 || ((uintptr_t)a->res & 7))) { me_set_error("me_gemm: bad residual"); return ME_EINVAL; }

@@ -71,11 +71,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, const float* __restrict__ stats,
                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta, long rows,
-                                                       int rows_per_group, int C, int ldx, int ldy, int groups, float eps, int silu) {
+                                                       int rows_per_group, long rows_per_group_total, int C, int ldx, int ldy, int groups,
+                                                       float eps, int silu) {
   const int tpr = C / 8;
   const long nvec = rows * tpr;
   const int cg = C / groups;
-  const float inv_cnt = 1.0f / ((float)rows_per_group * (float)cg);
+  const float inv_cnt = 1.0f / ((float)rows_per_group_total * (float)cg);   // global count when frame-sharded
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long)gridDim.x * 256) {
     const long row = idx / tpr;
     const int vc = (int)(idx - row * tpr);
@@ -154,11 +155,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 
 extern "C" void me_set_error(const char* msg);
 
-extern "C" int me_groupnorm(const me_groupnorm_args* a, void* stream) {
+static int gn_validate(const me_groupnorm_args* a) {
   if (!a || !a->X || !a->Y || !a->gamma || !a->beta || !a->stats) { me_set_error("me_groupnorm: null pointer"); return ME_EINVAL; }
   if (a->rows <= 0 || a->rows_per_group <= 0 || a->rows % a->rows_per_group) { me_set_error("me_groupnorm: rows must be a multiple of rows_per_group"); return ME_EINVAL; }
   if (a->groups <= 0 || a->groups > 64 || a->C % a->groups || a->C % 8 || a->ldx % 8 || a->ldy % 8) { me_set_error("me_groupnorm: bad channel geometry"); return ME_EINVAL; }
   if (((uintptr_t)a->X | (uintptr_t)a->Y | (uintptr_t)a->gamma | (uintptr_t)a->beta) & 15) { me_set_error("me_groupnorm: misaligned pointer"); return ME_EINVAL; }
+  return ME_OK;
+}
+
+extern "C" int me_groupnorm_stats(const me_groupnorm_args* a, void* stream) {
+  if (int rc = gn_validate(a)) return rc;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int nsg = a->rows / a->rows_per_group;
   if (hipMemsetAsync(a->stats, 0, (size_t)nsg * a->groups * 2 * sizeof(float), st) != hipSuccess) { me_set_error("me_groupnorm: memset failed"); return ME_EHIP; }
@@ -171,14 +177,28 @@ extern "C" int me_groupnorm(const me_groupnorm_args* a, void* stream) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), a->stats, a->rows_per_group,
                      chunk_rows, a->C, a->ldx, a->groups);
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_stats: kernel launch failed"); return ME_EHIP; }
+  return ME_OK;
+}
+
+extern "C" int me_groupnorm_apply(const me_groupnorm_args* a, int64_t rows_per_group_total, void* stream) {
+  if (int rc = gn_validate(a)) return rc;
+  if (rows_per_group_total < a->rows_per_group) { me_set_error("me_groupnorm_apply: total rows per group smaller than the local count"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const long nvec = (long)a->rows * (a->C / 8);
   long blocks = (nvec + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  (void)hipGetLastError();
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), reinterpret_cast<f16*>(a->Y),
                      a->stats, reinterpret_cast<const f16*>(a->gamma), reinterpret_cast<const f16*>(a->beta), (long)a->rows, a->rows_per_group,
-                     a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu);
-  if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm: kernel launch failed"); return ME_EHIP; }
+                     (long)rows_per_group_total, a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu);
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_apply: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
+}
+
+extern "C" int me_groupnorm(const me_groupnorm_args* a, void* stream) {
+  if (int rc = me_groupnorm_stats(a, stream)) return rc;
+  return me_groupnorm_apply(a, a->rows_per_group, stream);
 }
 
 extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {

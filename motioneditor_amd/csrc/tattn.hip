@@ -28,7 +28,11 @@ __global__ __launch_bounds__(512) void tattn_kernel(const me_tattn_args a) {
   const int b = bid / a.npix;
   const int kb = a.kv_map[b];
   const int hps = SLICE / a.dh;  // heads per slice
-  const int nthr = hps * F;
+  const int QF = a.q_frames > 0 ? a.q_frames : F;          // local query frames (frame sharding) ...
+  const int q0 = a.q_frames > 0 ? a.q_frame0 : 0;          // ... starting at this global frame
+  const int parts = a.kv_parts > 1 ? a.kv_parts : 1;
+  const int fpp = F / parts;                               // frames per all-gathered K/V part
+  const int nthr = hps * QF;
   const int tid = threadIdx.x;
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
@@ -36,21 +40,21 @@ __global__ __launch_bounds__(512) void tattn_kernel(const me_tattn_args a) {
   const f16* __restrict__ V = reinterpret_cast<const f16*>(a.V);
   f16* __restrict__ O = reinterpret_cast<f16*>(a.O);
   const int col0 = sl * SLICE;
-  const long krow0 = (long)kb * F * a.npix + p;  // + j * npix
 
   // stage K, V: F rows x 40 chunks of 16 bytes each
   for (int idx = tid; idx < F * (SLICE / 8); idx += blockDim.x) {
     const int j = idx / (SLICE / 8), c = idx - j * (SLICE / 8);
-    const long row = krow0 + (long)j * a.npix;
+    const long row = ((long)(j / fpp) * a.batch + kb) * fpp * a.npix + (long)(j % fpp) * a.npix + p;
     *reinterpret_cast<uint4*>(sK + j * SLD + c * 8) = ldg128(K + row * a.ldk + col0 + c * 8);
     *reinterpret_cast<uint4*>(sV + j * SLD + c * 8) = ldg128(V + row * a.ldv + col0 + c * 8);
   }
   __syncthreads();
   if (tid >= nthr) return;
 
-  const int hl = tid / F, i = tid - hl * F;
+  const int hl = tid / QF, il = tid - hl * QF;
+  const int i = q0 + il;                                   // global frame of this query
   const int lcol = hl * a.dh;
-  const long qrow = ((long)b * F + i) * a.npix + p;
+  const long qrow = ((long)b * QF + il) * a.npix + p;
   const int nch = a.dh / 8;
 
   float s[F];
@@ -110,7 +114,7 @@ template <int F>
 int launch_tattn(const me_tattn_args* a, hipStream_t st) {
   const int nslice = (a->heads * a->dh) / SLICE;
   const int hps = SLICE / a->dh;
-  const int threads = ((hps * F + 63) / 64) * 64;
+  const int threads = ((hps * (a->q_frames > 0 ? a->q_frames : F) + 63) / 64) * 64;
   const long blocks = (long)a->batch * a->npix * nslice;
   const size_t lds = (size_t)2 * F * SLD * sizeof(f16);
   static bool attr_set = false;
@@ -133,6 +137,8 @@ extern "C" int me_tattn(const me_tattn_args* a, void* stream) {
   if (SLICE % a->dh || (a->heads * a->dh) % SLICE) { me_set_error("me_tattn: head dim must divide 320 and heads*dh be a multiple of 320"); return ME_EINVAL; }
   if (a->ldq % 8 || a->ldk % 8 || a->ldv % 8 || a->ldo % 8) { me_set_error("me_tattn: row strides must be multiples of 8"); return ME_EINVAL; }
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) & 15) { me_set_error("me_tattn: misaligned pointer"); return ME_EINVAL; }
+  if (a->q_frames < 0 || a->q_frame0 < 0 || (a->q_frames > 0 && a->q_frame0 + a->q_frames > a->frames) ||
+      (a->kv_parts > 1 && a->frames % a->kv_parts)) { me_set_error("me_tattn: bad frame-shard geometry"); return ME_EINVAL; }
   for (int b = 0; b < a->batch; ++b)
     if (a->kv_map[b] < 0 || a->kv_map[b] >= a->batch) { me_set_error("me_tattn: kv_map out of range"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

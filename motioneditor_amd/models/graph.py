@@ -59,6 +59,7 @@ class AttnCall:
     dh: int
     nk: int          # keys per kv item (N for self, 77 for text)
     is_cross: bool
+    shard: object = None   # parallel.FrameShard: k/v are then the all-gather of every rank's frames (part-major items)
 
     def run(self, seg_item: torch.Tensor, seg_mode: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         return ops.attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, n_items=self.B * self.f, nq=self.N, nk=self.nk,
@@ -74,9 +75,14 @@ class TemporalCall:
     f: int
     N: int
     dh: int
+    shard: object = None   # parallel.FrameShard: q holds the local frames, k/v all frames (all-gathered, part-major)
 
     def run(self, kv_map: Optional[Sequence[int]] = None) -> torch.Tensor:
-        return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=self.f, npix=self.N, kv_map=kv_map)
+        if self.shard is None:
+            return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=self.f, npix=self.N, kv_map=kv_map)
+        sh = self.shard
+        return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=sh.f_total, npix=self.N, kv_map=kv_map,
+                                      q_frames=sh.f_loc, q_frame0=sh.frame0, kv_parts=sh.world)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -92,7 +98,7 @@ def conv3x3(P: Packed, name: str, x: Act, stride: int = 1, ups: int = 0, **epi) 
     return x.like(out, ho, wo)
 
 
-def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *, per_frame_stats: bool, eps: float = 1e-5) -> Act:
+def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *, per_frame_stats: bool, eps: float = 1e-5, shard=None) -> Act:
     """ResnetBlock2D.forward (resnet_2d.py:199-249).  GroupNorm statistics span all frames of a batch row
     for the 3-D UNet (5-D GroupNorm, :202,230) and one image for the 2-D ControlNet."""
     rpg = x.N if per_frame_stats else x.f * x.N
@@ -102,22 +108,28 @@ def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *
     has_t1 = P.has(p + ".temp_conv1.weight") and not P.is_zero(p + ".temp_conv1.weight", p + ".temp_conv1.bias")
     has_t2 = P.has(p + ".temp_conv2.weight") and not P.is_zero(p + ".temp_conv2.weight", p + ".temp_conv2.bias")
 
-    h = ops.groupnorm(x.t, P.vec(p + ".norm1.weight"), P.vec(p + ".norm1.bias"), rows_per_group=rpg, eps=eps, silu=True)
+    gn = {}
+    if shard is not None and not per_frame_stats:   # 5-D GroupNorm: statistics span ALL frames -> all-reduce over the frame shards
+        gn = dict(reduce=shard.allreduce_, rows_per_group_total=shard.f_total * x.N)
+    ftot = shard.f_total if shard is not None else x.f
+    rows = x.B * x.f * x.N
+    h = ops.groupnorm(x.t, P.vec(p + ".norm1.weight"), P.vec(p + ".norm1.bias"), rows_per_group=rpg, eps=eps, silu=True, **gn)
     if has_t1:
-        h = conv3x3(P, p + ".conv1", x.like(h)).t
+        hx = torch.empty((_ext_rows(x, shard), cout), dtype=P.dtype, device=x.t.device)
+        h = conv3x3(P, p + ".conv1", x.like(h), out=hx).t
         # h + temp_conv1(h) + temb  (resnet_2d.py:207-228)
-        h = ops.gemm(h, P.mat(p + ".temp_conv1.weight"), bias=P.vec(p + ".temp_conv1.bias"), tconv=(x.f, x.N, x.f),
-                     rowvec=tv, rows_per_vec=rows_per_vec, res=h)
+        h = _tconv(P, p + ".temp_conv1", hx, x, ftot, shard, rowvec=tv, rows_per_vec=rows_per_vec, res=h)
     else:
         h = conv3x3(P, p + ".conv1", x.like(h), rowvec=tv, rows_per_vec=rows_per_vec).t
-    h = ops.groupnorm(h, P.vec(p + ".norm2.weight"), P.vec(p + ".norm2.bias"), rows_per_group=rpg, eps=eps, silu=True)
+    h = ops.groupnorm(h, P.vec(p + ".norm2.weight"), P.vec(p + ".norm2.bias"), rows_per_group=rpg, eps=eps, silu=True, **gn)
     if P.has(p + ".conv_shortcut.weight"):
         sc = ops.gemm(x.t, P.mat(p + ".conv_shortcut.weight"), bias=P.vec(p + ".conv_shortcut.bias"))
     else:
         sc = x.t
     if has_t2:
-        h = conv3x3(P, p + ".conv2", x.like(h)).t
-        h = ops.gemm(h, P.mat(p + ".temp_conv2.weight"), bias=P.vec(p + ".temp_conv2.bias"), tconv=(x.f, x.N, x.f), res=h, res2=sc)
+        hx = torch.empty((_ext_rows(x, shard), cout), dtype=P.dtype, device=x.t.device)
+        h = conv3x3(P, p + ".conv2", x.like(h), out=hx).t
+        h = _tconv(P, p + ".temp_conv2", hx, x, ftot, shard, res=h, res2=sc)
     else:
         h = conv3x3(P, p + ".conv2", x.like(h), res=sc).t
     return x.like(h)
@@ -133,18 +145,45 @@ def _ln(P: Packed, p: str, x: torch.Tensor) -> torch.Tensor:
     return ops.layernorm(x, P.vec(p + ".weight"), P.vec(p + ".bias"))
 
 
+def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard):
+    """q, k, v row views of the self-attention projections of `n`.  Unsharded: one fused [rows, 3C] GEMM.  Frame-sharded:
+    q stays local, k|v is projected into a contiguous [rows, 2C] tensor and all-gathered over the frame shards."""
+    names = [p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]
+    if shard is None:
+        qkv = ops.gemm(n, P.fused(names))
+        return qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    q = ops.gemm(n, P.mat(names[0]))
+    kv = shard.all_gather_rows(ops.gemm(n, P.fused(names[1:])))
+    return q, kv[:, :C], kv[:, C:]
+
+
+def _tconv(P: Packed, name: str, h_ext: torch.Tensor, x: "Act", chunk: int, shard, **epi) -> torch.Tensor:
+    """TemporalConv k=3 over frames.  Sharded: h_ext has 2*B*N spare rows for the neighbours' boundary frames."""
+    rows = x.B * x.f * x.N
+    if shard is None:
+        return ops.gemm(h_ext, P.mat(name + ".weight"), M=rows, bias=P.vec(name + ".bias"), tconv=(x.f, x.N, chunk), **epi)
+    hp, hn = shard.exchange_halos(h_ext, x.B, x.N, ops.copy_rows)
+    return ops.gemm(h_ext, P.mat(name + ".weight"), M=rows, bias=P.vec(name + ".bias"),
+                    tconv=(x.f, x.N, chunk, shard.frame0, shard.f_total, hp, hn), **epi)
+
+
+def _ext_rows(x: "Act", shard) -> int:
+    return x.B * x.f * x.N + (2 * x.B * x.N if shard is not None else 0)
+
+
 def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_seg, *, spatial, temporal, place: str,
-                sc_attn: bool, has_temp: bool) -> Act:
+                sc_attn: bool, has_temp: bool, shard=None) -> Act:
     """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C]."""
     t, C = x.t, x.C
     dh = C // HEADS
     # --- attn1 (MotionFrameAttention / patched closure, attention_2d.py:705-768, fully_control_utils.py:113-161)
-    qkv = ops.gemm(_ln(P, p + ".norm1", t), P.fused([p + ".attn1.to_q.weight", p + ".attn1.to_k.weight", p + ".attn1.to_v.weight"]))
-    call = AttnCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh, x.N, False)
+    sh1 = shard if sc_attn else None   # plain per-frame self-attention (ControlNet) needs no other frames
+    q, k, v = _qkv(P, p + ".attn1", _ln(P, p + ".norm1", t), C, sh1)
+    call = AttnCall(q, k, v, x.B, x.f, x.N, dh, x.N, False, sh1)
     if spatial is not None:
         a = spatial(call=call, is_cross=False, place_in_unet=place, num_heads=HEADS)
     elif sc_attn:
-        a = call.run(*segments.prev_cur(x.B, x.f, t.device))
+        a = call.run(*segments.prev_cur(x.B, x.f, t.device, sh1))
     else:
         a = call.run(*segments.self_items(x.B * x.f, t.device))
     t = ops.gemm(a, P.mat(p + ".attn1.to_out.0.weight"), bias=P.vec(p + ".attn1.to_out.0.bias"), res=t)
@@ -162,20 +201,20 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
     t = feed_forward(P, p + ".ff", _ln(P, p + ".norm3", t), t)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
     if has_temp:
-        qkv = ops.gemm(_ln(P, p + ".norm_temp", t), P.fused([p + ".attn_temp.to_q.weight", p + ".attn_temp.to_k.weight", p + ".attn_temp.to_v.weight"]))
-        tc = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh)
+        q, k, v = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, shard)
+        tc = TemporalCall(q, k, v, x.B, x.f, x.N, dh, shard)
         a = temporal(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if temporal is not None else tc.run()
         t = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     return x.like(t)
 
 
 def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, temporal=None, place: str = "", sc_attn: bool = True,
-                  has_temp: bool = True) -> Act:
+                  has_temp: bool = True, shard=None) -> Act:
     """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out."""
     n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
     t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
     t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
-                    sc_attn=sc_attn, has_temp=has_temp).t
+                    sc_attn=sc_attn, has_temp=has_temp, shard=shard).t
     return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t))
 
 
@@ -208,7 +247,7 @@ def time_embedding(P: Packed, t: float, names: List[str], device):
 # ---------------------------------------------------------------------------------------------
 # ControlAdapter (controlnet_adapter.py:437-565)
 # ---------------------------------------------------------------------------------------------
-def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int] = None) -> torch.Tensor:
+def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int] = None, shard=None) -> torch.Tensor:
     """ResnetBlock.forward (controlnet_adapter.py:497-534).  x: ControlNet residual rows [(b t N), C];
     src: UNet edit-branch skip rows [(nb t N), C].  Returns motion residual rows [(nb t N), C].
 
@@ -220,11 +259,16 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int
     dh = C // HEADS
     nb = x.B if nb is None else nb
     # conv path: TemporalConv(k=3) -> ReLU -> TemporalConv(k=1) -> + x, on independent chunks of 8 frames
-    hc = ops.gemm(t, P.mat(p + ".block1.weight"), bias=P.vec(p + ".block1.bias"), tconv=(x.f, x.N, ADAPTER_CHUNK), act=1)
+    if shard is None:
+        tx = t
+    else:   # chunks of 8 global frames may straddle ranks: boundary frames of the conv input come from the neighbours
+        tx = torch.empty((_ext_rows(x, shard), C), dtype=P.dtype, device=dev)
+        ops.copy_rows(tx[:t.shape[0]], t)
+    hc = _tconv(P, p + ".block1", tx, x, ADAPTER_CHUNK, shard, act=1)
     hc = ops.gemm(hc, P.mat(p + ".block2.weight"), bias=P.vec(p + ".block2.bias"), res=t)
     # sparse-causal self attention inside chunks of 8 frames
-    qkv = ops.gemm(_ln(P, p + ".norm_temp", t), P.fused([p + ".attn_temp.to_q.weight", p + ".attn_temp.to_k.weight", p + ".attn_temp.to_v.weight"]))
-    a = AttnCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], x.B, x.f, x.N, dh, x.N, False).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev))
+    q_, k_, v_ = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, shard)
+    a = AttnCall(q_, k_, v_, x.B, x.f, x.N, dh, x.N, False, shard).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev, shard))
     a = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
     # pose x UNet-feature cross attention, per frame
@@ -238,8 +282,8 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int
     a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a)
     a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
     # causal temporal attention over the TRUE frame count
-    qkv = ops.gemm(_ln(P, p + ".norm_self_temp", a), P.fused([p + ".attn_self_temp.to_q.weight", p + ".attn_self_temp.to_k.weight", p + ".attn_self_temp.to_v.weight"]))
-    at = TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, x.f, x.N, dh).run()
+    q_, k_, v_ = _qkv(P, p + ".attn_self_temp", _ln(P, p + ".norm_self_temp", a), C, shard)
+    at = TemporalCall(q_, k_, v_, nb, x.f, x.N, dh, shard).run()
     return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc)
 
 
@@ -257,7 +301,7 @@ def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
 
 def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
                  mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
-                 taps: Optional[dict] = None) -> Act:
+                 taps: Optional[dict] = None, shard=None) -> Act:
     """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
     ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
     Returns eps rows [(B f N), 4] as an Act."""
@@ -268,7 +312,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     temb, toff = time_embedding(P, t, resnet_names(True), dev)
     text = text_rows(ehs, P.dtype)
     tseg = segments.cross_text(B, f, dev)
-    kw = dict(spatial=spatial, temporal=temporal)
+    kw = dict(spatial=spatial, temporal=temporal, shard=shard)   # shard: this rank holds f = f_total / world consecutive frames
 
     x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
                            img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
@@ -276,7 +320,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     for i in range(4):
         for j in range(2):
             n = f"down_blocks.{i}.resnets.{j}"
-            x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+            x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
             if DOWN_HAS_ATTN[i]:
                 x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", **kw)
             skips.append(x)
@@ -295,9 +339,9 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 for k, eb in enumerate(edit_rows):
                     ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
                 shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows)))
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard))
             else:            # (unet_2d_condition.py:483-485)
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t))
+                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard))
         if taps is not None:
             taps["motion"] = [m.clone() for m in motion]
         new_skips = []
@@ -315,10 +359,10 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
         skips = new_skips
 
     n = "mid_block.resnets.0"
-    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
     x = transformer2d(P, "mid_block.attentions.0", x, text, tseg, place="mid", **kw)
     n = "mid_block.resnets.1"
-    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False)
+    x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
     if mid_res is not None:
         if two_branch:
             nr = x.f * x.N
@@ -337,12 +381,13 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             ops.copy_rows(cat[:, :x.C], x.t)
             ops.copy_rows(cat[:, x.C:], s.t)
             n = f"up_blocks.{i}.resnets.{j}"
-            x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False)
+            x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False, shard=shard)
             if UP_HAS_ATTN[i]:
                 x = transformer2d(P, f"up_blocks.{i}.attentions.{j}", x, text, tseg, place="up", **kw)
         if i < 3:
             x = conv3x3(P, f"up_blocks.{i}.upsamplers.0.conv", x, ups=1)
-    y = ops.groupnorm(x.t, P.vec("conv_norm_out.weight"), P.vec("conv_norm_out.bias"), rows_per_group=x.f * x.N, eps=1e-5, silu=True)
+    gn = dict(reduce=shard.allreduce_, rows_per_group_total=shard.f_total * x.N) if shard is not None else {}
+    y = ops.groupnorm(x.t, P.vec("conv_norm_out.weight"), P.vec("conv_norm_out.bias"), rows_per_group=x.f * x.N, eps=1e-5, silu=True, **gn)
     return conv3x3(P, "conv_out", x.like(y))
 
 

@@ -67,10 +67,10 @@ class UNet2DConditionModel:
             return res
         return ops.nchw5_to_rows(res.to(self.device))
 
-    def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None) -> graph.Act:
+    def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None) -> graph.Act:
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
         return graph.unet_forward(self.P, sample.to(self.device), t, encoder_hidden_states.to(self.device), down_res=down_rows, mid_res=mid_rows,
-                                  two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps)
+                                  two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps, shard=shard)
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None, return_dict: bool = True,
                 normal_infer: bool = False, skeleton=None, down_block_additional_residuals=None, mid_block_additional_residual=None,

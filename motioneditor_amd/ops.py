@@ -59,7 +59,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
          bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
          res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
-         tconv: Optional[Tuple[int, int, int]] = None) -> torch.Tensor:
+         tconv: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
 
     w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
@@ -77,7 +77,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
             raise ValueError("gemm: conv needs 9 taps")
     elif tconv is not None:
         a.gather = capi.GATHER_TCONV
-        a.frames, a.npix, a.chunk = tconv
+        a.frames, a.npix, a.chunk = tconv[:3]
+        if len(tconv) > 3:   # frame-sharded: (frames, npix, chunk, frame0, frames_total, halo_prev_row, halo_next_row)
+            a.frame0, a.frames_total, a.halo_prev, a.halo_next = tconv[3:]
         if taps != 3:
             raise ValueError("gemm: tconv needs 3 taps")
     elif taps != 1:
@@ -171,10 +173,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
 
 
 def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, dh: int, batch: int, frames: int, npix: int,
-                       kv_map: Optional[Sequence[int]] = None, scale: Optional[float] = None) -> torch.Tensor:
+                       kv_map: Optional[Sequence[int]] = None, scale: Optional[float] = None, q_frames: int = 0, q_frame0: int = 0,
+                       kv_parts: int = 1) -> torch.Tensor:
+    """frames = K/V frames.  Frame-sharded: q holds q_frames local frames from global frame q_frame0; k, v are the
+    all-gather (part-major) of kv_parts equal frame shards."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk2d(t, "temporal_attention." + n)
-    out = empty(batch * frames * npix, heads * dh, q)
+    out = empty(batch * (q_frames or frames) * npix, heads * dh, q)
     a = TAttnArgs()
     a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
     a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
@@ -183,6 +188,7 @@ def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hea
     for i in range(8):
         a.kv_map[i] = km[i] if i < len(km) else 0
     a.scale = dh ** -0.5 if scale is None else scale
+    a.q_frames, a.q_frame0, a.kv_parts = q_frames, q_frame0, kv_parts
     e0 = _pb()
     capi.check(capi.lib().me_tattn(C.byref(a), _stream()), "me_tattn")
     _pe(e0, "tattn", 4.0 * batch * npix * heads * frames * frames * dh, 2.0 * 4 * batch * frames * npix * heads * dh)
@@ -193,7 +199,9 @@ _gn_scratch = {}
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_per_group: int, eps: float, silu: bool,
-              groups: int = 32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              groups: int = 32, out: Optional[torch.Tensor] = None, reduce=None, rows_per_group_total: Optional[int] = None) -> torch.Tensor:
+    """reduce: callable(stats fp32 tensor) -> None that all-reduces the (sum, sumsq) statistics over the frame shards
+    (the reference's 5-D GroupNorm spans all frames); rows_per_group_total = the global rows per group."""
     _chk2d(x, "groupnorm.x")
     rows, Cc = x.shape
     if out is None:
@@ -208,7 +216,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_
     a.rows, a.rows_per_group, a.C, a.ldx, a.ldy = rows, rows_per_group, Cc, x.stride(0), out.stride(0)
     a.groups, a.eps, a.silu = groups, eps, 1 if silu else 0
     e0 = _pb()
-    capi.check(capi.lib().me_groupnorm(C.byref(a), _stream()), "me_groupnorm")
+    if reduce is None:
+        capi.check(capi.lib().me_groupnorm(C.byref(a), _stream()), "me_groupnorm")
+    else:
+        capi.check(capi.lib().me_groupnorm_stats(C.byref(a), _stream()), "me_groupnorm_stats")
+        reduce(stats[:nsg * groups * 2])
+        capi.check(capi.lib().me_groupnorm_apply(C.byref(a), rows_per_group_total or rows_per_group, _stream()), "me_groupnorm_apply")
     _pe(e0, "groupnorm", 8.0 * rows * Cc, 4.0 * rows * Cc)
     return out
 

@@ -1,0 +1,70 @@
+"""Frame sharding of one clip over the GPUs of a node: each rank owns f/R consecutive frames of all
+four batch rows, so the reconstruction -> editing K/V injection stays rank-local.  The cross-frame couplings of the
+reference become these exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests):
+
+  * spatial attn1 (previous-frame keys), adapter sparse-causal attention (first / previous frame of an 8-frame
+    chunk), temporal attention (all earlier frames): ONE all-gather of the layer's K|V rows; the attention kernels
+    address the gathered tensor part-major through their key-segment tables / kv_parts argument;
+  * TemporalConv k=3: one-frame halos from both neighbours (point-to-point);
+  * ResnetBlock2D / conv_norm_out GroupNorm (statistics span all frames): all-reduce of (sum, sum of squares).
+ControlNet, cross-attention, feed-forward, spatial convolutions, per-frame GroupNorm, CFG and DDIM are rank-local.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FrameShard:
+    def __init__(self, f_total: int, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if f_total % self.world:
+            raise ValueError(f"{f_total} frames do not split evenly over {self.world} ranks")
+        self.f_total = f_total
+        self.f_loc = f_total // self.world
+        self.frame0 = self.rank * self.f_loc
+        self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
+
+    # ---- GroupNorm statistics -------------------------------------------------------------------------
+    def allreduce_(self, t: torch.Tensor) -> None:
+        dist.all_reduce(t, group=self.group)
+
+    # ---- K|V rows of all frame shards, part-major -----------------------------------------------------
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather(list(out.unbind(0)), t, group=self.group)
+        return out.reshape(self.world * t.shape[0], *t.shape[1:])
+
+    def item(self, B: int, b: int, g: int) -> int:
+        """kv item index of (batch row b, GLOBAL frame g) inside an all-gathered [world][B*f_loc items] tensor."""
+        return (g // self.f_loc) * (B * self.f_loc) + b * self.f_loc + g % self.f_loc
+
+    # ---- one-frame halos for the temporal convolutions --------------------------------------------------
+    def exchange_halos(self, x_ext: torch.Tensor, B: int, npix: int, copy_rows) -> tuple:
+        """x_ext rows = [B*f_loc*npix local | B*npix halo of the previous rank | B*npix halo of the next rank].
+        Sends this rank's first / last frame to its neighbours and receives theirs.  Returns (halo_prev_row,
+        halo_next_row) with -1 where there is no neighbour."""
+        rows = B * self.f_loc * npix
+        hb = B * npix
+        prev_blk, next_blk = x_ext[rows:rows + hb], x_ext[rows + hb:rows + 2 * hb]
+        ops_ = []
+        first = last = None
+        if self.rank > 0:
+            first = torch.empty_like(prev_blk)
+            for b in range(B):
+                copy_rows(first[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc) * npix:(b * self.f_loc + 1) * npix])
+            ops_ += [dist.P2POp(dist.isend, first, self._ranks[self.rank - 1], self.group), dist.P2POp(dist.irecv, prev_blk, self._ranks[self.rank - 1], self.group)]
+        if self.rank < self.world - 1:
+            last = torch.empty_like(next_blk)
+            for b in range(B):
+                copy_rows(last[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
+            ops_ += [dist.P2POp(dist.isend, last, self._ranks[self.rank + 1], self.group), dist.P2POp(dist.irecv, next_blk, self._ranks[self.rank + 1], self.group)]
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+        return (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)

@@ -97,6 +97,30 @@ class MotionEditorPipeline:
         return ((video / 2 + 0.5).clamp(0, 1)).cpu().float().numpy()
 
     @torch.no_grad()
+    def denoise_step_frame_sharded(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
+                                   guidance_scale: float, shard, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
+        """The same step with the FRAME axis sharded over the ranks of `shard` (parallel.FrameShard; SURVEY.md 8e, BASELINE
+        config 4).  latents fp32 [2,4,f_loc,h,w] and images [2*f_loc,3,H,W] (or [f_loc,...]) hold this rank's frames only.
+        Exchanges per layer: all-gather of K|V for attn1 / adapter sparse-causal / temporal attention, one-frame halos for the
+        temporal convolutions, all-reduce of the 5-D GroupNorm statistics.  ControlNet, CFG and DDIM are rank-local."""
+        if shard.f_total % 2:
+            raise NotImplementedError("frame sharding relies on the ControlNet batch-entry identity, which needs an even frame count")
+        f = latents.shape[2]
+        assert f == shard.f_loc, (f, shard.f_loc)
+        x4 = torch.cat([latents] * 2)
+        down = mid = None
+        two = False
+        if self.controlnet is not None and images is not None:
+            prompt = text_embeddings_input[[1, 3]]
+            img = images[:f] if images.shape[0] == 2 * f else images
+            # row r of the full "(b f)" ControlNet batch reads prompt r % 2: this rank's first row is global frame frame0
+            down, mid = self.controlnet.forward_rows(x4, [1], t, prompt, img, controlnet_conditioning_scale, row_offset=shard.frame0)
+            two = True
+        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, shard=shard)
+        ca, cb = self.scheduler.coeffs(int(t))
+        return ops.cfg_ddim(latents, eps.t, guidance=guidance_scale, ca=ca, cb=cb)
+
+    @torch.no_grad()
     def denoise_step_cfg_parallel(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
                                   guidance_scale: float, group=None, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
         """The same step split over a 2-rank process group along the classifier-free-guidance axis: rank 0 runs the

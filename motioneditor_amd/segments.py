@@ -42,24 +42,34 @@ def cross_interleaved(n_items: int, n_text: int, device, row_offset: int = 0):
     return _mk(("crossil", n_items, n_text, row_offset), [[(i + row_offset) % n_text] for i in range(n_items)], [[SEG_PLAIN]] * n_items, device)
 
 
-def prev_cur(B: int, f: int, device):
-    """MotionFrameAttention: keys = [frame max(i-1,0) | frame i] (attention_2d.py:732-740)."""
-    rows = [[b * f + max(i - 1, 0), b * f + i] for b in range(B) for i in range(f)]
-    return _mk(("prevcur", B, f), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+def _gi(shard, B, f):
+    """(b, GLOBAL frame) -> kv item index: plain (b*f + g) unsharded, part-major into the all-gathered K|V when sharded."""
+    if shard is None:
+        return (lambda b, g: b * f + g), 0, ()
+    return (lambda b, g: shard.item(B, b, g)), shard.frame0, (shard.world, shard.rank)
 
 
-def first_prev_chunked(B: int, f: int, chunk: int, device):
+def prev_cur(B: int, f: int, device, shard=None):
+    """MotionFrameAttention: keys = [frame max(i-1,0) | frame i] (attention_2d.py:732-740).  f = local frames."""
+    gi, f0, key = _gi(shard, B, f)
+    rows = [[gi(b, max(f0 + i - 1, 0)), gi(b, f0 + i)] for b in range(B) for i in range(f)]
+    return _mk(("prevcur", B, f) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+
+
+def first_prev_chunked(B: int, f: int, chunk: int, device, shard=None):
     """Adapter sparse-causal attention on independent chunks of `chunk` frames:
     keys = [first frame of chunk | previous frame in chunk] (controlnet_adapter.py:352-361,414,472)."""
+    gi, f0, key = _gi(shard, B, f)
     rows = []
     for b in range(B):
         for i in range(f):
-            c0 = i - i % chunk
-            rows.append([b * f + c0, b * f + c0 + max(i % chunk - 1, 0)])
-    return _mk(("firstprev", B, f, chunk), rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+            g = f0 + i
+            c0 = g - g % chunk
+            rows.append([gi(b, c0), gi(b, c0 + max(g % chunk - 1, 0))])
+    return _mk(("firstprev", B, f, chunk) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
 
 
-def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4):
+def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4, shard=None):
     """FullySelfAttentionControlMask on batch 4 = [u.rec, u.edit, c.rec, c.edit] (fully_control.py:425-447;
     B = 2 is one (rec, edit) pair, i.e. one classifier-free-guidance half on a CFG-parallel rank):
     recon rows keep [prev | cur]; edit rows attend [src prev (fg/bg dual, mask frame max(head-1,0)) |
@@ -67,14 +77,15 @@ def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4):
     (k[:, 3N:], fully_control.py:383).  With a binary mask (the reference's man.mask PNGs are 0/255) the
     fg/bg pair of every source key weighs exp(s) + exp(0) whichever way the bit points, so the kernel's
     DUAL_BIN mode needs no mask read."""
+    gi, f0, key = _gi(shard, B, f)
     rows, modes = [], []
     for b in range(B):
         for i in range(f):
+            g = f0 + i
             if b % 2 == 0:
-                rows.append([b * f + max(i - 1, 0), b * f + i, -1])
+                rows.append([gi(b, max(g - 1, 0)), gi(b, g), -1])
                 modes.append([SEG_PLAIN, SEG_PLAIN, SEG_PLAIN])
             else:
-                s = (b - 1) * f
-                rows.append([s + max(i - 1, 0), s + i, b * f + i])
+                rows.append([gi(b - 1, max(g - 1, 0)), gi(b - 1, g), gi(b, g)])
                 modes.append([SEG_DUAL_BIN, SEG_DUAL_BIN, SEG_PLAIN] if binary_mask else [SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
-    return _mk(("edited", f, binary_mask, B), rows, modes, device)
+    return _mk(("edited", f, binary_mask, B) + key, rows, modes, device)

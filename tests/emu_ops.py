@@ -39,6 +39,27 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
         y = F.conv2d(img, wk, None, stride=stride, padding=1)
         assert y.shape[2] == Hout and y.shape[3] == Wout
         acc = y.permute(0, 2, 3, 1).reshape(-1, N)
+    elif tconv is not None and len(tconv) > 3:
+        # frame-sharded: local frames [frame0, frame0+frames) of frames_total; halo rows appended to x
+        frames, npix, chunk, frame0, ftot, hp, hn = tconv
+        Ml = M if M is not None else x.shape[0]
+        nb = Ml // (frames * npix)
+        loc = xf[:Ml].reshape(nb, frames, npix, K)
+        acc = torch.zeros(nb, frames, npix, N)
+        for fr in range(frames):
+            g = frame0 + fr
+            for tap in range(3):
+                gs = g + tap - 1
+                if gs < 0 or gs >= ftot or gs // chunk != g // chunk:
+                    continue
+                ls = fr + tap - 1
+                if 0 <= ls < frames:
+                    src = loc[:, ls]
+                else:
+                    h0 = hp if ls < 0 else hn
+                    src = xf[h0:h0 + nb * npix].reshape(nb, npix, K)
+                acc[:, fr] += src @ wf[:, tap].t()
+        acc = acc.reshape(-1, N)
     elif tconv is not None:
         frames, npix, chunk = tconv
         nb = x.shape[0] // (frames * npix)
@@ -130,26 +151,39 @@ def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=N
     return res
 
 
-def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, scale=None):
+def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1):
     scale = dh ** -0.5 if scale is None else scale
     C = heads * dh
     km = list(kv_map) if kv_map is not None else list(range(batch))
+    qf = q_frames or frames
+    fpp = frames // max(kv_parts, 1)
 
-    def shp(t):  # rows (b f p) -> [b, p, H, f, dh]
-        return t.float()[:, :C].reshape(batch, frames, npix, heads, dh).permute(0, 2, 3, 1, 4)
+    def kv_shp(t):  # part-major rows (part b fl p) -> [b, p, H, f, dh]
+        t = t.float()[:, :C].reshape(max(kv_parts, 1), batch, fpp, npix, heads, dh).permute(1, 0, 2, 3, 4, 5).reshape(batch, frames, npix, heads, dh)
+        return t.permute(0, 2, 3, 1, 4)
 
-    qq, kk, vv = shp(q), shp(k)[km], shp(v)[km]
+    qq = q.float()[:, :C].reshape(batch, qf, npix, heads, dh).permute(0, 2, 3, 1, 4)
+    kk, vv = kv_shp(k)[km], kv_shp(v)[km]
     s = torch.einsum("bphid,bphjd->bphij", qq, kk) * scale
-    s = s + (1.0 - torch.tril(torch.ones(frames, frames))) * -10000.0
+    gi = (q_frame0 if q_frames else 0) + torch.arange(qf)
+    s = s + (torch.arange(frames)[None, :] > gi[:, None]).float() * -10000.0
     o = torch.einsum("bphij,bphjd->bphid", s.softmax(-1), vv)
-    return o.permute(0, 3, 1, 2, 4).reshape(batch * frames * npix, C).to(q.dtype)
+    return o.permute(0, 3, 1, 2, 4).reshape(batch * qf * npix, C).to(q.dtype)
 
 
-def groupnorm(x, gamma, beta, *, rows_per_group, eps, silu, groups=32, out=None):
+def groupnorm(x, gamma, beta, *, rows_per_group, eps, silu, groups=32, out=None, reduce=None, rows_per_group_total=None):
     rows, C = x.shape
     t = x.float().reshape(rows // rows_per_group, rows_per_group, groups, C // groups)
-    mean = t.mean(dim=(1, 3), keepdim=True)
-    var = t.var(dim=(1, 3), unbiased=False, keepdim=True)
+    if reduce is not None:   # frame-sharded: (sum, sumsq) all-reduced over the ranks, global count
+        st = torch.stack([t.sum(dim=(1, 3)), (t * t).sum(dim=(1, 3))], dim=-1).reshape(-1).contiguous()
+        reduce(st)
+        st = st.reshape(rows // rows_per_group, groups, 2)
+        cnt = float((rows_per_group_total or rows_per_group) * (C // groups))
+        mean = (st[..., 0] / cnt)[:, None, :, None]
+        var = (st[..., 1] / cnt)[:, None, :, None] - mean * mean
+    else:
+        mean = t.mean(dim=(1, 3), keepdim=True)
+        var = t.var(dim=(1, 3), unbiased=False, keepdim=True)
     y = ((t - mean) / torch.sqrt(var + eps)).reshape(rows, C) * gamma.float() + beta.float()
     if silu:
         y = F.silu(y)

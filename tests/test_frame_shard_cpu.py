@@ -1,0 +1,74 @@
+"""Multi-process (gloo, CPU) check of the FRAME-SHARDED denoising step (SURVEY.md 8e / BASELINE config 4): the clip's frames
+are split over the ranks; K|V all-gathers (attn1, adapter sparse-causal, temporal attention), one-frame halos (TemporalConv)
+and GroupNorm-statistic all-reduces must reproduce the single-process step.  f = 16 over 2 ranks (8-frame adapter chunks
+aligned with the shards) and f = 24 over 2 ranks (the chunk [8, 16) straddles the rank boundary).  Product pipeline / graph /
+editor code on tests/emu_ops.py."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _worker(rank, world, port, f, out_path):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_ops
+    import motioneditor_amd.models.unet_2d_condition as u
+    import motioneditor_amd.pipelines.pipeline_motion_editor as pm
+    from motioneditor_amd import parallel, schedulers, synth
+    from motioneditor_amd.attn_control import (FullySelfAttentionControlMask, TemporalSelfAttentionControl,
+                                               regiter_fully_attention_editor_diffusers, regiter_temporal_attention_editor_diffusers)
+    from motioneditor_amd.models import graph
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    for m in (graph, u, pm, schedulers):
+        m.ops = emu_ops
+    x = step_inputs(f=f, h=8, w=8)
+    unet = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cpu", dtype=torch.float32)
+    cn = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cpu", dtype=torch.float32)
+    pipe = MotionEditorPipeline(unet=unet, controlnet=cn)
+    ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
+    regiter_temporal_attention_editor_diffusers(pipe, ted)
+    sed = FullySelfAttentionControlMask(start_step=4, start_layer=10, source_masks=x["masks"])
+    regiter_fully_attention_editor_diffusers(pipe, sed)
+    pipe.scheduler.set_timesteps(50)
+    step = 4
+    t = pipe.scheduler.timesteps[step]
+    H = x["skeleton"].shape[-1]
+    images = x["skeleton"].reshape(f, 3, H, H)
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]])
+    shard = parallel.FrameShard(f)
+    lo, hi = shard.frame0, shard.frame0 + shard.f_loc
+    ted.cur_step = sed.cur_step = step
+    got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard)
+    assert (sed.cur_step, ted.cur_step, sed.cur_att_layer, ted.cur_att_layer) == (step + 1, step + 1, 0, 0)
+    parts = [torch.empty_like(got) for _ in range(world)]
+    dist.all_gather(parts, got)
+    full = torch.cat(parts, dim=2)
+    if rank == 0:   # single-process reference of the same step
+        ted.reset(); sed.reset()
+        ted.cur_step = sed.cur_step = step
+        want = pipe.denoise_step(x["latents"], t, emb, torch.cat([images] * 2), 7.5)
+        torch.save({"err": float((full - want).abs().max() / want.abs().mean())}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("f", [16, 24])
+def test_frame_sharded_step_equals_single_process(tmp_path, f):
+    out = tmp_path / "r.pt"
+    port = 29700 + (os.getpid() % 2000) + f
+    mp.spawn(_worker, args=(2, port, f, str(out)), nprocs=2, join=True)
+    err = torch.load(out)["err"]
+    assert err < 1e-4, err

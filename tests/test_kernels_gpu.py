@@ -281,3 +281,37 @@ def test_ddim_matches_reference_golden(ops):
     for t in (981, 501, 21, 1):
         out = s.step(cu(e), t, cu(x)).prev_sample
         check(out, torch.from_numpy(g[f"prev_{t}"]).reshape(2, 4, 1, 8, 8), f"ddim t={t}", rel=1e-3, mx=5e-3)  # eps passes through fp16 rows
+
+
+# ------------------------------------------------------------------ frame-sharding features of the kernels
+@pytest.mark.parametrize("F,parts,qf,q0,dh", [(16, 2, 8, 8, 40), (24, 3, 8, 8, 80), (24, 4, 6, 18, 40), (16, 1, 16, 0, 160)])
+def test_temporal_attention_sharded_queries_part_major_kv(ops, F, parts, qf, q0, dh):
+    B, npix, C = 4, 3, 8 * dh
+    q = rnd(B * qf * npix, C, seed=1)
+    kv = rnd(parts * B * (F // parts) * npix, 2 * C, seed=2)      # all-gathered K|V, part-major
+    args = dict(heads=8, dh=dh, batch=B, frames=F, npix=npix, kv_map=[0, 0, 2, 2], q_frames=qf, q_frame0=q0, kv_parts=parts)
+    got = ops.temporal_attention(cu(q), cu(kv)[:, :C], cu(kv)[:, C:], **args)
+    check(got, emu.temporal_attention(q, kv[:, :C], kv[:, C:], **args), f"tattn sharded F={F} parts={parts}")
+
+
+@pytest.mark.parametrize("C,f_loc,f_tot,frame0,chunk,npix,nb", [(320, 8, 24, 8, 24, 4, 2), (320, 12, 24, 12, 8, 4, 1), (640, 6, 24, 0, 8, 2, 2), (320, 6, 24, 18, 24, 3, 4)])
+def test_gemm_tconv_sharded_with_halos(ops, C, f_loc, f_tot, frame0, chunk, npix, nb):
+    rows = nb * f_loc * npix
+    hb = nb * npix
+    x = rnd(rows + 2 * hb, C, seed=1)                              # [local | prev halo | next halo]
+    w = rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
+    bias, res = rnd(C, seed=3), rnd(rows, C, seed=4)
+    hp = rows if frame0 > 0 else -1
+    hn = rows + hb if frame0 + f_loc < f_tot else -1
+    tc = (f_loc, npix, chunk, frame0, f_tot, hp, hn)
+    got = ops.gemm(cu(x), cu(w), M=rows, bias=cu(bias), tconv=tc, res=cu(res))
+    check(got, emu.gemm(x, w, M=rows, bias=bias, tconv=tc, res=res), f"tconv sharded f_loc={f_loc} frame0={frame0} chunk={chunk}")
+
+
+def test_groupnorm_with_cross_rank_statistic_reduction_hook(ops):
+    """stats -> reduce hook -> apply with the global count: doubling the statistics and the count must be the identity."""
+    C, rows, rpg = 640, 4 * 96, 96
+    x = (rnd(rows, C, seed=1) * 2 + 0.7).half()
+    gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
+    got = ops.groupnorm(cu(x), cu(gm), cu(bt), rows_per_group=rpg, eps=1e-5, silu=True, reduce=lambda st: st.mul_(2.0), rows_per_group_total=2 * rpg)
+    check(got, emu.groupnorm(x, gm, bt, rows_per_group=rpg, eps=1e-5, silu=True), "groupnorm split stats/apply")

@@ -177,3 +177,36 @@ def test_properties_at_larger_size(unet):
     assert rel_l2(m4[:, :8], m1[:, :8]) < 3e-3            # frames 0-7: other chunk + causal -> untouched
     assert rel_l2(m4[:, 9:], m1[:, 9:]) > 3e-2            # frame 9 itself, later frames of its chunk, and causal look-back
     unet.spatial_editor = unet.temporal_editor = None
+
+
+def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
+    """World-size-1 RCCL process group: exercises the frame-sharded code path (K|V all-gather, sharded tconv / temporal
+    attention arguments, GroupNorm split) through the real kernels; must equal the ordinary step to the noise floor.
+    Multi-rank correctness of the exchanges is covered by tests/test_frame_shard_cpu.py (gloo, world 2)."""
+    import torch.distributed as dist
+    from motioneditor_amd import parallel
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        x = step_inputs(f=16)
+        f = 16
+        pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+        sed, ted = editors(unet, x["masks"])
+        pipe.scheduler.set_timesteps(50)
+        t = pipe.scheduler.timesteps[4]
+        images = x["skeleton"].reshape(f, 3, 64, 64).cuda()
+        emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+        sed.cur_step = ted.cur_step = 4
+        want = pipe.denoise_step(x["latents"].cuda(), t, emb, torch.cat([images] * 2), 7.5)
+        sed.reset(); ted.reset()
+        sed.cur_step = ted.cur_step = 4
+        got = pipe.denoise_step_frame_sharded(x["latents"].cuda(), t, emb, images, 7.5, parallel.FrameShard(f))
+        e = rel_l2(got, want)
+        record("frame_shard_world1", e)
+        assert e < 3e-3, e
+    finally:
+        unet.spatial_editor = unet.temporal_editor = None
+        dist.destroy_process_group()
