@@ -210,15 +210,23 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
         mrun[qt] = mnew;
         const float e0 = MODE == ME_SEG_DUAL_BIN ? __builtin_amdgcn_exp2f(-mnew) : 0.f;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): the VALU pipe is the bound of this kernel
+        const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew}, e2 = {e0, e0};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            p[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][r], c, -mnew)) + e0;
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 sv = {s[qt][t][2 * h2], s[qt][t][2 * h2 + 1]};
+            const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
+            f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+            if constexpr (MODE == ME_SEG_DUAL_BIN) pv += e2;
+            p[t][2 * h2] = pv[0];
+            p[t][2 * h2 + 1] = pv[1];
             if constexpr (!FULL && MODE == ME_SEG_DUAL_BIN) {
-              if (kbase + t * 16 + r >= a.nk) p[t][r] = 0.f;
+              if (kbase + t * 16 + 2 * h2 >= a.nk) p[t][2 * h2] = 0.f;
+              if (kbase + t * 16 + 2 * h2 + 1 >= a.nk) p[t][2 * h2 + 1] = 0.f;
             }
-            if constexpr (!ONES) psum += p[t][r];
+            if constexpr (!ONES) psum += p[t][2 * h2] + p[t][2 * h2 + 1];
           }
       } else {
         // general (non-binary) masks: both copies' logits are needed.  Compiled only into the GD instantiation
@@ -257,14 +265,14 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
       }
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        f16x8 f;
+      for (int kk = 0; kk < 2; ++kk) {   // four v_cvt_pk_f16_f32 per fragment, no per-element inserts
+        union { f16x2 h[4]; f16x8 v; } f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          f[r] = (f16)p[2 * kk][r];
-          f[4 + r] = (f16)p[2 * kk + 1][r];
+        for (int h2 = 0; h2 < 2; ++h2) {
+          f.h[h2] = __builtin_convertvector((f32x2){p[2 * kk][2 * h2], p[2 * kk][2 * h2 + 1]}, f16x2);
+          f.h[2 + h2] = __builtin_convertvector((f32x2){p[2 * kk + 1][2 * h2], p[2 * kk + 1][2 * h2 + 1]}, f16x2);
         }
-        pf[qt][kk] = f;
+        pf[qt][kk] = f.v;
       }
     }
 
