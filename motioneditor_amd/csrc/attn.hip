@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int DT = (DH + 15) / 16;
   constexpr int KLD = D32 * 32 + 8;
   constexpr int BQ = 64 * QT;
-  constexpr int NLD = (KT * CH + 255) / 256;
+  constexpr int NCH = KT * CH;          // 16-byte chunks per K (or V) tile
+  constexpr int NFULL = NCH / 256;      // staging rounds in which every wave moves one chunk column (64 keys x 16 B)
+  constexpr int RW = (NCH % 256) / 64;  // leftover chunk columns
+  constexpr int NLD = NFULL + (RW ? 1 : 0);
   // V^T has padding rows when dh is not a multiple of 16 (40 -> 48, 80 -> 96): make the first one all ones, so the
   // PV MFMA accumulates the softmax denominator in accumulator row DH for free (no VALU row sums, and the sum is
   // taken over exactly the fp16-rounded P that multiplies V)
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4;
   const int l15 = lane & 15;
 
@@ -95,47 +98,84 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   const int T = nvalid * ntk;
   const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
+  // Staging map: lane = key inside the tile, wave = 16-byte chunk column (cc = wave + 4 * round), so a wave's
+  // transposed b16 stores hit 32 distinct LDS banks and the global address is "uniform tile base + per-lane row
+  // offset + immediate": no per-tile index arithmetic.  NCH % 256 leftover columns (dh 40: one, dh 80: two) go to
+  // RW waves rotated over the tiles so that no wave is always the slow one in front of the barrier.
   uint4 rk[NLD], rv[NLD];
-  auto gload = [&](int ti) {
-    const int seg = ti / ntk, kt = ti - seg * ntk;
-    const int kit = a.seg_item[item * a.nseg + seg];
-    const int key0 = kt * KT;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      const int cc = idx / KT, key = idx - cc * KT;   // a wave = 64 consecutive keys of ONE 16-byte chunk column:
-      const bool ok = idx < KT * CH && key0 + key < a.nk;  // its transposed b16 stores hit 32 distinct LDS banks
-      const long row = (long)kit * a.nk + key0 + key;
-      rk[i] = ok ? ldg128(K + row * a.ldk + h * DH + cc * 8) : zero128();
-      rv[i] = ok ? ldg128(V + row * a.ldv + h * DH + cc * 8) : zero128();
+  const int koff0 = lane * a.ldk + h * DH;
+  const int voff0 = lane * a.ldv + h * DH;
+  // load cursor = the tile being fetched (two ahead of the one consumed): uniform tile base pointers, bumped by a
+  // constant per tile and re-derived from seg_item only when a segment ends
+  int seg_l = 0, kt_l = 0;
+  const f16 *kptr_l = K, *vptr_l = V;
+  auto seg_base = [&]() {
+    const int kit = a.seg_item[item * a.nseg + seg_l];
+    kptr_l = K + (long)kit * a.nk * a.ldk;
+    vptr_l = V + (long)kit * a.nk * a.ldv;
+  };
+  auto advance_l = [&]() {
+    if (++kt_l == ntk) {
+      kt_l = 0;
+      if (++seg_l < nvalid) seg_base();
+    } else {
+      kptr_l += KT * a.ldk;
+      vptr_l += KT * a.ldv;
     }
   };
+  auto gload = [&](int ti) {
+    int ko = koff0, vo = voff0;
+    if ((kt_l + 1) * KT > a.nk) {   // tail tile: keys past nk re-read the last key (finite; their logits are masked)
+      const int kl = min(lane, a.nk - 1 - kt_l * KT);
+      ko = kl * a.ldk + h * DH;
+      vo = kl * a.ldv + h * DH;
+    }
+#pragma unroll
+    for (int i = 0; i < NFULL; ++i) {
+      rk[i] = ldg128(kptr_l + ko + (wave + 4 * i) * 8);
+      rv[i] = ldg128(vptr_l + vo + (wave + 4 * i) * 8);
+    }
+    if constexpr (RW > 0) {
+      const int r = (wave - ti) & 3;
+      if (r < RW) {
+        rk[NFULL] = ldg128(kptr_l + ko + (4 * NFULL + r) * 8);
+        rv[NFULL] = ldg128(vptr_l + vo + (4 * NFULL + r) * 8);
+      }
+    }
+    advance_l();
+  };
+  int seg_s = 0, kt_s = 0;   // store cursor (general dual-mask instantiation only: which mask plane / keys)
   auto sstore = [&](int ti) {
     f16* sK = sKb[ti & (NBUF - 1)];
     f16* sVt = sVtb[ti & (NBUF - 1)];
-    f16* sM = sMb[ti & (NBUF - 1)];
-    const int seg = ti / ntk, kt = ti - seg * ntk;
-    const int mode = a.seg_mode[item * a.nseg + seg];
+    auto put = [&](int cc, const uint4& k, const uint4& v) {
+      *reinterpret_cast<uint4*>(sK + lane * KLD + cc * 8) = k;
+      U128 u;
+      u.u = v;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int idx = tid + 256 * i;
-      if (idx < KT * CH) {
-        const int cc = idx / KT, key = idx - cc * KT;
-        *reinterpret_cast<uint4*>(sK + key * KLD + cc * 8) = rk[i];
-        U128 u;
-        u.u = rv[i];
+      for (int e = 0; e < 8; ++e) sVt[(cc * 8 + e) * VLD + lane] = u.e[e];
+    };
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sVt[(cc * 8 + e) * VLD + key] = u.e[e];
-      }
+    for (int i = 0; i < NFULL; ++i) put(wave + 4 * i, rk[i], rv[i]);
+    if constexpr (RW > 0) {
+      const int r = (wave - ti) & 3;
+      if (r < RW) put(4 * NFULL + r, rk[NFULL], rv[NFULL]);
     }
-    if (tid < KT) {
-      f16 mv = (f16)0.f;
-      const int key = kt * KT + tid;
-      if (mode != ME_SEG_PLAIN && key < a.nk) {
-        const int plane = mode == ME_SEG_DUAL_CUR ? h : (h > 0 ? h - 1 : 0);
-        mv = Mk[(long)plane * a.nk + key];
+    if constexpr (GD) {   // mask values of the tile's keys
+      if (tid < KT) {
+        const int mode = a.seg_mode[item * a.nseg + seg_s];
+        f16 mv = (f16)0.f;
+        const int key = kt_s * KT + tid;
+        if (mode != ME_SEG_PLAIN && key < a.nk) {
+          const int plane = mode == ME_SEG_DUAL_CUR ? h : (h > 0 ? h - 1 : 0);
+          mv = Mk[(long)plane * a.nk + key];
+        }
+        sMb[ti & (NBUF - 1)][tid] = mv;
       }
-      sM[tid] = mv;
+      if (++kt_s == ntk) {
+        kt_s = 0;
+        ++seg_s;
+      }
     }
   };
 
@@ -151,6 +191,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 
   __syncthreads();  // LDS zero-fill visible before the first stage is written
   if (T > 0) {
+    seg_base();
     gload(0);
     sstore(0);
     if (T > 1) gload(1);
@@ -159,13 +200,12 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   // One KV tile, specialised at compile time on the segment mode and on "tile fully inside nk": the mode / tail
   // tests are wave-uniform, and leaving them as run-time selects made hipcc if-convert BOTH softmax variants and
   // 32 tail compares into every tile (11 VALU per MFMA).  A scalar (readfirstlane) dispatch picks the body.
-  auto tile = [&](auto mode_c, auto full_c, int ti) {
+  auto tile = [&](auto mode_c, auto full_c, int ti, int kt) {
     constexpr int MODE = decltype(mode_c)::value;
     constexpr bool FULL = decltype(full_c)::value;
     const f16* sK = sKb[ti & (NBUF - 1)];
     const f16* sVt = sVtb[ti & (NBUF - 1)];
     const f16* sM = sMb[ti & (NBUF - 1)];
-    const int seg = ti / ntk, kt = ti - seg * ntk;
     const int kbase = kt * KT + g * 4;  // + t*16 + r
 
     // ---- S^T = K Q^T ----
@@ -297,24 +337,34 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   using BT = std::integral_constant<bool, true>;
   using BF = std::integral_constant<bool, false>;
 
-  for (int ti = 0; ti < T; ++ti) {
-    const int seg = ti / ntk, kt = ti - seg * ntk;
+  // One loop per (segment mode, full / tail) so that the accumulators stay in place between tiles: a single
+  // loop dispatching on the mode made the compiler copy all of o[] on every tile to merge the variants.
+  int ti = 0;
+  auto run = [&](auto mode_c, auto full_c, int kt0, int count) {
+    for (int n = 0; n < count; ++n, ++ti) {
+      tile(mode_c, full_c, ti, kt0 + n);
+      // stage tile ti+1 into the other buffer (every wave finished reading it one barrier ago), prefetch ti+2
+      if (ti + 1 < T) {
+        if (NBUF == 1) __syncthreads();  // single stage: everyone must be done reading it first
+        sstore(ti + 1);
+        if (ti + 2 < T) gload(ti + 2);
+      }
+      __syncthreads();
+    }
+  };
+  const int nfull = a.nk / KT;
+  for (int seg = 0; seg < nvalid; ++seg) {
     const int mode = __builtin_amdgcn_readfirstlane(a.seg_mode[item * a.nseg + seg]);
-    const bool full = (kt + 1) * KT <= a.nk;
     if (mode == ME_SEG_PLAIN) {
-      if (full) tile(IC0{}, BT{}, ti); else tile(IC0{}, BF{}, ti);
+      run(IC0{}, BT{}, 0, nfull);
+      run(IC0{}, BF{}, nfull, ntk - nfull);
     } else if (mode == ME_SEG_DUAL_BIN) {
-      if (full) tile(IC3{}, BT{}, ti); else tile(IC3{}, BF{}, ti);
+      run(IC3{}, BT{}, 0, nfull);
+      run(IC3{}, BF{}, nfull, ntk - nfull);
     } else {
-      if constexpr (GD) tile(ICG{}, BF{}, ti);
+      if constexpr (GD) run(ICG{}, BF{}, 0, ntk);
+      else ti += ntk;   // unreachable: me_attn routes general masks to the GD instantiation
     }
-    // stage tile ti+1 into the other buffer (every wave finished reading it one barrier ago), prefetch ti+2
-    if (ti + 1 < T) {
-      if (NBUF == 1) __syncthreads();  // single stage: everyone must be done reading it first
-      sstore(ti + 1);
-      if (ti + 2 < T) gload(ti + 2);
-    }
-    __syncthreads();
   }
 
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] / l ----

@@ -85,8 +85,9 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
 // lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
 // sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
-template <int NT, int MT, int WN>
-__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wm, int wn, int lane, f16* sC, int CLD) {
+// rowfn(i) = global output row of this lane's column in m tile i, or -1 (tail); m0 only addresses the sC tile.
+template <int NT, int MT, int WN, class RowFn>
+__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
@@ -95,8 +96,8 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
   const int nq = (lane >> 4) * 4;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-    if (m >= a.M) continue;
+    const int m = rowfn(i);
+    if (m < 0) continue;
     const f16* rv = rowvec ? rowvec + (long)(m / a.rows_per_vec) * a.ldrv : nullptr;
     if (!a.geglu) {
 #pragma unroll
@@ -178,13 +179,14 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
 
 // BM = 128 (4 waves, 2 blocks/CU) or 256 (8 waves, 1 block/CU).  The 256 x 320 tile halves the L2 -> LDS fill per
 // FLOP (142 vs 71 flop/byte of staged operands): the 128-row tiles measured fill-bound at ~8 TB/s for K <= 640.
-template <int BM, int BN, int STAGE>
-__global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
-  constexpr int NTHR = BM * 2;    // 64 rows x 2 wave columns per 64 threads
+template <int BM, int BN, int STAGE, int WM = 64>
+__global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(const me_gemm_args a) {
+  constexpr int NTHR = BM / WM * 128;  // WM rows x 2 wave columns per 64 threads
   constexpr int RSTR = NTHR / 8;  // row stride between a thread's staged rows
   constexpr int WN = BN / 2;      // per-wave N extent
   constexpr int NT = WN / 16;     // 16-wide n tiles per wave
-  constexpr int MT = 4;           // 16-wide m tiles per wave (64 rows)
+  constexpr int MT = WM / 16;     // 16-wide m tiles per wave
+  constexpr int XROWS = BM / RSTR;  // X rows staged per thread
   constexpr int WROWS = BN / RSTR;  // W rows staged per thread
   constexpr int LD = STAGE == STAGE_GLDS ? BK : BK + 8;  // LDS row stride in halves
 
@@ -223,17 +225,17 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
     scol = (tid & 7) * 8;
   }
 
-  RowInfo rinfo[4];
+  RowInfo rinfo[XROWS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rinfo[i] = make_row(a, m0 + srow + RSTR * i);
+  for (int i = 0; i < XROWS; ++i) rinfo[i] = make_row(a, m0 + srow + RSTR * i);
 
-  long xoff[4];  // element offset of the source row for the current tap, or -1
+  long xoff[XROWS];  // element offset of the source row for the current tap, or -1
   int cur_tap = -1;
   auto set_tap = [&](int tap) {
     if (tap != cur_tap) {
       cur_tap = tap;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XROWS; ++i) {
         const int s = src_row(a, rinfo[i], tap);
         xoff[i] = s < 0 ? -1L : (long)s * a.ldx;
       }
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
       f16x8 fx[MT], fw[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
-        const int row = wm * 64 + i * 16 + frow;
+        const int row = wm * WM + i * 16 + frow;
         const int ch = STAGE == STAGE_GLDS ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
         fx[i] = *reinterpret_cast<const f16x8*>(bx + row * LD + ch * 8);
       }
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
       char* dx = reinterpret_cast<char*>(sX + buf * BM * LD) + wave * 1024;
       char* dw = reinterpret_cast<char*>(sW + buf * BN * LD) + wave * 1024;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < XROWS; ++i) {
         const f16* src = (kok && xoff[i] >= 0) ? X + xoff[i] + c : zsrc;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dx + i * (RSTR * 128)), 16, 0, 0);
       }
@@ -306,14 +308,14 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
       __syncthreads();  // LDS-DMA pending -> the compiler drains vmcnt(0) here: next slab landed, this slab free
     }
   } else {
-    uint4 rx[4], rw[WROWS];
+    uint4 rx[XROWS], rw[WROWS];
     auto gload = [&](int it) {
       const int tap = it / nkc;
       const int c = (it - tap * nkc) * BK + scol;
       set_tap(tap);
       const bool kok = c < a.K;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
+      for (int i = 0; i < XROWS; ++i) rx[i] = (kok && xoff[i] >= 0) ? ldg128(X + xoff[i] + c) : zero128();
 #pragma unroll
       for (int i = 0; i < WROWS; ++i) {
         const int n = n0 + srow + RSTR * i;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
       f16* dx = sX + buf * BM * LD;
       f16* dw = sW + buf * BN * LD;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(dx + (srow + RSTR * i) * LD + scol) = rx[i];
+      for (int i = 0; i < XROWS; ++i) *reinterpret_cast<uint4*>(dx + (srow + RSTR * i) * LD + scol) = rx[i];
 #pragma unroll
       for (int i = 0; i < WROWS; ++i) *reinterpret_cast<uint4*>(dw + (srow + RSTR * i) * LD + scol) = rw[i];
     };
@@ -345,14 +347,18 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
   const int Nout = a.geglu ? a.N / 2 : a.N;
   constexpr bool CFITS = (size_t)BM * (BN + 8) <= (size_t)2 * (BM + BN) * LD;   // the C tile fits the staging buffers
   const bool wide_store = CFITS && (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);
+  auto rowfn = [&](int i) {
+    const int m = m0 + wm * WM + i * 16 + (lane & 15);
+    return m < a.M ? m : -1;
+  };
   if (!wide_store) {
-    epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane, nullptr, 0);
+    epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, nullptr, 0);
     return;
   }
   // the K loop ended on a barrier: the staging buffers are free and become the C tile
   constexpr int CLD = BN + 8;
   f16* sC = reinterpret_cast<f16*>(smem);
-  epilogue<NT, MT, WN>(a, acc, m0, n0, wm, wn, lane, sC, CLD);
+  epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
   __syncthreads();
   f16* C = reinterpret_cast<f16*>(a.C);
   const int vpr = ncols / 8;                           // 16-byte vectors per row
@@ -362,6 +368,132 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm_kernel(const me_gemm_args a) {
     const int m = m0 + row, n = nb0 + c8;
     if (m < a.M && n < Nout) *reinterpret_cast<uint4*>(C + (long)m * a.ldc + n) = *reinterpret_cast<const uint4*>(sC + row * CLD + c8);
   }
+}
+
+// ---- 3x3 / stride-1 convolution with an LDS halo tile ----
+// The gather kernel above re-stages every activation row once per tap (9 x 32 KB of X per 64-channel slab beside
+// 9 x 40 KB of W) and is bound by the L2 -> LDS fill (~14 B/clk/CU), not by MFMA.  Here one block owns a 16 x 16
+// output patch of one image x 320 output channels: the 18 x 18 input patch (halo included) of a 64-channel slab
+// is DMA'd ONCE (41 KB) and all nine taps read their operand-B fragments from it at shifted pixel offsets, so
+// only the weight slab changes per tap -> 45 KB instead of 72 KB staged per 256 x 320 x 64 MACs.
+// Each MFMA m tile is one patch row (16 consecutive pixels = 16 consecutive halo rows at a fixed tap), so the
+// usual (row >> 1) & 7 chunk swizzle keeps the fragment reads conflict-free.
+constexpr int HALO_W = 18, HALO_ROWS = HALO_W * HALO_W, HALO_INSTR = (HALO_ROWS + 7) / 8;
+constexpr int HALO_BYTES = HALO_INSTR * 1024, CONVW_BYTES = 320 * 128;
+
+__global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a) {
+  constexpr int BN = 320, WN = 160, NT = 10, MT = 4;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sH = smem;                 // [HALO_INSTR * 8 halo pixels][64 ch], single buffer
+  char* sWt = smem + HALO_BYTES;   // [2][320][64 ch]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nbn = a.N / BN;
+  const int tx_n = a.Win >> 4, ppi = tx_n * (a.Hin >> 4);
+  const int hw = a.Hin * a.Win;
+  const int w = xcd_remap(blockIdx.x, (a.M / hw) * ppi * nbn);
+  const int tile_n = w % nbn, patch = w / nbn;
+  const int img = patch / ppi, pr = patch - img * ppi;
+  const int ty = pr / tx_n, tx = pr - ty * tx_n;
+  const int y0 = ty * 16, x0 = tx * 16, n0 = tile_n * BN;
+
+  const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
+  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
+  const f16* zsrc = reinterpret_cast<const f16*>(&g_zero16);
+
+  // DMA lane mapping as in gemm_kernel: instruction q = wave + 8*i covers LDS rows 8q..8q+7
+  const int srow = wave * 8 + (lane >> 3);
+  const int scol = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  int hsrc[6];  // source row of halo pixel srow + 64*i, -1 = zero padding
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int hr = srow + 64 * i;
+    int s = -1;
+    if (hr < HALO_ROWS) {
+      const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) s = img * hw + iy * a.Win + ix;
+    }
+    hsrc[i] = s;
+  }
+  auto load_halo = [&](int kc) {
+    const int c = kc * BK + scol;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (wave + 8 * i < HALO_INSTR) {
+        const f16* src = hsrc[i] >= 0 ? X + (long)hsrc[i] * a.ldx + c : zsrc;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
+    }
+  };
+  const f16* wbase = W + ((long)(n0 + srow) * 9) * a.K + scol;
+  auto load_w = [&](int tap, int kc, int buf) {
+    const f16* src = wbase + (long)tap * a.K + kc * BK;
+    char* dw = sWt + buf * CONVW_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (long)i * 64 * 9 * a.K), (lptr_t)(dw + i * 8192), 16, 0, 0);
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fg = lane >> 4;
+  auto compute = [&](int tap, int buf) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const char* bw = sWt + buf * CONVW_BYTES;
+    const int hbase = (wm * 4 + ky) * HALO_W + kx + frow;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      f16x8 fx[MT], fw[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int row = hbase + i * HALO_W;
+        fx[i] = *reinterpret_cast<const f16x8*>(sH + row * 128 + (((ks * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * WN + j * 16 + frow;
+        fw[j] = *reinterpret_cast<const f16x8*>(bw + row * 128 + (((ks * 4 + fg) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = mfma16(fw[j], fx[i], acc[j][i]);
+    }
+  };
+
+  const int nkc = a.K / BK;
+  load_halo(0);
+  load_w(0, 0, 0);
+  __syncthreads();
+  int it = 0;
+  for (int kc = 0; kc < nkc; ++kc) {
+    for (int tap = 0; tap < 9; ++tap, ++it) {
+      const int buf = it & 1;
+      const bool last_tap = tap == 8;
+      if (!last_tap) load_w(tap + 1, kc, buf ^ 1);
+      else if (kc + 1 < nkc) load_w(0, kc + 1, buf ^ 1);
+      compute(tap, buf);
+      if (last_tap && kc + 1 < nkc) {
+        __syncthreads();       // every wave is done with this slab's halo tile
+        load_halo(kc + 1);
+      }
+      __syncthreads();         // drains the DMAs: next weight slab (and halo tile) landed, this weight buffer free
+    }
+  }
+
+  auto rowfn = [&](int i) { return img * hw + (y0 + wm * 4 + i) * a.Win + x0 + (lane & 15); };
+  epilogue<NT, MT, WN>(a, acc, rowfn, 0, n0, wn, lane, nullptr, 0);
 }
 
 int stage_impl() {
@@ -382,6 +514,33 @@ long big_min_blocks() {   // ME_GEMM_BIG_MIN: smallest grid (in 256x320 blocks) 
   return v;
 }
 
+long halo_min_blocks() {   // ME_CONV_HALO_MIN: smallest grid (16x16-pixel patches x 320-channel tiles) that takes the halo kernel
+  static long v = -1;
+  if (v < 0) {
+    const char* e = getenv("ME_CONV_HALO_MIN");
+    v = e ? atol(e) : 512;
+  }
+  return v;
+}
+
+bool conv_halo() {   // ME_CONV_HALO=0 sends 3x3 convolutions back to the gather kernel
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ME_CONV_HALO");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
+bool wave128() {   // ME_GEMM_WAVE128=1: 4 waves x (128 x 160) per 256 x 320 tile, one wave per SIMD
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ME_GEMM_WAVE128");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  return on == 1;
+}
+
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -395,12 +554,12 @@ bool tile160() {
 
 extern "C" void me_set_error(const char* msg);
 
-template <int BM, int BN, int STAGE>
+template <int BM, int BN, int STAGE, int WM = 64>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * (STAGE == STAGE_GLDS ? BK : BK + 8) * sizeof(f16);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, STAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, STAGE, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return ME_EHIP;
     }
@@ -408,7 +567,27 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   }
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE>), dim3(nbm * nbn), dim3(BM * 2), lds, st, *a);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn), dim3(BM / WM * 128), lds, st, *a);
+  if (hipGetLastError() != hipSuccess) {
+    me_set_error("me_gemm: kernel launch failed");
+    return ME_EHIP;
+  }
+  return ME_OK;
+}
+
+static int launch_conv_halo(const me_gemm_args* a, hipStream_t st) {
+  const int lds = HALO_BYTES + 2 * CONVW_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return ME_EHIP;
+    }
+    attr_set = true;
+  }
+  const long blocks = (long)(a->M / 256) * (a->N / 320);
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(conv3_halo_kernel, dim3((unsigned)blocks), dim3(512), lds, st, *a);
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");
     return ME_EHIP;
@@ -444,7 +623,11 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (stage_impl() == STAGE_GLDS) {
     // big tile when the grid still fills the chip: every model width is a multiple of 320
     const long big_blocks = (long)((a->M + 255) / 256) * (a->N / 320);
-    if (a->N % 320 == 0 && big_blocks >= big_min_blocks()) return launch_gemm<256, 320, STAGE_GLDS>(a, st);
+    if (a->gather == ME_GATHER_CONV3 && a->stride == 1 && a->ups == 0 && a->N % 320 == 0 && a->K % 64 == 0 && a->Hin % 16 == 0 &&
+        a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
+      return launch_conv_halo(a, st);
+    if (a->N % 320 == 0 && big_blocks >= big_min_blocks())
+      return wave128() ? launch_gemm<256, 320, STAGE_GLDS, 128>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
     if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<128, 160, STAGE_GLDS>(a, st);
     return wide ? launch_gemm<128, 128, STAGE_GLDS>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
   }

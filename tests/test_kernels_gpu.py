@@ -105,6 +105,21 @@ def test_gemm_conv3x3(ops, Cin, Cout, H, W, stride, ups, nimg):
     check(got, emu.gemm(x, w, M=nimg * ho * wo, bias=bias, conv=conv), f"conv {Cin}->{Cout} {H}x{W} s{stride} u{ups}")
 
 
+@pytest.mark.parametrize("Cin,Cout,H,W,nimg", [(128, 320, 64, 48, 43), (64, 640, 32, 32, 64), (192, 320, 16, 16, 520)])
+def test_gemm_conv3x3_halo_tile(ops, Cin, Cout, H, W, nimg):
+    """Grids of >= 512 (16x16 patch, 320 channel) tiles take the LDS-halo kernel; full epilogue (bias, per-image
+    row vector, residual, SiLU) and image-border / patch-border taps."""
+    assert nimg * (H // 16) * (W // 16) * (Cout // 320) >= 512
+    M = nimg * H * W
+    x = rnd(M, Cin, seed=1)
+    w = rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
+    bias, res, rowvec = rnd(Cout, seed=3), rnd(M, Cout, seed=4), rnd(nimg, Cout, seed=5)
+    conv = (H, W, H, W, 1, 0)
+    got = ops.gemm(cu(x), cu(w), M=M, bias=cu(bias), conv=conv, rowvec=cu(rowvec), rows_per_vec=H * W, res=cu(res), act=2)
+    want = emu.gemm(x, w, M=M, bias=bias, conv=conv, rowvec=rowvec, rows_per_vec=H * W, res=res, act=2)
+    check(got, want, f"halo conv {Cin}->{Cout} {H}x{W} x{nimg}")
+
+
 @pytest.mark.parametrize("C,frames,npix,chunk,nb", [(320, 16, 4, 16, 2), (320, 16, 9, 8, 2), (640, 24, 4, 8, 1), (1280, 8, 1, 8, 4)])
 def test_gemm_tconv(ops, C, frames, npix, chunk, nb):
     x = rnd(nb * frames * npix, C, seed=1)

@@ -41,6 +41,12 @@ def bench_gemm():
                  (f"L{li} conv3x3", M, C, C, (hw, hw, hw, hw, 1, 0), None, False), (f"L{li} tconv", M, C, C, None, (f, hw * hw, f), False)]
     rows += [("L0 conv 960->320", B * f * 4096, 320, 960, (64, 64, 64, 64, 1, 0), None, False),
              ("L1 conv 1920->640", B * f * 1024, 640, 1920, (32, 32, 32, 32, 1, 0), None, False),
+             ("L0 conv 640->320", B * f * 4096, 320, 640, (64, 64, 64, 64, 1, 0), None, False),
+             ("L1 conv 1280->640", B * f * 1024, 640, 1280, (32, 32, 32, 32, 1, 0), None, False),
+             ("L2 conv 2560->1280", B * f * 256, 1280, 2560, (16, 16, 16, 16, 1, 0), None, False),
+             ("L1->L0 ups conv 640", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, False),
+             ("L2->L1 ups conv 1280", B * f * 1024, 1280, 1280, (16, 16, 32, 32, 1, 1), None, False),
+             ("cn L0 conv3x3", 2 * f * 4096, 320, 320, (64, 64, 64, 64, 1, 0), None, False),
              ("L0 conv_out 320->4", B * f * 4096, 4, 320, (64, 64, 64, 64, 1, 0), None, False),
              ("cond 16->16 @512", 48 * 512 * 512, 16, 16, (512, 512, 512, 512, 1, 0), None, False),
              ("cond 96->256 s2", 48 * 64 * 64, 256, 96, (128, 128, 64, 64, 2, 0), None, False)]
