@@ -63,10 +63,10 @@ def bench_gemm():
     print("sum ms", round(tot, 2))
 
 
-def bench_attn():
+def bench_attn(only_first=False):
     B, f = 4, 24
     print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
-    for name, dh, N, seg, items, mask in [("L0 prev|cur", 40, 4096, "pc", B * f, False), ("L0 edited", 40, 4096, "ed", B * f, True),
+    for name, dh, N, seg, items, mask in [("L0 prev|cur", 40, 4096, "pc", B * f, False)] if only_first else [("L0 prev|cur", 40, 4096, "pc", B * f, False), ("L0 edited", 40, 4096, "ed", B * f, True),
                                           ("L0 self (cn)", 40, 4096, "self", 2 * f, False), ("L0 cross 77", 40, 4096, "cross", B * f, False),
                                           ("L1 prev|cur", 80, 1024, "pc", B * f, False), ("L1 edited", 80, 1024, "ed", B * f, True),
                                           ("L2 prev|cur", 160, 256, "pc", B * f, False)]:
@@ -108,5 +108,7 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+    if "attn1" in what:
+        bench_attn(True)
     if "misc" in what:
         bench_misc()
