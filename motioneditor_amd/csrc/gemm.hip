@@ -86,94 +86,131 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
 // sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
 // rowfn(i) = global output row of this lane's column in m tile i, or -1 (tail); m0 only addresses the sC tile.
-template <int NT, int MT, int WN, class RowFn>
-__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
+//
+// F >= 0 fixes the set of optional terms at compile time (bit 0 bias, 1 row vector, 2 residual, 3 second residual;
+// no activation): with the wave-uniform tests evaluated inside the 40 (i, j) iterations, each iteration was a chain
+// of scalar branches with a load -> wait pair behind every one, and the epilogue of a 256 x 320 tile cost as much
+// as four K slabs (~10 us of a 27 us tile at K = 320).  The combinations the model's large GEMMs use get a
+// specialised body whose loads are issued row by row, back to back; F < 0 is the generic run-time version.
+template <int F, int NT, int MT, int WN, class RowFn>
+__device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
   const f16* res2 = reinterpret_cast<const f16*>(a.res2);
   f16* C = reinterpret_cast<f16*>(a.C);
-  const int nq = (lane >> 4) * 4;
+  const bool has_bias = F >= 0 ? (F & 1) != 0 : bias != nullptr;
+  const bool has_rv = F >= 0 ? (F & 2) != 0 : rowvec != nullptr;
+  const bool has_res = F >= 0 ? (F & 4) != 0 : res != nullptr;
+  const bool has_res2 = F >= 0 ? (F & 8) != 0 : res2 != nullptr;
+  const int act = F >= 0 ? 0 : a.act;
+  const int nb = n0 + wn * WN + (lane >> 4) * 4;   // first column of n tile j is nb + 16 j
+  const uint2 z2 = make_uint2(0u, 0u);
+  U64 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j].u = (has_bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : z2;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = rowfn(i);
     if (m < 0) continue;
-    const f16* rv = rowvec ? rowvec + (long)(m / a.rows_per_vec) * a.ldrv : nullptr;
-    if (!a.geglu) {
+    U64 rv[NT], r1[NT], r2[NT];
+    if (has_rv) {
+      const f16* p = rowvec + (long)(m / a.rows_per_vec) * a.ldrv + nb;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = n0 + wn * WN + j * 16 + nq;
-        if (n >= a.N) continue;
-        float v[4];
+      for (int j = 0; j < NT; ++j) rv[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+    }
+    if (has_res) {
+      const f16* p = res + (long)m * a.ldr + nb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
-        if (bias) {
-          U64 b;
-          b.u = *reinterpret_cast<const uint2*>(bias + n);
+      for (int j = 0; j < NT; ++j) r1[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+    }
+    if (has_res2) {
+      const f16* p = res2 + (long)m * a.ldr2 + nb;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-        }
-        if (rv) {
-          U64 b;
-          b.u = *reinterpret_cast<const uint2*>(rv + n);
+      for (int j = 0; j < NT; ++j) r2[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+    }
+    f16* crow = C + (long)m * a.ldc + nb;                 // + 16 j
+    f16* lrow = sC + (m - m0) * CLD + (nb - n0);          // never step below the LDS tile: the address is 32-bit
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-        }
-        if (a.act == 1) {
+    for (int j = 0; j < NT; ++j) {
+      const int n = nb + 16 * j;
+      if (n >= a.N) continue;
+      float v[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        } else if (a.act == 2) {
+      for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
+      if (has_bias) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-        }
-        if (res) {
-          U64 b;
-          b.u = *reinterpret_cast<const uint2*>(res + (long)m * a.ldr + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-        }
-        if (res2) {
-          U64 b;
-          b.u = *reinterpret_cast<const uint2*>(res2 + (long)m * a.ldr2 + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-        }
-        U64 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o.e[r] = (f16)v[r];
-        if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (n - n0)) = o.u;
-        else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
+        for (int r = 0; r < 4; ++r) v[r] += (float)bv[j].e[r];
       }
-    } else {
-      // packed rows: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns
+      if (has_rv) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[j].e[r];
+      }
+      if (act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+      } else if (act == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (has_res) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)r1[j].e[r];
+      }
+      if (has_res2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)r2[j].e[r];
+      }
+      union { f16x2 h[2]; uint2 u; } o;
+      o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
+      o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+      if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o.u;
+      else *reinterpret_cast<uint2*>(crow + 16 * j) = o.u;
+    }
+  }
+}
+
+template <int NT, int MT, int WN, class RowFn>
+__device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
+  if (a.geglu) {
+    // packed rows: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns
+    const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+    f16* C = reinterpret_cast<f16*>(a.C);
+    const int nb = n0 + wn * WN + (lane >> 4) * 4;
+    const int nob = (n0 + wn * WN) / 2 + (lane >> 4) * 4;
+    U64 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j].u = (bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : make_uint2(0u, 0u);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = rowfn(i);
+      if (m < 0) continue;
 #pragma unroll
       for (int jj = 0; jj < NT / 2; ++jj) {
-        const int np = n0 + wn * WN + jj * 32 + nq;  // packed row of the value part
-        if (np >= a.N) continue;
-        const int no = (n0 + wn * WN) / 2 + jj * 16 + nq;  // output column
-        float va[4], vg[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          va[r] = acc[2 * jj][i][r] * a.alpha;
-          vg[r] = acc[2 * jj + 1][i][r] * a.alpha;
-        }
-        if (bias) {
-          U64 b, g;
-          b.u = *reinterpret_cast<const uint2*>(bias + np);
-          g.u = *reinterpret_cast<const uint2*>(bias + np + 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            va[r] += (float)b.e[r];
-            vg[r] += (float)g.e[r];
-          }
-        }
+        if (nb + 32 * jj >= a.N) continue;
+        const int no = nob + 16 * jj;  // output column
         U64 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o.e[r] = (f16)(va[r] * gelu_erf_fast(vg[r]));
+        for (int r = 0; r < 4; ++r) {
+          const float va = acc[2 * jj][i][r] * a.alpha + (float)bv[2 * jj].e[r];
+          const float vg = acc[2 * jj + 1][i][r] * a.alpha + (float)bv[2 * jj + 1].e[r];
+          o.e[r] = (f16)(va * gelu_erf_fast(vg));
+        }
         if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
         else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
       }
     }
+    return;
+  }
+  const int f = (a.bias ? 1 : 0) | (a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0);
+  if (a.act != 0) return epilogue_rows<-1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
+  switch (f) {   // wave-uniform
+    case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // q | k | v projections
+    case 1: return epilogue_rows<1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // biased linear / conv
+    case 3: return epilogue_rows<3, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // resnet conv1 + time embedding
+    case 5: return epilogue_rows<5, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // out projection / ff2 / conv2 / tconv + residual
+    case 13: return epilogue_rows<13, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);  // + second residual
+    default: return epilogue_rows<-1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
   }
 }
 

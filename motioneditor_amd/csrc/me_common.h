@@ -35,7 +35,8 @@ union U64 {
 __device__ __forceinline__ uint4 ldg128(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint4 zero128() { return make_uint4(0u, 0u, 0u, 0u); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with hardware exp2 / rcp (1 ulp each, far below fp16 resolution) instead of the IEEE division sequence
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

@@ -1,9 +1,9 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "attn or attention" > gpurun_out/t_attn.log 2>&1
-echo "tests rc=$?" >> gpurun_out/t_attn.log
-tail -3 gpurun_out/t_attn.log
-for v in 0 2 0; do
-ME_ATTN_VARIANT=$v timeout 300 python tools/kbench.py attn 2>&1 | grep "L0 \|L1 \|L2 "
-done
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu > gpurun_out/t_all.log 2>&1
+tail -3 gpurun_out/t_all.log
+ME_GEMM_BIG_MIN=1 ME_CONV_HALO=0 timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/t_pers.log 2>&1
+tail -2 gpurun_out/t_pers.log
+timeout 300 python tools/kbench.py gemmk 2>&1 | tail -11
+timeout 300 python tools/kbench.py gemm > gpurun_out/kb_ep.log 2>&1

@@ -63,6 +63,32 @@ def bench_gemm():
     print("sum ms", round(tot, 2))
 
 
+def bench_gemm_cached():
+    """Same dense shapes with every X row aliased to row 0 (stride-0 view): X comes from L2, only the output streams.
+    The gap to the normal run = what HBM latency / bandwidth on the activation stream costs."""
+    B, f = 4, 24
+    print(f"{'gemm':24s} {'M':>8s} {'N':>6s} {'K':>6s} {'ms':>8s} {'ms X-cached':>12s}")
+    for name, M, N, K in [("L0 qkv", B * f * 4096, 960, 320), ("L0 out", B * f * 4096, 320, 320), ("L0 ff2", B * f * 4096, 320, 1280),
+                          ("L1 qkv", B * f * 1024, 1920, 640), ("L1 ff2", B * f * 1024, 640, 2560), ("L2 ff2", B * f * 256, 1280, 5120)]:
+        x, w = rnd(M, K), rnd(N, 1, K)
+        xc = x[:256].repeat(1, 1).as_strided((M, K), (0, 1))
+        ms = timeit(lambda: ops.gemm(x, w))
+        msc = timeit(lambda: ops.gemm(xc, w))
+        print(f"{name:24s} {M:8d} {N:6d} {K:6d} {ms:8.3f} {msc:12.3f}")
+
+
+def bench_gemm_ksweep():
+    """Fixed M, N; K sweep: slope = time per 64-wide K slab, intercept = per-tile prologue + epilogue."""
+    M = 4 * 24 * 4096
+    print(f"{'N':>6s} {'K':>6s} {'ms':>8s} {'us/tile':>8s}")
+    for N in (320, 960):
+        for K in (64, 128, 320, 640, 1280):
+            x, w = rnd(M, K), rnd(N, 1, K)
+            ms = timeit(lambda: ops.gemm(x, w))
+            tiles = (M // 256) * (N // 320)
+            print(f"{N:6d} {K:6d} {ms:8.3f} {ms * 1e3 * 256 / tiles:8.2f}")
+
+
 def bench_attn(only_first=False):
     B, f = 4, 24
     print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
@@ -108,6 +134,10 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+    if "gemmk" in what:
+        bench_gemm_ksweep()
+    if "gemmc" in what:
+        bench_gemm_cached()
     if "attn1" in what:
         bench_attn(True)
     if "misc" in what:
