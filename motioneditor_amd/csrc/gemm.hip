@@ -87,130 +87,190 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
 // rowfn(i) = global output row of this lane's column in m tile i, or -1 (tail); m0 only addresses the sC tile.
 //
-// F >= 0 fixes the set of optional terms at compile time (bit 0 bias, 1 row vector, 2 residual, 3 second residual;
-// no activation): with the wave-uniform tests evaluated inside the 40 (i, j) iterations, each iteration was a chain
-// of scalar branches with a load -> wait pair behind every one, and the epilogue of a 256 x 320 tile cost as much
-// as four K slabs (~10 us of a 27 us tile at K = 320).  The combinations the model's large GEMMs use get a
-// specialised body whose loads are issued row by row, back to back; F < 0 is the generic run-time version.
+// F fixes the set of optional terms at compile time (bit 0 bias, 1 row vector, 2 residual, 3 second residual; no
+// activation): with the wave-uniform tests evaluated inside the 40 (i, j) iterations, each iteration was a chain of
+// scalar branches with a load -> wait pair behind every one, and the epilogue of a 256 x 320 tile cost as much as
+// four K slabs (~10 us of a 27 us tile at K = 320).  The combinations the model's large GEMMs use get a branch-free
+// body that fetches the row-dependent terms for two 16-row groups at a time (two memory round trips per tile,
+// 40 registers per term); everything else takes epilogue_generic.
 template <int F, int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
+  static_assert(F >= 0 && MT % 2 == 0, "specialised epilogue");
   const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
   const f16* res2 = reinterpret_cast<const f16*>(a.res2);
   f16* C = reinterpret_cast<f16*>(a.C);
-  const bool has_bias = F >= 0 ? (F & 1) != 0 : bias != nullptr;
-  const bool has_rv = F >= 0 ? (F & 2) != 0 : rowvec != nullptr;
-  const bool has_res = F >= 0 ? (F & 4) != 0 : res != nullptr;
-  const bool has_res2 = F >= 0 ? (F & 8) != 0 : res2 != nullptr;
-  const int act = F >= 0 ? 0 : a.act;
+  constexpr bool has_bias = (F & 1) != 0, has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
   const int nb = n0 + wn * WN + (lane >> 4) * 4;   // first column of n tile j is nb + 16 j
   const uint2 z2 = make_uint2(0u, 0u);
-  U64 bv[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bv[j].u = (has_bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : z2;
+  for (int i0 = 0; i0 < MT; i0 += 2) {
+    int m[2];
+    U64 rv[2][NT], r1[2][NT], r2[2][NT];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      m[ii] = rowfn(i0 + ii);
+      const long mm = m[ii] < 0 ? 0 : m[ii];
+      if constexpr (has_rv) {
+        const f16* p = rowvec + (mm / a.rows_per_vec) * a.ldrv + nb;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+      }
+      if constexpr (has_res) {
+        const f16* p = res + mm * a.ldr + nb;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) r1[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+      }
+      if constexpr (has_res2) {
+        const f16* p = res2 + mm * a.ldr2 + nb;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) r2[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
+      }
+    }
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      if (m[ii] < 0) continue;
+      const int i = i0 + ii;
+      f16* crow = C + (long)m[ii] * a.ldc + nb;                // + 16 j
+      f16* lrow = sC + (m[ii] - m0) * CLD + (nb - n0);         // never step below the LDS tile: the address is 32-bit
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = nb + 16 * j;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
+        if constexpr (has_bias) {   // cache-resident: reloaded per row instead of held in 20 registers
+          U64 b;
+          b.u = *reinterpret_cast<const uint2*>(bias + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+        }
+        if constexpr (has_rv) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[ii][j].e[r];
+        }
+        if constexpr (has_res) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r1[ii][j].e[r];
+        }
+        if constexpr (has_res2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)r2[ii][j].e[r];
+        }
+        union { f16x2 h[2]; uint2 u; } o;
+        o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
+        o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+        if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o.u;
+        else *reinterpret_cast<uint2*>(crow + 16 * j) = o.u;
+      }
+    }
+  }
+}
+
+// any combination of terms, tested element by element (activations, rare combinations)
+template <int NT, int MT, int WN, class RowFn>
+__device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
+  const f16* res = reinterpret_cast<const f16*>(a.res);
+  const f16* res2 = reinterpret_cast<const f16*>(a.res2);
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const int nq = (lane >> 4) * 4;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = rowfn(i);
     if (m < 0) continue;
-    U64 rv[NT], r1[NT], r2[NT];
-    if (has_rv) {
-      const f16* p = rowvec + (long)(m / a.rows_per_vec) * a.ldrv + nb;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) rv[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-    }
-    if (has_res) {
-      const f16* p = res + (long)m * a.ldr + nb;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) r1[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-    }
-    if (has_res2) {
-      const f16* p = res2 + (long)m * a.ldr2 + nb;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) r2[j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-    }
-    f16* crow = C + (long)m * a.ldc + nb;                 // + 16 j
-    f16* lrow = sC + (m - m0) * CLD + (nb - n0);          // never step below the LDS tile: the address is 32-bit
+    const f16* rv = rowvec ? rowvec + (long)(m / a.rows_per_vec) * a.ldrv : nullptr;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = nb + 16 * j;
+      const int n = n0 + wn * WN + j * 16 + nq;
       if (n >= a.N) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
-      if (has_bias) {
+      if (bias) {
+        U64 b;
+        b.u = *reinterpret_cast<const uint2*>(bias + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)bv[j].e[r];
+        for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
-      if (has_rv) {
+      if (rv) {
+        U64 b;
+        b.u = *reinterpret_cast<const uint2*>(rv + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[j].e[r];
+        for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
-      if (act == 1) {
+      if (a.act == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-      } else if (act == 2) {
+      } else if (a.act == 2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
       }
-      if (has_res) {
+      if (res) {
+        U64 b;
+        b.u = *reinterpret_cast<const uint2*>(res + (long)m * a.ldr + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)r1[j].e[r];
+        for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
-      if (has_res2) {
+      if (res2) {
+        U64 b;
+        b.u = *reinterpret_cast<const uint2*>(res2 + (long)m * a.ldr2 + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)r2[j].e[r];
+        for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
-      union { f16x2 h[2]; uint2 u; } o;
-      o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
-      o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
-      if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o.u;
-      else *reinterpret_cast<uint2*>(crow + 16 * j) = o.u;
+      U64 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o.e[r] = (f16)v[r];
+      if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (n - n0)) = o.u;
+      else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
+    }
+  }
+}
+
+// GEGLU: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns (weights.py packs them so)
+template <int NT, int MT, int WN, class RowFn>
+__device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const int nb = n0 + wn * WN + (lane >> 4) * 4;
+  const int nob = (n0 + wn * WN) / 2 + (lane >> 4) * 4;
+  U64 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j].u = (bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : make_uint2(0u, 0u);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = rowfn(i);
+    if (m < 0) continue;
+#pragma unroll
+    for (int jj = 0; jj < NT / 2; ++jj) {
+      if (nb + 32 * jj >= a.N) continue;
+      const int no = nob + 16 * jj;  // output column
+      U64 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float va = acc[2 * jj][i][r] * a.alpha + (float)bv[2 * jj].e[r];
+        const float vg = acc[2 * jj + 1][i][r] * a.alpha + (float)bv[2 * jj + 1].e[r];
+        o.e[r] = (f16)(va * gelu_erf_fast(vg));
+      }
+      if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
+      else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
     }
   }
 }
 
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
-  if (a.geglu) {
-    // packed rows: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns
-    const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
-    f16* C = reinterpret_cast<f16*>(a.C);
-    const int nb = n0 + wn * WN + (lane >> 4) * 4;
-    const int nob = (n0 + wn * WN) / 2 + (lane >> 4) * 4;
-    U64 bv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) bv[j].u = (bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : make_uint2(0u, 0u);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = rowfn(i);
-      if (m < 0) continue;
-#pragma unroll
-      for (int jj = 0; jj < NT / 2; ++jj) {
-        if (nb + 32 * jj >= a.N) continue;
-        const int no = nob + 16 * jj;  // output column
-        U64 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float va = acc[2 * jj][i][r] * a.alpha + (float)bv[2 * jj].e[r];
-          const float vg = acc[2 * jj + 1][i][r] * a.alpha + (float)bv[2 * jj + 1].e[r];
-          o.e[r] = (f16)(va * gelu_erf_fast(vg));
-        }
-        if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
-        else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
-      }
-    }
-    return;
-  }
-  const int f = (a.bias ? 1 : 0) | (a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0);
-  if (a.act != 0) return epilogue_rows<-1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
+  if (a.geglu) return epilogue_geglu<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
+  const int f = a.act != 0 ? -1 : ((a.bias ? 1 : 0) | (a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0));
   switch (f) {   // wave-uniform
-    case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // q | k | v projections
-    case 1: return epilogue_rows<1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // biased linear / conv
-    case 3: return epilogue_rows<3, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // resnet conv1 + time embedding
-    case 5: return epilogue_rows<5, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // out projection / ff2 / conv2 / tconv + residual
-    case 13: return epilogue_rows<13, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);  // + second residual
-    default: return epilogue_rows<-1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
+    case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // q | k | v projections
+    case 1: return epilogue_rows<1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // biased linear / conv
+    case 3: return epilogue_rows<3, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // resnet conv1 + time embedding
+    case 5: return epilogue_rows<5, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // out projection / ff2 / conv2 / tconv + residual
+    default: return epilogue_generic<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
   }
 }
 

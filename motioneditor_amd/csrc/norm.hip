@@ -69,36 +69,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
   }
 }
 
+// y = x * A[c] + B[c] (+ SiLU) with A = rstd * gamma, B = beta - mean * rstd * gamma.  A thread owns ONE 16-byte
+// channel vector and walks down the rows of its block's chunk, so the per-channel scale / shift live in 16
+// registers and the inner loop is load - 8 FMA - store (the first version re-derived row, group, mean and rstd with
+// integer divisions and an rsqrt for every vector and ran at 2 TB/s).  blockDim.x = vectors per row handled by the
+// block (a divisor of C/8, <= 256), blockDim.y rows in flight: a wave covers whole contiguous row segments.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, const float* __restrict__ stats,
                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta, long rows,
                                                        int rows_per_group, long rows_per_group_total, int C, int ldx, int ldy, int groups,
-                                                       float eps, int silu) {
-  const int tpr = C / 8;
-  const long nvec = rows * tpr;
+                                                       float eps, int silu, int chunk) {
+  const int vc = blockIdx.y * blockDim.x + threadIdx.x;   // 16-byte vector column
   const int cg = C / groups;
   const float inv_cnt = 1.0f / ((float)rows_per_group_total * (float)cg);   // global count when frame-sharded
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nvec; idx += (long)gridDim.x * 256) {
-    const long row = idx / tpr;
-    const int vc = (int)(idx - row * tpr);
+  U128 gm, bt;
+  gm.u = ldg128(gamma + vc * 8);
+  bt.u = ldg128(beta + vc * 8);
+  float A[8], B[8];
+  int sg_prev = -1;
+  const long r0 = (long)blockIdx.x * chunk;
+  const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  for (long row = r0 + threadIdx.y; row < r1; row += blockDim.y) {
     const int sg = (int)(row / rows_per_group);
-    U128 u, gm, bt, o;
+    if (sg != sg_prev) {   // at most a few times per chunk
+      sg_prev = sg;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ge = (vc * 8 + e) / cg;
+        const float mean = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
+        const float var = fmaxf(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean * mean, 0.f);
+        A[e] = rsqrtf(var + eps) * (float)gm.e[e];
+        B[e] = (float)bt.e[e] - mean * A[e];
+      }
+    }
+    U128 u, o;
     u.u = ldg128(X + row * ldx + vc * 8);
-    gm.u = ldg128(gamma + vc * 8);
-    bt.u = ldg128(beta + vc * 8);
-    int gprev = -1;
-    float mean = 0.f, rstd = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ge = (vc * 8 + e) / cg;
-      if (ge != gprev) {
-        gprev = ge;
-        const float s = stats[((long)sg * groups + ge) * 2 + 0];
-        const float q = stats[((long)sg * groups + ge) * 2 + 1];
-        mean = s * inv_cnt;
-        const float var = fmaxf(q * inv_cnt - mean * mean, 0.f);
-        rstd = rsqrtf(var + eps);
-      }
-      float v = ((float)u.e[e] - mean) * rstd * (float)gm.e[e] + (float)bt.e[e];
+      float v = __builtin_fmaf((float)u.e[e], A[e], B[e]);
       if (silu) v = silu_f(v);
       o.e[e] = (f16)v;
     }
@@ -185,13 +192,20 @@ extern "C" int me_groupnorm_apply(const me_groupnorm_args* a, int64_t rows_per_g
   if (int rc = gn_validate(a)) return rc;
   if (rows_per_group_total < a->rows_per_group) { me_set_error("me_groupnorm_apply: total rows per group smaller than the local count"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const long nvec = (long)a->rows * (a->C / 8);
-  long blocks = (nvec + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  // block = bx vectors of a row x by rows in flight; bx = the largest divisor of C/8 that fits 256 threads
+  const int tpr = a->C / 8;
+  int ny = 1;
+  while (tpr / ny > 256 || tpr % ny) ++ny;
+  const int bx = tpr / ny, by = 256 / bx > 0 ? 256 / bx : 1;
+  // rows per block: ~16 rows per thread, but at least ~2048 blocks' worth of parallelism on big inputs
+  long chunk = (long)by * 16;
+  while (chunk > by && (a->rows + chunk - 1) / chunk * ny < 2048) chunk /= 2;
+  if (chunk < by) chunk = by;
+  const long nbx = (a->rows + chunk - 1) / chunk;
   (void)hipGetLastError();
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), reinterpret_cast<f16*>(a->Y),
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, (unsigned)ny), dim3(bx, by), 0, st, reinterpret_cast<const f16*>(a->X), reinterpret_cast<f16*>(a->Y),
                      a->stats, reinterpret_cast<const f16*>(a->gamma), reinterpret_cast<const f16*>(a->beta), (long)a->rows, a->rows_per_group,
-                     (long)rows_per_group_total, a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu);
+                     (long)rows_per_group_total, a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu, (int)chunk);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_apply: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }
