@@ -82,89 +82,89 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
   return hb < 0 ? -1 : hb + r.x0;
 }
 
+// The bias enters as the accumulators' initial value (bias / alpha, so that alpha * acc adds exactly the bias): its
+// loads happen before the K loop, when registers are free, and the epilogue never sees it.
+template <int NT, int MT, int WN>
+__device__ __forceinline__ void init_acc(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int n0, int wn, int lane) {
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  const int nb = n0 + wn * WN + (lane >> 4) * 4;
+  const float inv_alpha = bias ? 1.0f / a.alpha : 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    U64 b;
+    b.u = (bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : make_uint2(0u, 0u);
+    const f32x4 v = {(float)b.e[0] * inv_alpha, (float)b.e[1] * inv_alpha, (float)b.e[2] * inv_alpha, (float)b.e[3] * inv_alpha};
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = v;
+  }
+}
+
 // lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
 // sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
 // rowfn(i) = global output row of this lane's column in m tile i, or -1 (tail); m0 only addresses the sC tile.
 //
-// F fixes the set of optional terms at compile time (bit 0 bias, 1 row vector, 2 residual, 3 second residual; no
-// activation): with the wave-uniform tests evaluated inside the 40 (i, j) iterations, each iteration was a chain of
-// scalar branches with a load -> wait pair behind every one, and the epilogue of a 256 x 320 tile cost as much as
-// four K slabs (~10 us of a 27 us tile at K = 320).  The combinations the model's large GEMMs use get a branch-free
-// body that fetches the row-dependent terms for two 16-row groups at a time (two memory round trips per tile,
-// 40 registers per term); everything else takes epilogue_generic.
+// F fixes the set of optional terms at compile time (bit 1 row vector, 2 residual, 3 second residual; no
+// activation) for the combinations the model's large GEMMs use; everything else takes epilogue_generic.
+//   * With the wave-uniform tests evaluated inside the 40 (i, j) iterations, each iteration was a chain of scalar
+//     branches with a load -> wait pair behind every one: the epilogue of a 256 x 320 tile cost as much as four
+//     K slabs (~10 us of a 27 us tile at K = 320).
+//   * vmcnt retires in order, so a load issued after a store cannot be waited for without draining that store:
+//     every load of the epilogue is issued before its first store.
+//   * 160 accumulator registers leave no room for 80 registers of residual, so the tile is first packed to fp16
+//     (4 -> 2 registers per (i, j), the accumulators die), then each term is fetched whole and added with packed
+//     fp16 adds -- the rounding the reference's own half-precision `conv(x) + temb`, `attn(x) + x` perform.
 template <int F, int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
-  static_assert(F >= 0 && MT % 2 == 0, "specialised epilogue");
-  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  static_assert(F >= 0 && (F & 1) == 0, "specialised epilogue");
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);  // may alias C (in-place residual)
   const f16* res2 = reinterpret_cast<const f16*>(a.res2);
   f16* C = reinterpret_cast<f16*>(a.C);
-  constexpr bool has_bias = (F & 1) != 0, has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
+  constexpr bool has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
   const int nb = n0 + wn * WN + (lane >> 4) * 4;   // first column of n tile j is nb + 16 j
-  const uint2 z2 = make_uint2(0u, 0u);
+  union P4 { f16x2 h[2]; uint2 u; };
+  P4 o[MT][NT];
+  int mrow[MT];
 #pragma unroll
-  for (int i0 = 0; i0 < MT; i0 += 2) {
-    int m[2];
-    U64 rv[2][NT], r1[2][NT], r2[2][NT];
+  for (int i = 0; i < MT; ++i) {
+    mrow[i] = rowfn(i);
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      m[ii] = rowfn(i0 + ii);
-      const long mm = m[ii] < 0 ? 0 : m[ii];
-      if constexpr (has_rv) {
-        const f16* p = rowvec + (mm / a.rows_per_vec) * a.ldrv + nb;
+    for (int j = 0; j < NT; ++j) {
+      o[i][j].h[0] = __builtin_convertvector((f32x2){acc[j][i][0] * a.alpha, acc[j][i][1] * a.alpha}, f16x2);
+      o[i][j].h[1] = __builtin_convertvector((f32x2){acc[j][i][2] * a.alpha, acc[j][i][3] * a.alpha}, f16x2);
+    }
+  }
+  // o += src[row(i) * ld + column]: all 40 loads, then 80 packed adds
+  auto add_term = [&](const f16* src, auto rowoff) {
+    P4 t[MT][NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) rv[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-      }
-      if constexpr (has_res) {
-        const f16* p = res + mm * a.ldr + nb;
+    for (int i = 0; i < MT; ++i) {
+      const f16* p = src + rowoff(mrow[i] < 0 ? 0 : mrow[i]) + nb;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) r1[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-      }
-      if constexpr (has_res2) {
-        const f16* p = res2 + mm * a.ldr2 + nb;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) r2[ii][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : z2;
-      }
+      for (int j = 0; j < NT; ++j) t[i][j].u = nb + 16 * j < a.N ? *reinterpret_cast<const uint2*>(p + 16 * j) : make_uint2(0u, 0u);
     }
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-      if (m[ii] < 0) continue;
-      const int i = i0 + ii;
-      f16* crow = C + (long)m[ii] * a.ldc + nb;                // + 16 j
-      f16* lrow = sC + (m[ii] - m0) * CLD + (nb - n0);         // never step below the LDS tile: the address is 32-bit
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int n = nb + 16 * j;
-        if (n >= a.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
-        if constexpr (has_bias) {   // cache-resident: reloaded per row instead of held in 20 registers
-          U64 b;
-          b.u = *reinterpret_cast<const uint2*>(bias + n);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-        }
-        if constexpr (has_rv) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[ii][j].e[r];
-        }
-        if constexpr (has_res) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)r1[ii][j].e[r];
-        }
-        if constexpr (has_res2) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)r2[ii][j].e[r];
-        }
-        union { f16x2 h[2]; uint2 u; } o;
-        o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
-        o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
-        if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o.u;
-        else *reinterpret_cast<uint2*>(crow + 16 * j) = o.u;
+        o[i][j].h[0] += t[i][j].h[0];
+        o[i][j].h[1] += t[i][j].h[1];
       }
+  };
+  if constexpr (has_rv) add_term(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; });
+  if constexpr (has_res) add_term(res, [&](int m) { return (long)m * a.ldr; });
+  if constexpr (has_res2) add_term(res2, [&](int m) { return (long)m * a.ldr2; });
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (mrow[i] < 0) continue;
+    f16* crow = C + (long)mrow[i] * a.ldc + nb;                // + 16 j
+    f16* lrow = sC + (mrow[i] - m0) * CLD + (nb - n0);         // never step below the LDS tile: the address is 32-bit
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (nb + 16 * j >= a.N) continue;
+      if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o[i][j].u;
+      else *reinterpret_cast<uint2*>(crow + 16 * j) = o[i][j].u;
     }
   }
 }
@@ -172,7 +172,6 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
 // any combination of terms, tested element by element (activations, rare combinations)
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
-  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);
   const f16* res2 = reinterpret_cast<const f16*>(a.res2);
@@ -190,12 +189,6 @@ __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.alpha;
-      if (bias) {
-        U64 b;
-        b.u = *reinterpret_cast<const uint2*>(bias + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
-      }
       if (rv) {
         U64 b;
         b.u = *reinterpret_cast<const uint2*>(rv + n);
@@ -233,13 +226,9 @@ __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&
 // GEGLU: tile 2jj = value rows, tile 2jj+1 = gate rows of the same 16 output columns (weights.py packs them so)
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
-  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
   f16* C = reinterpret_cast<f16*>(a.C);
   const int nb = n0 + wn * WN + (lane >> 4) * 4;
   const int nob = (n0 + wn * WN) / 2 + (lane >> 4) * 4;
-  U64 bv[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) bv[j].u = (bias && nb + 16 * j < a.N) ? *reinterpret_cast<const uint2*>(bias + nb + 16 * j) : make_uint2(0u, 0u);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = rowfn(i);
@@ -251,8 +240,8 @@ __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&ac
       U64 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float va = acc[2 * jj][i][r] * a.alpha + (float)bv[2 * jj].e[r];
-        const float vg = acc[2 * jj + 1][i][r] * a.alpha + (float)bv[2 * jj + 1].e[r];
+        const float va = acc[2 * jj][i][r] * a.alpha;
+        const float vg = acc[2 * jj + 1][i][r] * a.alpha;
         o.e[r] = (f16)(va * gelu_erf_fast(vg));
       }
       if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
@@ -264,12 +253,12 @@ __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&ac
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
   if (a.geglu) return epilogue_geglu<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
-  const int f = a.act != 0 ? -1 : ((a.bias ? 1 : 0) | (a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0));
+  const int f = a.act != 0 ? -1 : ((a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0));
   switch (f) {   // wave-uniform
-    case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // q | k | v projections
-    case 1: return epilogue_rows<1, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // biased linear / conv
-    case 3: return epilogue_rows<3, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // resnet conv1 + time embedding
-    case 5: return epilogue_rows<5, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // out projection / ff2 / conv2 / tconv + residual
+    case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // projections, (biased) linears / convs
+    case 2: return epilogue_rows<2, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // resnet conv1 + time embedding
+    case 4: return epilogue_rows<4, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // out projection / ff2 / conv2 / tconv + residual
+    case 12: return epilogue_rows<12, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);  // + second residual
     default: return epilogue_generic<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
   }
 }
@@ -340,10 +329,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   };
 
   f32x4 acc[NT][MT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  init_acc<NT, MT, WN>(a, acc, n0, wn, lane);
 
   const int frow = lane & 15;
   const int fg = lane >> 4;
@@ -539,10 +525,7 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a
   };
 
   f32x4 acc[NT][MT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  init_acc<NT, MT, WN>(a, acc, n0, wn, lane);
 
   const int frow = lane & 15, fg = lane >> 4;
   auto compute = [&](int tap, int buf) {

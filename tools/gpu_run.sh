@@ -1,8 +1,8 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu > gpurun_out/t_all.log 2>&1
-tail -2 gpurun_out/t_all.log
+timeout 1200 python -m pytest tests -x -q -m gpu > gpurun_out/t_all.log 2>&1
+tail -3 gpurun_out/t_all.log
 timeout 900 python bench.py --shapes --no-cpu-baseline > gpurun_out/bench_shapes3.log 2>&1
 grep "^\[shape\]" gpurun_out/bench_shapes3.log | head -12
 tail -1 gpurun_out/bench_shapes3.log | python -c "

@@ -89,6 +89,17 @@ def bench_gemm_ksweep():
             print(f"{N:6d} {K:6d} {ms:8.3f} {ms * 1e3 * 256 / tiles:8.2f}")
 
 
+def bench_gemm_epi():
+    """Epilogue terms on the bandwidth-bound L0 / L1 square projections."""
+    print(f"{'shape':28s} {'plain':>8s} {'bias':>8s} {'res':>8s} {'bias+res':>9s} {'inplace':>8s}")
+    for M, C in ((4 * 24 * 4096, 320), (4 * 24 * 1024, 640), (4 * 24 * 256, 1280)):
+        x, w, b, r = rnd(M, C), rnd(C, 1, C), rnd(C), rnd(M, C)
+        o = torch.empty_like(r)
+        t = [timeit(lambda: ops.gemm(x, w, out=o)), timeit(lambda: ops.gemm(x, w, bias=b, out=o)), timeit(lambda: ops.gemm(x, w, res=r, out=o)),
+             timeit(lambda: ops.gemm(x, w, bias=b, res=r, out=o)), timeit(lambda: ops.gemm(x, w, bias=b, res=r, out=r))]
+        print(f"M{M} N{C} K{C}".ljust(28) + " ".join(f"{v:8.3f}" for v in t))
+
+
 def bench_attn(only_first=False):
     B, f = 4, 24
     print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
@@ -134,6 +145,8 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+    if "gemme" in what:
+        bench_gemm_epi()
     if "gemmk" in what:
         bench_gemm_ksweep()
     if "gemmc" in what:
