@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect the judged evidence on the GPU box: usage  bash tools/collect_profiles.sh <tag>   (e.g. r01_v4)
+# Writes gpurun_out/<tag>_*; copy what should be kept into profiles/ afterwards.
+tag=${1:-r01}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rm -f gpurun_out/parity.jsonl
+timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider > gpurun_out/${tag}_pytest_gpu.log 2>&1
+echo "pytest exit $?" > gpurun_out/${tag}_summary.txt
+cp gpurun_out/parity.jsonl gpurun_out/${tag}_parity.jsonl 2>/dev/null
+timeout 900 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
+echo "build+smoke exit $?" >> gpurun_out/${tag}_summary.txt
+timeout 1200 python bench.py > gpurun_out/${tag}_bench.log 2>&1
+echo "bench exit $?" >> gpurun_out/${tag}_summary.txt
+tail -1 gpurun_out/${tag}_bench.log > gpurun_out/${tag}_bench_c3.json
+rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
+( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof -o r -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_rocprof.log 2>&1 )
+echo "rocprof exit $?" >> gpurun_out/${tag}_summary.txt
+python tools/rocpd_summary.py $(find gpurun_out/${tag}_prof -name "*.db" | head -1) gpurun_out/${tag}_bench_c3_kernel_stats.csv 3 >> gpurun_out/${tag}_summary.txt 2>&1
+( cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_pmc_f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_pmc_f.log 2>&1 )
+( cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > $R/gpurun_out/${tag}_pmc_w.log 2>&1 )
+python tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*.db" | head -1) $(find gpurun_out/${tag}_pmc_w -name "*.db" | head -1) gpurun_out/${tag}_pmc_hbm.csv gpurun_out/${tag}_pmc_traffic.json 3 >> gpurun_out/${tag}_summary.txt 2>&1
+timeout 600 python tools/kbench.py gemm attn misc > gpurun_out/${tag}_kbench.txt 2>&1
+rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
+cat gpurun_out/${tag}_summary.txt; tail -c 600 gpurun_out/${tag}_bench_c3.json

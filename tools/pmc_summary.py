@@ -28,7 +28,7 @@ with open(out_csv, "w", newline="") as fh:
     for k, n, f_kb, w_kb in rows[:40]:
         per = (2 * f_kb + w_kb) * 1024 / n
         w.writerow([k, n, f"{f_kb:.0f}", f"{w_kb:.0f}", f"{per:.0f}", f"{(2 * f_kb + w_kb) * 1024 / steps / 1e9:.2f}"])
-        name = "gemm" if "gemm_kernel" in k else ("attn_dh40" if "attn_kernel<40" in k else ("attn_dh80" if "attn_kernel<80" in k else None))
+        name = "gemm" if ("gemm_kernel" in k or "conv3_halo_kernel" in k) else ("attn_dh40" if "attn_kernel<40" in k else ("attn_dh80" if "attn_kernel<80" in k else None))
         if name:
             d = fam.setdefault(name, [0, 0.0])
             d[0] += n
