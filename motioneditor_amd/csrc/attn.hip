@@ -29,7 +29,7 @@ constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: 16 rows x 16 B hit 64 distinct banks)
 
-template <int DH, int QT, bool GD, int MINW, int NBUF, bool PIPE = false, bool PRIO = false>
+template <int DH, int QT, bool GD, int MINW, int NBUF>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   constexpr int CH = DH / 8;
   constexpr int D32 = (DH + 31) / 32;
@@ -200,228 +200,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 
   __syncthreads();  // LDS zero-fill visible before the first stage is written
   const int nfull = a.nk / KT;
-  if constexpr (PIPE) {
-    // ---- software-pipelined main loop (dh 40) ----
-    // MFMA and VALU only overlap inside ONE wave's instruction stream (an MFMA holds the issue port 4 of its 16
-    // cycles), and the plain loop runs them back to back: S -> softmax -> PV (PMC: VALU 58 % + MFMA 31 % busy,
-    // not overlapped).  Here iteration ti computes S(ti+1) = K(ti+1) Q^T in the same basic block as the exp /
-    // convert half of softmax(ti), so the 16 S MFMAs run underneath ~64 VALU/transcendental instructions.
-    // K therefore runs one tile ahead of V: LDS holds K(ti+1), K(ti+2)' and V(ti), V(ti+1)'; registers K(ti+2|3), V(ti+1|2).
-    static_assert(NBUF == 2 && !GD, "pipelined loop: two LDS stages, plain / binary-mask segments");
-    int seg_k = 0, kt_k = 0, seg_v = 0, kt_v = 0;
-    const f16 *kptr = K, *vptr = V;
-    auto base_of = [&](const f16* B, int ld, int seg) { return B + (long)a.seg_item[item * a.nseg + seg] * a.nk * ld; };
-    auto adv = [&](int& seg, int& kt, const f16*& ptr, const f16* B, int ld) {
-      if (++kt == ntk) {
-        kt = 0;
-        if (++seg < nvalid) ptr = base_of(B, ld, seg);
-      } else {
-        ptr += KT * ld;
-      }
-    };
-    auto row_off = [&](int kt, int ld) {   // tail tile: keys past nk re-read the last key (finite; logits masked)
-      const int kl = (kt + 1) * KT > a.nk ? min(lane, a.nk - 1 - kt * KT) : lane;
-      return kl * ld + h * DH;
-    };
-    auto loadK = [&](int j) {
-      const int off = row_off(kt_k, a.ldk);
-#pragma unroll
-      for (int i = 0; i < NFULL; ++i) rk[i] = ldg128(kptr + off + (wave + 4 * i) * 8);
-      if constexpr (RW > 0) {
-        const int r = (wave - j) & 3;
-        if (r < RW) rk[NFULL] = ldg128(kptr + off + (4 * NFULL + r) * 8);
-      }
-      adv(seg_k, kt_k, kptr, K, a.ldk);
-    };
-    auto loadV = [&](int j) {
-      const int off = row_off(kt_v, a.ldv);
-#pragma unroll
-      for (int i = 0; i < NFULL; ++i) rv[i] = ldg128(vptr + off + (wave + 4 * i) * 8);
-      if constexpr (RW > 0) {
-        const int r = (wave - j) & 3;
-        if (r < RW) rv[NFULL] = ldg128(vptr + off + (4 * NFULL + r) * 8);
-      }
-      adv(seg_v, kt_v, vptr, V, a.ldv);
-    };
-    auto storeK = [&](int j) {
-      f16* sK = sKb[j & 1];
-#pragma unroll
-      for (int i = 0; i < NFULL; ++i) *reinterpret_cast<uint4*>(sK + lane * KLD + (wave + 4 * i) * 8) = rk[i];
-      if constexpr (RW > 0) {
-        const int r = (wave - j) & 3;
-        if (r < RW) *reinterpret_cast<uint4*>(sK + lane * KLD + (4 * NFULL + r) * 8) = rk[NFULL];
-      }
-    };
-    auto storeV = [&](int j) {
-      f16* sVt = sVtb[j & 1];
-      auto put = [&](int cc, const uint4& v) {
-        U128 u;
-        u.u = v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sVt[(cc * 8 + e) * VLD + vpos] = u.e[e];
-      };
-#pragma unroll
-      for (int i = 0; i < NFULL; ++i) put(wave + 4 * i, rv[i]);
-      if constexpr (RW > 0) {
-        const int r = (wave - j) & 3;
-        if (r < RW) put(4 * NFULL + r, rv[NFULL]);
-      }
-    };
-    // S^T(j) = K(j) Q^T
-    auto qk = [&](f32x4 (&sd)[QT][4], int j) {
-      const f16* sK = sKb[j & 1];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sd[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < D32; ++ks) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KLD + ks * 32 + g * 8);
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) sd[qt][t] = mfma16(fk, fq[qt][ks], sd[qt][t]);
-        }
-      }
-    };
-    // softmax + PV of tile ti from sc, S of tile ti+1 into sn (computed even past the last tile: stale but
-    // harmless LDS contents, result unused -- a branch would split the block and forbid the interleave)
-    auto step = [&](auto mode_c, auto full_c, f32x4 (&sc)[QT][4], f32x4 (&sn)[QT][4], int ti, int kt) {
-      constexpr int MODE = decltype(mode_c)::value;
-      constexpr bool FULL = decltype(full_c)::value;
-      const f16* sVt = sVtb[ti & 1];
-      const int kbase = kt * KT + g * 4;  // + t*16 + r
-      float alpha[QT], e0[QT];
-      bool resc = false;
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        if constexpr (!FULL) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (kbase + t * 16 + r >= a.nk) sc[qt][t][r] = NEG_BIG;
-        }
-        float mr = NEG_BIG;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, sc[qt][t][r]);
-        mr = xor32_max(xor16_max(mr));
-        const float mnew = MODE == ME_SEG_PLAIN ? fmaxf(mrun[qt], mr * c) : fmaxf(mrun[qt], fmaxf(mr * c, 0.f));
-        alpha[qt] = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-        mrun[qt] = mnew;
-        e0[qt] = MODE == ME_SEG_DUAL_BIN ? __builtin_amdgcn_exp2f(-mnew) : 0.f;
-        resc |= alpha[qt] != 1.0f;
-      }
-      // rescale only when some query of the wave saw its running max move (exact: alpha == 1 otherwise)
-      if (__builtin_amdgcn_readfirstlane(__any(resc))) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha[qt];
-      }
-      qk(sn, ti + 1);
-      f16x8 pf[QT][2];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        float p[4][4];
-        float psum = 0.f;
-        const f32x2 c2 = {c, c}, nm2 = {-mrun[qt], -mrun[qt]}, e2 = {e0[qt], e0[qt]};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const f32x2 sv = {sc[qt][t][2 * h2], sc[qt][t][2 * h2 + 1]};
-            const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
-            f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-            if constexpr (MODE == ME_SEG_DUAL_BIN) pv += e2;
-            p[t][2 * h2] = pv[0];
-            p[t][2 * h2 + 1] = pv[1];
-            if constexpr (!FULL && MODE == ME_SEG_DUAL_BIN) {
-              if (kbase + t * 16 + 2 * h2 >= a.nk) p[t][2 * h2] = 0.f;
-              if (kbase + t * 16 + 2 * h2 + 1 >= a.nk) p[t][2 * h2 + 1] = 0.f;
-            }
-            if constexpr (!ONES) psum += p[t][2 * h2] + p[t][2 * h2 + 1];
-          }
-        if constexpr (!ONES) lrun[qt] = lrun[qt] * alpha[qt] + psum;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          union { f16x2 h[4]; f16x8 v; } f;
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            f.h[h2] = __builtin_convertvector((f32x2){p[2 * kk][2 * h2], p[2 * kk][2 * h2 + 1]}, f16x2);
-            f.h[2 + h2] = __builtin_convertvector((f32x2){p[2 * kk + 1][2 * h2], p[2 * kk + 1][2 * h2 + 1]}, f16x2);
-          }
-          pf[qt][kk] = f.v;
-        }
-      }
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const f16x8 fv = *reinterpret_cast<const f16x8*>(sVt + (dt * 16 + l15) * VLD + kk * 32 + g * 8);
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv, pf[qt][kk], o[qt][dt]);
-        }
-      }
-    };
-
-    f32x4 s0[QT][4], s1[QT][4];
-    if (T > 0) {
-      kptr = base_of(K, a.ldk, 0);
-      vptr = base_of(V, a.ldv, 0);
-      loadK(0);
-      storeK(0);
-      if (T > 1) loadK(1);
-      loadV(0);
-      __syncthreads();
-      qk(s0, 0);
-      if (T > 1) storeK(1);
-      storeV(0);
-      if (T > 2) loadK(2);
-      if (T > 1) loadV(1);
-    }
-    __syncthreads();
-    int ti = 0;
-    auto stage = [&]() {
-      // K(ti) and V(ti-1) were last read one barrier ago: their stages take K(ti+2), V(ti+1)
-      if (ti + 2 < T) storeK(ti + 2);
-      if (ti + 1 < T) storeV(ti + 1);
-      if (ti + 3 < T) loadK(ti + 3);
-      if (ti + 2 < T) loadV(ti + 2);
-      __syncthreads();
-      ++ti;
-    };
-    // tiles in pairs (s0 -> s1 -> s0) so that the two score tiles never change registers; an odd tail copies once
-    auto run = [&](auto mode_c, auto full_c, int kt0, int count) {
-      int n = 0;
-      for (; n + 1 < count; n += 2) {
-        step(mode_c, full_c, s0, s1, ti, kt0 + n);
-        stage();
-        step(mode_c, full_c, s1, s0, ti, kt0 + n + 1);
-        stage();
-      }
-      if (n < count) {
-        step(mode_c, full_c, s0, s1, ti, kt0 + n);
-        stage();
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) s0[qt][t] = s1[qt][t];
-      }
-    };
-    for (int seg = 0; seg < nvalid; ++seg) {
-      const int mode = __builtin_amdgcn_readfirstlane(a.seg_mode[item * a.nseg + seg]);
-      if (mode == ME_SEG_PLAIN) {
-        run(IC0{}, BT{}, 0, nfull);
-        run(IC0{}, BF{}, nfull, ntk - nfull);
-      } else {   // me_attn routes general (non-binary) masks to the GD instantiation
-        run(IC3{}, BT{}, 0, nfull);
-        run(IC3{}, BF{}, nfull, ntk - nfull);
-      }
-    }
-  } else {
   if (T > 0) {
     seg_base();
     gload(0);
@@ -446,7 +224,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int t = 0; t < 4; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);   // matrix phases outrank the other waves' VALU phases
 #pragma unroll
     for (int ks = 0; ks < D32; ++ks) {
 #pragma unroll
@@ -456,7 +233,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
       }
     }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
 
     // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
     f16x8 pf[QT][2];
@@ -551,7 +327,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     }
 
     // ---- O^T += V^T P^T ----
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -561,7 +336,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
         for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv, pf[qt][kk], o[qt][dt]);
       }
     }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
   };
 
   // One loop per (segment mode, full / tail) so that the accumulators stay in place between tiles: a single
@@ -593,8 +367,6 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     }
   }
 
-  }
-
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] / l ----
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -618,17 +390,17 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   }
 }
 
-template <int DH, int QT, bool GD, int MINW, int NBUF, bool PIPE = false, bool PRIO = false>
+template <int DH, int QT, bool GD, int MINW, int NBUF>
 int launch_attn(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 64 * QT;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW, NBUF, PIPE, PRIO>), dim3((unsigned)total), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW, NBUF>), dim3((unsigned)total), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }
 
-int variant() {   // A/B knobs: ME_ATTN_VARIANT=1 one 16-query tile per wave; =2 dh 40 software-pipelined (S of the next tile under the exps; 2 waves/SIMD), =3 dh 40 with s_setprio around the MFMA phases
+int variant() {   // ME_ATTN_VARIANT=1: one 16-query tile per wave (fewer registers, more waves per SIMD) -- A/B knob
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("ME_ATTN_VARIANT");
@@ -652,8 +424,6 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
     case 40:
       if (a->general_dual) rc = launch_attn<40, 2, true, 2, 1>(a, st);
       else if (variant() == 1) rc = launch_attn<40, 1, false, 4, 2>(a, st);
-      else if (variant() == 2) rc = launch_attn<40, 2, false, 2, 2, true>(a, st);
-      else if (variant() == 3) rc = launch_attn<40, 2, false, 3, 2, false, true>(a, st);
       else rc = launch_attn<40, 2, false, 3, 2>(a, st);
       break;
     case 80:

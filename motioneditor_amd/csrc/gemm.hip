@@ -6,10 +6,12 @@
 // input folded into the gather) and the k=3 temporal conv: only the row-gather src(m, tap) differs.
 // Activations are channels-last so every tap is a contiguous K-run of one source row.
 //
-// Tiling: 128 x BN x 64 block tile, 256 threads = 4 waves in a 2 x 2 grid, each wave 64 x (BN/2)
-// built from v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as MFMA operand A and the ACTIVATION
-// fragment as operand B, so a lane ends up holding 4 consecutive output channels of one output row
-// (8-byte stores, bias/GEGLU epilogue without cross-lane traffic).
+// Tiling: BM x BN x 64 block tile, waves in a (BM/64) x 2 grid, each wave 64 x (BN/2) built from
+// v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as MFMA operand A and the ACTIVATION fragment as operand B, so a
+// lane ends up holding 4 consecutive output channels of one output row (8-byte stores, epilogue without cross-lane
+// traffic).  256 x 320 (8 waves, one block per CU) when the grid still fills the chip, 128 x {160, 128, 64} otherwise.
+// The bias is the accumulators' initial value; the epilogue packs the tile to fp16 and adds the row-vector /
+// residual terms with packed fp16 adds (see epilogue_rows).
 //
 // Staging (STAGE_GLDS, default): global_load_lds_dwordx4 -- each wave instruction DMAs 8 rows x 128 B
 // straight into LDS (no VGPR round trip, no ds_write).  The LDS image is lane-linear, so the
@@ -612,15 +614,6 @@ bool conv_halo() {   // ME_CONV_HALO=0 sends 3x3 convolutions back to the gather
   return on == 1;
 }
 
-bool wave128() {   // ME_GEMM_WAVE128=1: 4 waves x (128 x 160) per 256 x 320 tile, one wave per SIMD
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("ME_GEMM_WAVE128");
-    on = (e && e[0] == '1') ? 1 : 0;
-  }
-  return on == 1;
-}
-
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -707,7 +700,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);
     if (a->N % 320 == 0 && big_blocks >= big_min_blocks())
-      return wave128() ? launch_gemm<256, 320, STAGE_GLDS, 128>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
+      return launch_gemm<256, 320, STAGE_GLDS>(a, st);
     if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<128, 160, STAGE_GLDS>(a, st);
     return wide ? launch_gemm<128, 128, STAGE_GLDS>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
   }
