@@ -62,6 +62,26 @@ def test_gemm_dense_epilogue_all(ops):
         check(got, want, f"gemm epilogue act={act}")
 
 
+@pytest.mark.parametrize("terms", ["none", "bias", "rowvec", "res", "res+res2", "bias+rowvec", "bias+res", "bias+rowvec+res", "inplace"])
+@pytest.mark.parametrize("M,N,K", [(256 * 520, 320, 64), (1000, 640, 128), (300, 128, 64)])
+def test_gemm_epilogue_term_combinations(ops, terms, M, N, K):
+    """Each specialised epilogue body (epilogue_rows<F>) and the generic one, on the 256x320 tile (>= 512 tiles),
+    the 128x160 tile and the 128x128 tile; bias enters through the accumulator init."""
+    x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3) if "bias" in terms or terms == "inplace" else None
+    rowvec = rnd(8, N, seed=4) if "rowvec" in terms else None
+    res = rnd(M, N, seed=5) if "res" in terms or terms == "inplace" else None
+    res2 = rnd(M, N, seed=6) if "res2" in terms else None
+    rpv = (M + 7) // 8
+    want = emu.gemm(x, w, bias=bias, rowvec=rowvec, rows_per_vec=rpv if rowvec is not None else 0, res=res, res2=res2)
+    if terms == "inplace":
+        out = cu(res).clone()
+        ops.gemm(cu(x), cu(w), bias=cu(bias), res=out, out=out)
+    else:
+        out = ops.gemm(cu(x), cu(w), bias=cu(bias), rowvec=cu(rowvec), rows_per_vec=rpv if rowvec is not None else 0, res=cu(res), res2=cu(res2))
+    check(out, want, f"gemm {M}x{N}x{K} terms={terms}")
+
+
 def test_gemm_inplace_residual_and_strided_views(ops):
     M, C = 260, 320
     x, w = rnd(M, C, seed=1), rnd(C, 1, C, seed=2, scale=C ** -0.5)
