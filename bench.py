@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--parallel", choices=["cfg", "replicas", "frames"], default="cfg",
                     help="N > 1: CFG-parallel GPU pairs (even N), independent replicas, or ONE clip with its frames sharded over all N ranks")
     ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
+    ap.add_argument("--editors", choices=["active", "inactive"], default="active",
+                    help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
+    ap.add_argument("--zero-tconv", action="store_true",
+                    help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,6 +125,8 @@ def main():
     capi.lib()  # no HIP library -> hard failure (no fallback path exists)
     usd = synth.synth_state_dict(synth.unet_schema())
     csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
+    if args.zero_tconv:
+        usd = {k: (np.zeros_like(v) if ".temp_conv" in k and not k.startswith("controlnet_adapter.") else v) for k, v in usd.items()}
     f, h, w = args.frames, args.latent, args.latent
     cfg_par = dist_on and args.parallel == "cfg" and world % 2 == 0
     group = None
@@ -147,6 +153,8 @@ def main():
     ts = pipe.scheduler.timesteps
 
     def run_step(i, lat):
+        if args.editors == "inactive":
+            sed.cur_step = ted.cur_step = 0      # the editors count steps themselves: hold them before start_step
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
         if frame_par:
             return pipe.denoise_step_frame_sharded(lat, ts[i], emb, images, 7.5, shard)
@@ -154,7 +162,7 @@ def main():
             return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=group)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
-    sed.cur_step = ted.cur_step = 4          # editors active: the steady-state step (46 of 50)
+    sed.cur_step = ted.cur_step = 4 if args.editors == "active" else 0   # active: the steady-state step (46 of 50)
     i0 = 4
     for k in range(args.warmup):
         lat = run_step(i0 + k, lat)
@@ -186,8 +194,8 @@ def main():
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
-                                      f"(editors active), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
-                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
+                                      f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
+                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv), "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
                           "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
                                                                           f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
                                                                           if cfg_par else (f"frames{world}: one clip, {f // world} frames per GPU; RCCL all-gather of K|V (attn1, adapter, temporal attention), "

@@ -1,5 +1,10 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "epilogue_term" > gpurun_out/t_epi.log 2>&1
-tail -5 gpurun_out/t_epi.log
+for fl in "" "--editors inactive" "--zero-tconv" "--frames 8" "--frames 16" "--frames 8 --latent 32"; do
+echo "flags: $fl"
+timeout 600 python bench.py --no-cpu-baseline $fl 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'], d['achieved_tflops_whole_job'], {k:v['ms_per_step'] for k,v in d['kernel_families'].items()})"
+done
