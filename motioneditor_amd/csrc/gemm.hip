@@ -701,6 +701,10 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
       return launch_conv_halo(a, st);
     if (a->N % 320 == 0 && big_blocks >= big_min_blocks())
       return launch_gemm<256, 320, STAGE_GLDS>(a, st);
+    // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
+    // two each (+8 % on those shapes; 64-row tiles measured worse)
+    const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);
+    if (a->N % 128 == 0 && blocks160 < 512) return launch_gemm<128, 128, STAGE_GLDS>(a, st);
     if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<128, 160, STAGE_GLDS>(a, st);
     return wide ? launch_gemm<128, 128, STAGE_GLDS>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
   }

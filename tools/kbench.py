@@ -100,6 +100,18 @@ def bench_gemm_epi():
         print(f"M{M} N{C} K{C}".ljust(28) + " ".join(f"{v:8.3f}" for v in t))
 
 
+def bench_gemm_small():
+    """Small-M layers (level 3 / mid / ControlNet): few tiles per CU."""
+    print(f"{'shape':36s} {'ms':>8s} {'TF/s':>7s}")
+    for M, N, K, conv in [(1536, 1280, 1280, (8, 8, 8, 8, 1, 0)), (1536, 1280, 1280, None), (3072, 1280, 1280, (8, 8, 8, 8, 1, 0)), (6144, 1280, 1280, (8, 8, 8, 8, 1, 0)),
+                          (6144, 1280, 2560, (8, 8, 8, 8, 1, 0)), (6144, 1280, 1280, None), (6144, 3840, 1280, None), (24576, 640, 640, None), (24576, 1280, 1280, None),
+                          (98304, 320, 320, None), (98304, 320, 320, (64, 64, 64, 64, 1, 0))]:
+        taps = 9 if conv else 1
+        x, w = rnd(M, K), rnd(N, taps, K)
+        ms = timeit(lambda: ops.gemm(x, w, M=M, conv=conv))
+        print(f"M{M} N{N} K{K} taps{taps}".ljust(36) + f" {ms:8.3f} {2.0*M*N*K*taps/ms/1e9:7.1f}")
+
+
 def bench_attn(only_first=False):
     B, f = 4, 24
     print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
@@ -145,6 +157,8 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+    if "gemms" in what:
+        bench_gemm_small()
     if "gemme" in what:
         bench_gemm_epi()
     if "gemmk" in what:
