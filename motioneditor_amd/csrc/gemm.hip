@@ -298,7 +298,12 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
 
   const int taps = a.gather == ME_GATHER_CONV3 ? 9 : (a.gather == ME_GATHER_TCONV ? 3 : 1);
   const int nkc = (a.K + BK - 1) / BK;
-  const int nit = taps * nkc;
+  // 3x3 convs with fewer than 64 input channels (the ControlNet conditioning embedding: 16, 32) pack (tap, channel)
+  // into ONE K axis of 9 K -- the weights [N][9][K] are contiguous in exactly that order -- instead of nine 64-wide
+  // slabs that are 75 % / 50 % zero padding: 3 / 5 slabs instead of 9.  A lane's 16-byte chunk then belongs to
+  // the tap (slab * 64 + chunk offset) / K, different lanes gather different taps of their rows.
+  const bool packk = STAGE == STAGE_GLDS && a.gather == ME_GATHER_CONV3 && a.K < BK && BK % a.K == 0;
+  const int nit = packk ? (9 * a.K + BK - 1) / BK : taps * nkc;
 
   // staging assignment
   //   REG : thread -> rows tid/8 + 32*i, 16-byte chunk tid%8
@@ -366,10 +371,18 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
     typedef __attribute__((address_space(3))) void* lptr_t;
     const f16* zsrc = reinterpret_cast<const f16*>(&g_zero16);
     auto gload = [&](int it, int buf) {
-      const int tap = it / nkc;
-      const int c = (it - tap * nkc) * BK + scol;
+      int tap = it / nkc;
+      int c = (it - tap * nkc) * BK + scol;
+      bool kok = c < a.K;
+      long wk = (long)tap * a.K + c;       // offset inside a weight row
+      if (packk) {
+        wk = it * BK + scol;
+        tap = (int)wk / a.K;
+        c = (int)wk - tap * a.K;
+        kok = tap < 9;
+        if (!kok) tap = 8;
+      }
       set_tap(tap);
-      const bool kok = c < a.K;
       char* dx = reinterpret_cast<char*>(sX + buf * BM * LD) + wave * 1024;
       char* dw = reinterpret_cast<char*>(sW + buf * BN * LD) + wave * 1024;
 #pragma unroll
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
 #pragma unroll
       for (int i = 0; i < WROWS; ++i) {
         const int n = n0 + srow + RSTR * i;
-        const f16* src = (kok && n < a.N) ? W + ((long)n * taps + tap) * a.K + c : zsrc;
+        const f16* src = (kok && n < a.N) ? W + (long)n * taps * a.K + wk : zsrc;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dw + i * (RSTR * 128)), 16, 0, 0);
       }
     };

@@ -113,7 +113,8 @@ def test_gemm_geglu(ops, C, M):
 
 @pytest.mark.parametrize("Cin,Cout,H,W,stride,ups,nimg", [(320, 320, 8, 8, 1, 0, 5), (320, 640, 8, 8, 2, 0, 3), (640, 640, 4, 4, 1, 1, 3), (16, 32, 16, 16, 2, 0, 2),
                                                           (96, 96, 8, 8, 1, 0, 2), (320, 4, 8, 8, 1, 0, 4), (1280, 1280, 2, 2, 1, 0, 8), (1280, 1280, 1, 1, 1, 0, 16),
-                                                          (2560, 1280, 2, 2, 1, 0, 4), (640, 320, 16, 12, 1, 0, 2)])
+                                                          (2560, 1280, 2, 2, 1, 0, 4), (640, 320, 16, 12, 1, 0, 2),
+                                                          (16, 16, 24, 20, 1, 0, 3), (32, 32, 16, 16, 1, 0, 2), (32, 96, 16, 16, 2, 0, 2), (8, 16, 8, 8, 1, 0, 2)])
 def test_gemm_conv3x3(ops, Cin, Cout, H, W, stride, ups, nimg):
     x = rnd(nimg * H * W, Cin, seed=1)
     w = rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
