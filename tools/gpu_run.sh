@@ -1,4 +1,8 @@
 #!/bin/bash
+cd /root/repo/motioneditor_amd
+cp libmotioned.so /tmp/new.so; cp libmotioned_old.so /tmp/old.so
 cd /root/repo
-timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "conv3x3" 2>&1 | tail -3
-timeout 300 python tools/kbench.py gemm 2>&1 | grep "cond"
+for v in old new old new; do
+cp /tmp/$v.so motioneditor_amd/libmotioned.so
+echo $v; timeout 300 python tools/kbench.py attn 2>&1 | grep "L0 prev\|L0 edited\|L1 edited\|L2"
+done
