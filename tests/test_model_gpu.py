@@ -139,6 +139,38 @@ def test_denoise_step_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch
     assert e <= STEP_TOL, e
 
 
+def test_six_consecutive_steps_cross_the_editor_start(unet, controlnet, unet_sd_torch, cn_sd_torch):
+    """Steps 0..5 of a run with the editors counting on their own (start_step = 4): the un-edited -> edited
+    transition, the per-step uncond embedding and the DDIM recursion, product loop vs oracle loop.
+    Tolerance: SURVEY 8c allows 2e-2 on the latents after 10 steps."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    from test_step_cpu import step_inputs
+    x = step_inputs()
+    f = x["latents"].shape[2]
+    ddim = ref_cpu.DDIM()
+    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64)
+    g = torch.Generator().manual_seed(5)
+    uncs = [x["uncond"] + 0.05 * i * torch.randn(x["uncond"].shape, generator=g) for i in range(6)]
+
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    sed, ted = editors(unet, x["masks"])
+    pipe.scheduler.set_timesteps(50)
+    want, got = x["latents"], x["latents"].cuda()
+    errs = []
+    for i in range(6):
+        t = ddim.timesteps[i]
+        assert sp.cur_step == sed.cur_step == i and tp.cur_step == ted.cur_step == i
+        want = ref_cpu.denoise_step(unet_sd_torch, cn_sd_torch, ddim, want, t, uncs[i], x["cond"], images, sp, tp, 7.5)
+        emb = torch.cat([uncs[i].expand(2, 77, 768), x["cond"]]).cuda()
+        got = pipe.denoise_step(got, t, emb, images.cuda(), 7.5)
+        errs.append(rel_l2(got, want))
+    unet.spatial_editor = unet.temporal_editor = None
+    record("six_steps_latents", errs[-1])
+    assert errs[-1] <= 2e-2, errs
+
+
 def test_properties_at_larger_size(unet):
     """Size-independent checks on a bigger clip (B=4, f=16, 32x32 latents): (1) determinism; (2) the
     reconstruction rows do not depend on the editing rows' inputs (K/V injection is one-way);

@@ -1,8 +1,4 @@
 #!/bin/bash
-cd /root/repo/motioneditor_amd
-cp libmotioned.so /tmp/new.so; cp libmotioned_old.so /tmp/old.so
 cd /root/repo
-for v in old new old new; do
-cp /tmp/$v.so motioneditor_amd/libmotioned.so
-echo $v; timeout 300 python tools/kbench.py attn 2>&1 | grep "L0 prev\|L0 edited\|L1 edited\|L2"
-done
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "six_consecutive" 2>&1 | tail -5
+grep six gpurun_out/parity.jsonl
