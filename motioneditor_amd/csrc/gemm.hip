@@ -260,7 +260,8 @@ __device__ __forceinline__ void epilogue(const me_gemm_args& a, f32x4 (&acc)[NT]
     case 0: return epilogue_rows<0, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // projections, (biased) linears / convs
     case 2: return epilogue_rows<2, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // resnet conv1 + time embedding
     case 4: return epilogue_rows<4, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);   // out projection / ff2 / conv2 / tconv + residual
-    case 12: return epilogue_rows<12, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);  // + second residual
+    case 6: return epilogue_rows<6, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);    // temp_conv1: + time embedding + residual
+    case 12: return epilogue_rows<12, NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);  // temp_conv2: + residual + shortcut
     default: return epilogue_generic<NT, MT, WN>(a, acc, rowfn, m0, n0, wn, lane, sC, CLD);
   }
 }

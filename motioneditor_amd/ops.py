@@ -112,7 +112,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.alpha = alpha
     e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
-    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}")
+    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
+        f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}")
     return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
 
 

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /root/repo
-timeout 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "six_consecutive" 2>&1 | tail -5
-grep six gpurun_out/parity.jsonl
+timeout 900 python bench.py --shapes --no-cpu-baseline 2> gpurun_out/shapes_flags.txt > /dev/null
+grep "^\[shape\]" gpurun_out/shapes_flags.txt | head -40
