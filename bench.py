@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
     ap.add_argument("--editors", choices=["active", "inactive"], default="active",
                     help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
+    ap.add_argument("--inversion", action="store_true",
+                    help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     args = ap.parse_args()
@@ -152,7 +154,14 @@ def main():
     unc = [u.to(device) for u in x["uncond"]]
     ts = pipe.scheduler.timesteps
 
+    if args.inversion:
+        from motioneditor_amd import util
+        pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
+        lat = lat[:1].contiguous()
+
     def run_step(i, lat):
+        if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
+            return util.ddim_loop(pipe, pipe.scheduler, lat, 1, normal_infer=True, text_embeddings=cond[:1])[-1]
         if args.editors == "inactive":
             sed.cur_step = ted.cur_step = 0      # the editors count steps themselves: hold them before start_step
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
@@ -190,7 +199,8 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = n_clips * args.steps / dt
-        out = {"metric": "denoise-steps/sec, 24f x 512^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)", "value": round(value, 4),
+        out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
+                          "denoise-steps/sec, 24f x 512^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "

@@ -301,7 +301,7 @@ def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
 
 def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
                  mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
-                 taps: Optional[dict] = None, shard=None) -> Act:
+                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False) -> Act:
     """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
     ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
     Returns eps rows [(B f N), 4] as an Act."""
@@ -312,7 +312,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     temb, toff = time_embedding(P, t, resnet_names(True), dev)
     text = text_rows(ehs, P.dtype)
     tseg = segments.cross_text(B, f, dev)
-    kw = dict(spatial=spatial, temporal=temporal, shard=shard)   # shard: this rank holds f = f_total / world consecutive frames
+    # normal_infer (DDIM inversion, inference.py:292): attn1 = plain per-frame self-attention (attention_2d.py:770-777)
+    kw = dict(spatial=spatial, temporal=temporal, shard=shard, sc_attn=not normal_infer)   # shard: this rank holds f = f_total / world consecutive frames
 
     x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
                            img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)

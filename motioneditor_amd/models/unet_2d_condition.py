@@ -67,17 +67,21 @@ class UNet2DConditionModel:
             return res
         return ops.nchw5_to_rows(res.to(self.device))
 
-    def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None) -> graph.Act:
+    def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None,
+                     normal_infer: bool = False) -> graph.Act:
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
         return graph.unet_forward(self.P, sample.to(self.device), t, encoder_hidden_states.to(self.device), down_res=down_rows, mid_res=mid_rows,
-                                  two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps, shard=shard)
+                                  two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps, shard=shard,
+                                  normal_infer=normal_infer)
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None, return_dict: bool = True,
                 normal_infer: bool = False, skeleton=None, down_block_additional_residuals=None, mid_block_additional_residual=None,
                 source_masks=None, target_masks=None, rectangle_source_masks=None, taps=None):
-        if class_labels is not None or attention_mask is not None or normal_infer or skeleton is not None:
-            raise NotImplementedError("class_labels / attention_mask / normal_infer / skeleton are not on the inference hot path "
+        if class_labels is not None or attention_mask is not None or skeleton is not None:
+            raise NotImplementedError("class_labels / attention_mask / skeleton are not on the inference hot path "
                                       "(pipeline_motion_editor.py:632-640 passes none of them)")
+        if normal_infer and (self.spatial_editor is not None or down_block_additional_residuals is not None):
+            raise NotImplementedError("normal_infer is the DDIM-inversion forward (util.py:89-96): single branch, no editors, no ControlNet")
         down = mid = None
         two = False
         if down_block_additional_residuals is not None:
@@ -91,7 +95,7 @@ class UNet2DConditionModel:
                 mid = m
                 two = sample.shape[0] == 4 and m.shape[0] * 2 == sample.shape[0] * sample.shape[2] * (sample.shape[3] // 8) * (sample.shape[4] // 8)
             down = [self._residual_rows(r, two) for r in down_block_additional_residuals]
-        out = self.forward_rows(sample, timestep, encoder_hidden_states, down, mid, two, taps)
+        out = self.forward_rows(sample, timestep, encoder_hidden_states, down, mid, two, taps, normal_infer=normal_infer)
         B, _, f, h, w = sample.shape
         y = ops.rows_to_nchw5(out.t, B, 4, f, h, w)
         return UNet2DConditionOutput(sample=y) if return_dict else (y,)

@@ -14,7 +14,10 @@ not product code.  What it does:
      the state-dict key schema as unet_keys.txt, and DDIM vectors from the reference's in-tree
      ``prev_step`` (p2p/null_text_optimization.py:26-36).
 
-Usage:  python oracle/make_golden.py [--skip-two-branch]
+  5. (--only-inversion / full run) DDIM inversion: the reference UNet with ``normal_infer=True`` and the reference's
+     in-tree ``next_step`` (util.py:77-87) walked over three inversion steps -> inversion.npz.
+
+Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion]
 """
 from __future__ import annotations
 
@@ -106,6 +109,64 @@ def reference_ddim_vectors():
     print("ddim.npz written; oracle DDIM == reference prev_step")
 
 
+def _ref_function(path: Path, name: str):
+    """Compile ONE function of a reference file without importing the module (its imports need packages this image lacks)."""
+    tree = ast.parse(path.read_text())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = {"Union": __import__("typing").Union, "torch": torch, "np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), f"ref_{name}", "exec"), ns)
+    return ns[name]
+
+
+def inversion_goldens(unet, sd):
+    """DDIM inversion (util.py:111-124 as inference.py:289-293 calls it): normal_infer UNet forward + next_step."""
+    next_step = _ref_function(REF / "motion_editor/util.py", "next_step")
+    d = ref_cpu.DDIM()
+
+    class Sched:
+        class config:
+            num_train_timesteps = 1000
+        num_inference_steps = 50
+        alphas_cumprod = d.alphas_cumprod
+        final_alpha_cumprod = d.alphas_cumprod[0]
+        timesteps = d.timesteps
+
+    ci = make_case_inputs("inversion", B=1, f=8, h=16, w=16)
+    cond = ci["ehs"]
+    out = {}
+    with torch.no_grad():
+        ref = quiet(unet, ci["sample"], torch.tensor(1), cond, normal_infer=True).sample
+        mine = ref_cpu.unet_forward(sd, ci["sample"], 1, cond, normal_infer=True)
+        e = relerr(mine, ref)
+        print("normal_infer oracle vs reference rel err", e)
+        assert e < 2e-4, e
+        out["unet_normal_infer_t1"] = ref.numpy().astype(np.float32)
+        # next_step vectors
+        g = torch.Generator().manual_seed(7)
+        x, eps = torch.randn(1, 4, 8, 8, 8, generator=g), torch.randn(1, 4, 8, 8, 8, generator=g)
+        for t in (1, 21, 501, 981):
+            r = next_step(eps, t, x, Sched)
+            assert relerr(d.next_step(eps, t, x), r) < 1e-6
+            ca, cb = d.next_coeffs(t)
+            assert relerr(ca * x + cb * eps, r) < 1e-5
+            out[f"next_{t}"] = r.numpy()
+        out["ns_x"], out["ns_eps"] = x.numpy(), eps.numpy()
+        # three inversion steps with the reference's own pieces (ddim_loop body, util.py:118-123)
+        lat = ci["sample"]
+        for i in range(3):
+            t = Sched.timesteps[len(Sched.timesteps) - i - 1]
+            noise = quiet(unet, lat, torch.tensor(t), cond, normal_infer=True).sample
+            lat = next_step(noise, t, lat, Sched)
+            out[f"loop_latent_{i + 1}"] = lat.numpy().astype(np.float32)
+        mine = ref_cpu.ddim_loop(sd, d, ci["sample"], 3, cond, normal_infer=True)
+        e2 = relerr(mine[-1], lat)
+        print("3-step inversion oracle vs reference rel err", e2)
+        assert e2 < 2e-4, e2
+    out["oracle_relerr"] = np.array([e, e2])
+    np.savez_compressed(GOLD / "inversion.npz", **out)
+    print("inversion.npz written")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -123,6 +184,10 @@ def main():
             fh.write(f"{k} {' '.join(str(int(s)) for s in v.shape)}\n")
     assert {k: tuple(v.shape) for k, v in ref_sd.items()} == dict(schema), "schema mismatch vs reference"
     sd = {k: torch.from_numpy(v) for k, v in sd_np.items()}
+
+    if "--only-inversion" in sys.argv:
+        inversion_goldens(unet, sd)
+        return
 
     from motion_editor.attn_control.fully_control import FullySelfAttentionControlMask
     from motion_editor.attn_control.fully_control_utils import regiter_fully_attention_editor_diffusers
@@ -180,6 +245,8 @@ def main():
         np.savez_compressed(GOLD / f"unet_two_{tag}.npz", out=ref.numpy().astype(np.float32), out_stats=stats(ref),
                             skip_stats=np.stack([stats(s) for s in taps["skips"]]), motion_stats=np.stack([stats(s) for s in taps["motion"]]),
                             mid_stats=stats(taps["mid"]), oracle_relerr=e)
+    # editors were registered on `unet` above: the inversion forward runs on a fresh, un-patched model
+    inversion_goldens(build_reference_unet(sd_np), sd)
     print("golden fixtures written to", GOLD)
 
 

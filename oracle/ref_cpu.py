@@ -367,7 +367,10 @@ UP_HAS_ATTN = (False, True, True, True)
 def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
                  down_res: Optional[Sequence[torch.Tensor]] = None, mid_res: Optional[torch.Tensor] = None,
                  spatial: Optional[SpatialEditor] = None, temporal: Optional[TemporalEditor] = None,
-                 taps: Optional[dict] = None) -> torch.Tensor:
+                 taps: Optional[dict] = None, normal_infer: bool = False) -> torch.Tensor:
+    """normal_infer=True (DDIM inversion, inference.py:292): attn1 is plain per-frame self-attention
+    (attention_2d.py:770-777 -> CrossAttention.forward); everything else, temporal attention included, unchanged."""
+    sc = not normal_infer
     B = sample.shape[0]
     tt = torch.as_tensor(t).reshape(-1).expand(B)
     emb = time_embed(sd, "", tt)
@@ -377,7 +380,7 @@ def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
         for j in range(2):
             x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, emb)
             if DOWN_HAS_ATTN[i]:
-                x = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal)
+                x = transformer2d(sd, f"down_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal, sc_attn=sc)
             skips.append(x)
         if i < 3:
             x = inflated_conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
@@ -398,7 +401,7 @@ def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
             taps["motion"] = [a.clone() for a in add]
         skips = [s + a for s, a in zip(skips, add)]
     x = resnet_block(sd, "mid_block.resnets.0", x, emb)
-    x = transformer2d(sd, "mid_block.attentions.0", x, ehs, spatial, temporal)
+    x = transformer2d(sd, "mid_block.attentions.0", x, ehs, spatial, temporal, sc_attn=sc)
     x = resnet_block(sd, "mid_block.resnets.1", x, emb)
     if mid_res is not None:
         x = x + mid_res
@@ -409,7 +412,7 @@ def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
             x = torch.cat([x, skips.pop()], dim=1)
             x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, emb)
             if UP_HAS_ATTN[i]:
-                x = transformer2d(sd, f"up_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal)
+                x = transformer2d(sd, f"up_blocks.{i}.attentions.{j}", x, ehs, spatial, temporal, sc_attn=sc)
         if i < 3:
             x = inflated_conv(sd, f"up_blocks.{i}.upsamplers.0.conv", upsample_nearest_2x(x))
     x = F.silu(F.group_norm(x, 32, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], 1e-5))
@@ -484,12 +487,44 @@ class DDIM:
         cb = (1 - a_p) ** 0.5 - (a_p * (1 - a_t) / a_t) ** 0.5
         return ca, cb
 
+    def next_coeffs(self, t: int) -> Tuple[float, float]:
+        """DDIM inversion, next = ca * x + cb * eps (util.py:77-87): the model output at `t` is applied between
+        t - 20 (clamped to 999; alpha = final_alpha_cumprod = alphas_cumprod[0] below 0) and t."""
+        cur_t = min(t - self.num_train_timesteps // self.num_inference_steps, 999)
+        a_c = float(self.alphas_cumprod[cur_t]) if cur_t >= 0 else float(self.alphas_cumprod[0])
+        a_n = float(self.alphas_cumprod[t])
+        ca = (a_n / a_c) ** 0.5
+        cb = (1 - a_n) ** 0.5 - (a_n * (1 - a_c) / a_c) ** 0.5
+        return ca, cb
+
+    def next_step(self, eps: torch.Tensor, t: int, x: torch.Tensor) -> torch.Tensor:
+        """util.py:77-87, term by term."""
+        cur_t = min(t - self.num_train_timesteps // self.num_inference_steps, 999)
+        a_c = self.alphas_cumprod[cur_t] if cur_t >= 0 else self.alphas_cumprod[0]
+        a_n = self.alphas_cumprod[t]
+        x0 = (x - (1 - a_c) ** 0.5 * eps) / a_c ** 0.5
+        return a_n ** 0.5 * x0 + (1 - a_n) ** 0.5 * eps
+
     def step(self, eps: torch.Tensor, t: int, x: torch.Tensor) -> torch.Tensor:
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.alphas_cumprod[0]
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
         return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
+
+
+def ddim_loop(unet_sd: SD, ddim: DDIM, latent: torch.Tensor, num_inv_steps: int, cond: torch.Tensor,
+              normal_infer: bool = True) -> List[torch.Tensor]:
+    """DDIM inversion (util.py:111-124, called with normal_infer=True from inference.py:289-293): single-branch UNet on
+    the conditional embedding only (no CFG), timesteps walked upwards; returns every intermediate latent."""
+    out = [latent]
+    for i in range(num_inv_steps):
+        t = ddim.timesteps[len(ddim.timesteps) - i - 1]
+        ehs = cond if cond.shape[0] == latent.shape[0] else cond.repeat(latent.shape[0], 1, 1)   # util.py:91-93
+        eps = unet_forward(unet_sd, latent, t, ehs, normal_infer=normal_infer)
+        latent = ddim.next_step(eps, t, latent)
+        out.append(latent)
+    return out
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,90 @@
+"""DDIM inversion (forward half; reference util.py:77-130 as inference.py:289-293 calls it):
+oracle vs the reference's golden vectors (tests/golden/inversion.npz, written by oracle/make_golden.py from the
+reference's own UNet with normal_infer=True and its in-tree next_step), and the product's host logic
+(motioneditor_amd/util.py + the normal_infer launch graph) on the emulated ABI vs the same goldens."""
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from conftest import GOLD, max_rel
+from motioneditor_amd import synth, util
+from motioneditor_amd.models import graph
+from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+from motioneditor_amd.schedulers import DDIMScheduler
+from oracle import ref_cpu
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD / "inversion.npz")
+
+
+def test_oracle_next_step_matches_reference_vectors(gold):
+    d = ref_cpu.DDIM()
+    x, eps = T(gold["ns_x"]), T(gold["ns_eps"])
+    for t in (1, 21, 501, 981):
+        want = T(gold[f"next_{t}"])
+        assert max_rel(d.next_step(eps, t, x), want) < 1e-5
+        ca, cb = d.next_coeffs(t)
+        assert max_rel(ca * x + cb * eps, want) < 1e-4
+
+
+def test_product_next_step_matches_reference_vectors(gold):
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    x, eps = T(gold["ns_x"]), T(gold["ns_eps"])
+    for t in (1, 21, 501, 981):
+        assert max_rel(util.next_step(eps, t, x, s), T(gold[f"next_{t}"])) < 1e-4
+    assert list(s.timesteps)[-3:] == [41, 21, 1]   # the inversion walks these first (util.py:119)
+
+
+def test_oracle_normal_infer_unet_and_loop_match_reference(gold, unet_sd_torch):
+    c = synth.make_case_inputs("inversion", B=1, f=8, h=16, w=16)
+    with torch.no_grad():
+        out = ref_cpu.unet_forward(unet_sd_torch, c["sample"], 1, c["ehs"], normal_infer=True)
+        assert max_rel(out, T(gold["unet_normal_infer_t1"])) < 2e-5
+        lats = ref_cpu.ddim_loop(unet_sd_torch, ref_cpu.DDIM(), c["sample"], 3, c["ehs"], normal_infer=True)
+    for i in range(3):
+        assert max_rel(lats[i + 1], T(gold[f"loop_latent_{i + 1}"])) < 2e-5
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    monkeypatch.setattr(graph, "ops", emu_ops)
+    import motioneditor_amd.models.unet_2d_condition as u
+    monkeypatch.setattr(u, "ops", emu_ops)
+    monkeypatch.setattr(util, "ops", emu_ops)
+    return emu_ops
+
+
+def test_product_graph_normal_infer_and_ddim_loop_match_reference(emu, gold, unet_sd_np):
+    """The launch graph with normal_infer=True (attn1 = per-frame self-attention segments) and util.ddim_loop on the
+    emulated ABI."""
+    c = synth.make_case_inputs("inversion", B=1, f=8, h=16, w=16)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    out = unet(c["sample"], 1, c["ehs"], normal_infer=True).sample
+    assert max_rel(out, T(gold["unet_normal_infer_t1"])) < 2e-4
+    # normal_infer differs from the sparse-causal forward (otherwise the flag would be untested)
+    assert max_rel(unet(c["sample"], 1, c["ehs"]).sample, T(gold["unet_normal_infer_t1"])) > 1e-2
+
+    class Pipe:
+        pass
+
+    pipe = Pipe()
+    pipe.unet = unet
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    lats = util.ddim_inversion(pipe, s, c["sample"], 3, normal_infer=True, text_embeddings=c["ehs"])
+    assert len(lats) == 4
+    for i in range(3):
+        assert max_rel(lats[i + 1], T(gold[f"loop_latent_{i + 1}"])) < 2e-4
+
+
+def test_normal_infer_rejects_editors_and_controlnet_residuals(emu, unet_sd_np):
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    c = synth.make_case_inputs("two", B=4, f=8, h=16, w=16)
+    with pytest.raises(NotImplementedError):
+        unet(c["sample"], 1, c["ehs"], normal_infer=True, down_block_additional_residuals=c["down_res"], mid_block_additional_residual=c["mid_res"])

@@ -171,6 +171,31 @@ def test_six_consecutive_steps_cross_the_editor_start(unet, controlnet, unet_sd_
     assert errs[-1] <= 2e-2, errs
 
 
+def test_ddim_inversion_vs_reference_golden(unet):
+    """SURVEY 8f rank 1 (forward half): normal_infer UNet and three inversion steps (util.ddim_inversion) on the HIP
+    path vs tests/golden/inversion.npz (reference UNet with normal_infer=True + the reference's next_step)."""
+    from motioneditor_amd import synth, util
+    from motioneditor_amd.schedulers import DDIMScheduler
+    g = np.load(GOLD / "inversion.npz")
+    c = synth.make_case_inputs("inversion", B=1, f=8, h=16, w=16)
+    out = unet(c["sample"], 1, c["ehs"], normal_infer=True).sample.float().cpu()
+    e = rel_l2(out, torch.from_numpy(g["unet_normal_infer_t1"]))
+    record("unet_normal_infer", e)
+    assert e <= UNET_TOL, e
+
+    class Pipe:
+        pass
+
+    pipe = Pipe()
+    pipe.unet = unet
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    lats = util.ddim_inversion(pipe, s, c["sample"], 3, normal_infer=True, text_embeddings=c["ehs"])
+    e3 = rel_l2(lats[-1].float().cpu(), torch.from_numpy(g["loop_latent_3"]))
+    record("inversion_3_steps_latents", e3)
+    assert e3 <= STEP_TOL, e3
+
+
 def test_properties_at_larger_size(unet):
     """Size-independent checks on a bigger clip (B=4, f=16, 32x32 latents): (1) determinism; (2) the
     reconstruction rows do not depend on the editing rows' inputs (K/V injection is one-way);
