@@ -108,6 +108,8 @@ def main():
                     help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
     ap.add_argument("--inversion", action="store_true",
                     help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
+    ap.add_argument("--vae-decode", action="store_true",
+                    help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     args = ap.parse_args()
@@ -125,6 +127,31 @@ def main():
 
     from motioneditor_amd import capi, ops, synth
     capi.lib()  # no HIP library -> hard failure (no fallback path exists)
+    if args.vae_decode:
+        from motioneditor_amd.models.vae import AutoencoderKL
+        vae = AutoencoderKL.from_synthetic(device)
+        z = torch.from_numpy(synth.synth_normal("bench.vae", (args.frames, 4, args.latent, args.latent), 33)).to(device)
+        for _ in range(args.warmup):
+            vae.decode(z)
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = vae.decode(z).sample
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        fam = {}
+        for name, fl, by, e0, e1, detail in prof:
+            d = fam.setdefault(name, [0.0, 0.0])
+            d[0] += e0.elapsed_time(e1) * 1e-3
+            d[1] += fl
+        assert torch.isfinite(img).all()
+        print(json.dumps({"metric": "vae-decode frames/sec (SD-1.5 AutoencoderKL decoder)", "value": round(args.frames * args.steps / dt, 3), "unit": "frames/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+                          "dtype": "f16", "data": "synthetic", "config": {"workload": f"{args.frames} latent frames {args.latent}x{args.latent} -> {8 * args.latent}x{8 * args.latent} images"},
+                          "kernel_families": {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0} for k, v in sorted(fam.items())}}))
+        return
     usd = synth.synth_state_dict(synth.unet_schema())
     csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
     if args.zero_tconv:

@@ -221,6 +221,12 @@ int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, in
 int me_rows_to_nchw(float* Y, int64_t img_stride, int64_t ch_stride, const void* X, int32_t ldx,
                     int32_t n_img, int32_t C, int32_t npix, void* stream);
 
+/* Y[r, :] = softmax(X[r, :]) over `cols` fp16 logits per row, fp32 arithmetic (already scaled: the producing
+ * me_gemm applies 1/sqrt(d) through alpha).  Used by the VAE decoder's single-head 512-wide attention, whose head
+ * dimension is outside me_attn's {40, 80, 160}: diffusers AttentionBlock, softmax(Q K^T / sqrt(512)).
+ * cols % 8 == 0, cols <= 8192; X and Y may alias. */
+int me_softmax_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,7 @@ SYMBOLS = {
     "me_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "me_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), _i64, _vp]),
     "me_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), _vp]),
+    "me_softmax_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_silu": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
       float s[8], q[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-      for (int r = r0 + rl; r < r1; r += RL) {
+#pragma unroll 4
+      for (int r = r0 + rl; r < r1; r += RL) {   // 4 independent 16-byte loads in flight per thread
         U128 u;
         u.u = ldg128(base + (long)r * ldx + vc * 8);
 #pragma unroll
@@ -85,31 +86,48 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, con
   gm.u = ldg128(gamma + vc * 8);
   bt.u = ldg128(beta + vc * 8);
   float A[8], B[8];
-  int sg_prev = -1;
   const long r0 = (long)blockIdx.x * chunk;
   const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
-  for (long row = r0 + threadIdx.y; row < r1; row += blockDim.y) {
+  long row = r0 + threadIdx.y;
+  while (row < r1) {
+    // rows of one sample-group share the scale / shift: derive them once, then stream (4 loads in flight per thread)
     const int sg = (int)(row / rows_per_group);
-    if (sg != sg_prev) {   // at most a few times per chunk
-      sg_prev = sg;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ge = (vc * 8 + e) / cg;
-        const float mean = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
-        const float var = fmaxf(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean * mean, 0.f);
-        A[e] = rsqrtf(var + eps) * (float)gm.e[e];
-        B[e] = (float)bt.e[e] - mean * A[e];
-      }
-    }
-    U128 u, o;
-    u.u = ldg128(X + row * ldx + vc * 8);
+    const long seg_end = (long)(sg + 1) * rows_per_group < r1 ? (long)(sg + 1) * rows_per_group : r1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float v = __builtin_fmaf((float)u.e[e], A[e], B[e]);
-      if (silu) v = silu_f(v);
-      o.e[e] = (f16)v;
+      const int ge = (vc * 8 + e) / cg;
+      const float mean = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
+      const float var = fmaxf(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean * mean, 0.f);
+      A[e] = rsqrtf(var + eps) * (float)gm.e[e];
+      B[e] = (float)bt.e[e] - mean * A[e];
     }
-    *reinterpret_cast<uint4*>(Y + row * ldy + vc * 8) = o.u;
+    auto emit = [&](const U128& u, long r) {
+      U128 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = __builtin_fmaf((float)u.e[e], A[e], B[e]);
+        if (silu) v = silu_f(v);
+        o.e[e] = (f16)v;
+      }
+      *reinterpret_cast<uint4*>(Y + r * ldy + vc * 8) = o.u;
+    };
+    const long st = blockDim.y;
+    for (; row + 3 * st < seg_end; row += 4 * st) {   // X may alias Y: the four loads are issued explicitly ahead of the stores
+      U128 u0, u1, u2, u3;
+      u0.u = ldg128(X + row * ldx + vc * 8);
+      u1.u = ldg128(X + (row + st) * ldx + vc * 8);
+      u2.u = ldg128(X + (row + 2 * st) * ldx + vc * 8);
+      u3.u = ldg128(X + (row + 3 * st) * ldx + vc * 8);
+      emit(u0, row);
+      emit(u1, row + st);
+      emit(u2, row + 2 * st);
+      emit(u3, row + 3 * st);
+    }
+    for (; row < seg_end; row += st) {
+      U128 u;
+      u.u = ldg128(X + row * ldx + vc * 8);
+      emit(u, row);
+    }
   }
 }
 
@@ -153,6 +171,51 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
       bt.u = ldg128(beta + vc * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.e[e] = (f16)(((float)u[k].e[e] - mean) * rstd * (float)gm.e[e] + (float)bt.e[e]);
+      *reinterpret_cast<uint4*>(Y + row * ldy + vc * 8) = o.u;
+    }
+  }
+}
+
+
+// Row softmax, one wave per row, the row held in registers (cols <= 8192 -> <= 16 vectors of 8 per lane).
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* X, f16* Y, long rows, int cols, int ldx, int ldy) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int tpr = cols / 8;
+  U128 u[NV];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    if (vc < tpr) {
+      u[k].u = ldg128(X + row * ldx + vc * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)u[k].e[e]);
+    }
+  }
+  mx = wave_max(mx);
+  float p[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (lane + 64 * k < tpr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p[k][e] = __builtin_amdgcn_exp2f(((float)u[k].e[e] - mx) * 1.4426950408889634f);
+        sum += p[k][e];
+      }
+    }
+  }
+  const float inv = 1.0f / wave_sum(sum);
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    if (vc < tpr) {
+      U128 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (f16)(p[k][e] * inv);
       *reinterpret_cast<uint4*>(Y + row * ldy + vc * 8) = o.u;
     }
   }
@@ -234,5 +297,22 @@ extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {
   else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_layernorm: kernel launch failed"); return ME_EHIP; }
+  return ME_OK;
+}
+
+extern "C" int me_softmax_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream) {
+  if (!Y || !X) { me_set_error("me_softmax_rows: null pointer"); return ME_EINVAL; }
+  if (rows <= 0 || cols <= 0 || cols % 8 || cols > 8192 || ldx % 8 || ldy % 8) { me_set_error("me_softmax_rows: cols must be a multiple of 8 and <= 8192"); return ME_EINVAL; }
+  if (((uintptr_t)X | (uintptr_t)Y) & 15) { me_set_error("me_softmax_rows: misaligned pointer"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  const int nv = (cols / 8 + 63) / 64;
+  const f16* x = reinterpret_cast<const f16*>(X);
+  f16* y = reinterpret_cast<f16*>(Y);
+  (void)hipGetLastError();
+  if (nv <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, dim3(blocks), dim3(256), 0, st, x, y, (long)rows, cols, ldx, ldy);
+  else if (nv <= 8) hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(blocks), dim3(256), 0, st, x, y, (long)rows, cols, ldx, ldy);
+  else hipLaunchKernelGGL(softmax_rows_kernel<16>, dim3(blocks), dim3(256), 0, st, x, y, (long)rows, cols, ldx, ldy);
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_softmax_rows: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }

@@ -239,6 +239,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return out
 
 
+def softmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Row softmax of fp16 logits [rows, cols] (fp32 arithmetic); out may be x."""
+    if x.dtype != F16 or x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("softmax_rows: expected an fp16 [rows, cols] view with unit column stride")
+    if out is None:
+        out = torch.empty_like(x)
+    e0 = _pb()
+    capi.check(capi.lib().me_softmax_rows(out.data_ptr(), out.stride(0), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "me_softmax_rows")
+    _pe(e0, "softmax", 0.0, 4.0 * x.shape[0] * x.shape[1])
+    return out
+
+
 def axpy_rows(y: torch.Tensor, x: torch.Tensor, a_: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     """y = x + alpha * a_ on equal-shape [rows, cols] views (y may alias x)."""
     for t, n in ((y, "y"), (x, "x"), (a_, "a")):

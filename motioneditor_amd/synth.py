@@ -178,11 +178,56 @@ def controlnet_schema() -> "OrderedDict[str, Shape]":
     return s
 
 
+VAE_UP_CH = (512, 512, 256, 128)
+
+
+def vae_decoder_schema() -> "OrderedDict[str, Shape]":
+    """Key -> shape of the decoder half of diffusers 0.15.1 ``AutoencoderKL`` (SD-1.5 VAE: block_out_channels
+    (128, 256, 512, 512), layers_per_block 2, latent_channels 4, norm_num_groups 32) plus ``post_quant_conv``."""
+    s: "OrderedDict[str, Shape]" = OrderedDict()
+
+    def conv(p, cout, cin, k):
+        s[p + ".weight"] = (cout, cin, k, k)
+        s[p + ".bias"] = (cout,)
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cout, cin, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cout, cin, 1)
+
+    conv("post_quant_conv", 4, 4, 1)
+    conv("decoder.conv_in", 512, 4, 3)
+    resnet("decoder.mid_block.resnets.0", 512, 512)
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", 512)
+    for n in ("query", "key", "value", "proj_attn"):
+        s[f"{a}.{n}.weight"] = (512, 512)
+        s[f"{a}.{n}.bias"] = (512,)
+    resnet("decoder.mid_block.resnets.1", 512, 512)
+    prev = 512
+    for i, c in enumerate(VAE_UP_CH):
+        for j in range(3):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i < 3:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", c, c, 3)
+        prev = c
+    norm("decoder.conv_norm_out", 128)
+    conv("decoder.conv_out", 3, 128, 3)
+    return s
+
+
 # ---------------------------------------------------------------------------------------------
 # deterministic synthetic tensors
 # ---------------------------------------------------------------------------------------------
 _RESIDUAL_OUT = ("to_out.0.weight", "proj_out.weight", "conv2.weight", "ff.net.2.weight", "temp_conv1.weight", "temp_conv2.weight",
-                 "block1.weight", "block2.weight", "conv_shortcut.weight")
+                 "block1.weight", "block2.weight", "conv_shortcut.weight", "proj_attn.weight")
 
 
 def synth_tensor(name: str, shape: Shape, seed: int = 33) -> np.ndarray:

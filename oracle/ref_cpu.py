@@ -556,3 +556,62 @@ def denoise_step(unet_sd: SD, cn_sd: Optional[SD], ddim: DDIM, latents: torch.Te
     if taps is not None:
         taps["noise_pred"] = eps
     return ddim.step(eps, t, latents)                             # :648
+
+
+# --------------------------------------------------------------------------------------------
+# AutoencoderKL.decode (diffusers 0.15.1 -- NOT in the reference tree; PARITY UNPINNED).
+# Restated from the published SD-1.5 VAE decoder (diffusers `models/vae.py` Decoder, `unet_2d_blocks.py`
+# UNetMidBlock2D / UpDecoderBlock2D, `resnet.py` ResnetBlock2D with temb=None, `attention.py` AttentionBlock);
+# call site: pipeline_motion_editor.py:346-355 (`decode_latents`), per frame.
+# --------------------------------------------------------------------------------------------
+VAE_UP_CH = (512, 512, 256, 128)     # reversed block_out_channels (128, 256, 512, 512)
+
+
+def _conv2d(sd: SD, p: str, x: torch.Tensor, padding: int = 1) -> torch.Tensor:
+    return F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], padding=padding)
+
+
+def vae_resnet(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """ResnetBlock2D, temb None, groups 32, eps 1e-6, output_scale_factor 1."""
+    h = F.silu(F.group_norm(x, 32, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-6))
+    h = _conv2d(sd, p + ".conv1", h)
+    h = F.silu(F.group_norm(h, 32, sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-6))
+    h = _conv2d(sd, p + ".conv2", h)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = _conv2d(sd, p + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+def vae_attention(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """AttentionBlock, one head of width C: softmax(q k^T / sqrt(C)) v, proj_attn, + residual."""
+    b, c, hh, ww = x.shape
+    n = F.group_norm(x, 32, sd[p + ".group_norm.weight"], sd[p + ".group_norm.bias"], 1e-6).reshape(b, c, hh * ww).transpose(1, 2)
+    q, k, v = _lin(sd, p + ".query", n), _lin(sd, p + ".key", n), _lin(sd, p + ".value", n)
+    a = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (1.0 / math.sqrt(c)), dim=-1)
+    o = _lin(sd, p + ".proj_attn", torch.bmm(a, v))
+    return o.transpose(1, 2).reshape(b, c, hh, ww) + x
+
+
+def vae_decode(sd: SD, z: torch.Tensor) -> torch.Tensor:
+    """z [n,4,h,w] (already divided by 0.18215) -> image [n,3,8h,8w]: post_quant_conv (1x1), Decoder."""
+    x = _conv2d(sd, "post_quant_conv", z, padding=0)
+    x = _conv2d(sd, "decoder.conv_in", x)
+    x = vae_resnet(sd, "decoder.mid_block.resnets.0", x)
+    x = vae_attention(sd, "decoder.mid_block.attentions.0", x)
+    x = vae_resnet(sd, "decoder.mid_block.resnets.1", x)
+    for i in range(4):
+        for j in range(3):
+            x = vae_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}", x)
+        if i < 3:
+            x = _conv2d(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    x = F.silu(F.group_norm(x, 32, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], 1e-6))
+    return _conv2d(sd, "decoder.conv_out", x)
+
+
+def decode_latents(sd: SD, latents: torch.Tensor) -> torch.Tensor:
+    """pipeline_motion_editor.py:346-355: [b,4,f,h,w] latents -> [b,3,f,8h,8w] video in [0,1]."""
+    b, c, f, h, w = latents.shape
+    x = (1 / 0.18215) * latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    v = vae_decode(sd, x)
+    v = v.reshape(b, f, *v.shape[1:]).permute(0, 2, 1, 3, 4)
+    return (v / 2 + 0.5).clamp(0, 1)

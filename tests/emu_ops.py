@@ -222,6 +222,14 @@ def timestep_embed(rows, dim, t, device):
     return torch.cat([torch.cos(ang), torch.sin(ang)])[None].repeat(rows, 1).to(_EMU_DTYPE)
 
 
+def softmax_rows(x, out=None):
+    y = torch.softmax(x.float(), dim=-1).to(_EMU_DTYPE)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def cfg_ddim(latents, eps_rows, *, guidance, ca, cb):
     nb, C, f, h, w = latents.shape
     e = eps_rows.float()[:, :C].reshape(2 * nb, f, h * w, C).permute(0, 3, 1, 2).reshape(2 * nb, C, f, h, w)

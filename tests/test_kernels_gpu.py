@@ -279,6 +279,21 @@ def test_layernorm(ops, C, rows):
     check(ops.layernorm(cu(x), cu(gm), cu(bt)), emu.layernorm(x, gm, bt), f"layernorm C={C}")
 
 
+@pytest.mark.parametrize("rows,cols", [(64, 64), (130, 1024), (77, 4096), (9, 8192), (33, 72)])
+def test_softmax_rows(ops, rows, cols):
+    # peaked rows: the largest probability carries the fp16 rounding error, so the max-abs criterion is relative to
+    # the output's largest value, not its mean
+    x = (rnd(rows, cols, seed=1) * 4).half()
+    mx = MAX_REL * cols
+    check(ops.softmax_rows(cu(x)), emu.softmax_rows(x), f"softmax {rows}x{cols}", mx=mx)
+    xg = cu(x).clone()
+    ops.softmax_rows(xg, out=xg)   # in place
+    check(xg, emu.softmax_rows(x), "softmax in place", mx=mx)
+    view = cu(rnd(rows, cols + 8, seed=2))[:, 8:]   # strided view (ldx != cols) keeps 16-byte alignment
+    check(ops.softmax_rows(view), emu.softmax_rows(view.cpu()), "softmax strided", mx=mx)
+    assert float((ops.softmax_rows(cu(x)).float().sum(1) - 1).abs().max()) < 2e-3
+
+
 # ------------------------------------------------------------------ element-wise
 def test_elementwise_family(ops):
     x, a = rnd(300, 640, seed=1), rnd(300, 640, seed=2)

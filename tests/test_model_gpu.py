@@ -196,6 +196,22 @@ def test_ddim_inversion_vs_reference_golden(unet):
     assert e3 <= STEP_TOL, e3
 
 
+def test_vae_decode_vs_cpu_oracle():
+    """SURVEY 8f rank 2 (parity unpinned: diffusers AutoencoderKL is not in the reference tree): decoder on the HIP
+    path vs oracle/ref_cpu.py::vae_decode, two 16x16 latent frames -> 128x128 images."""
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from oracle import ref_cpu
+    sd_np = synth.synth_state_dict(synth.vae_decoder_schema(), salt="vae.")
+    z = torch.from_numpy(synth.synth_normal("vae.z", (2, 4, 16, 16), 33))
+    with torch.no_grad():
+        want = ref_cpu.vae_decode({k: torch.from_numpy(v) for k, v in sd_np.items()}, z)
+    got = AutoencoderKL(sd_np, device="cuda").decode(z.cuda()).sample.float().cpu()
+    e = rel_l2(got, want)
+    record("vae_decode", e)
+    assert got.shape == (2, 3, 128, 128) and e <= 5e-3, e
+
+
 def test_properties_at_larger_size(unet):
     """Size-independent checks on a bigger clip (B=4, f=16, 32x32 latents): (1) determinism; (2) the
     reconstruction rows do not depend on the editing rows' inputs (K/V injection is one-way);

@@ -1,13 +1,9 @@
 #!/bin/bash
 cd /root/repo
-for n in 2048 1024 512 256; do
-echo "GN blocks $n"
-ME_GN_BLOCKS=$n timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "softmax or groupnorm" 2>&1 | tail -3
+timeout 600 python bench.py --vae-decode --steps 2 --warmup 1 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())
-print('main', d['ms_per_step'], d['kernel_families']['groupnorm'])"
-ME_GN_BLOCKS=$n timeout 600 python bench.py --inversion --no-cpu-baseline 2>&1 | tail -1 | python -c "
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_families'])"
+timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())
-print('inv ', d['ms_per_step'], d['kernel_families']['groupnorm'])"
-done
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_families']['groupnorm'])"
