@@ -56,3 +56,26 @@ def test_unet_two_branch_with_editors_matches_reference_golden(emu, unet_sd_np, 
     # per-stage checksums for bisecting (abs-mean of each skip / motion residual)
     for i, s in enumerate(taps["skips"]):
         assert abs(float(s.abs().mean()) - g["skip_stats"][i, 1]) < 1e-3 * g["skip_stats"][i, 1]
+
+
+def test_zero_temporal_conv_is_skipped_and_equals_running_it(emu, unet_sd_np, monkeypatch):
+    """Real checkpoints keep TemporalConv at its zero initialisation (resnet_2d.py:15-16): the launch graph skips those
+    GEMMs; the oracle executes them with zero weights.  Same output, and not a single tconv launch."""
+    from oracle import ref_cpu
+    sd0 = {k: (np.zeros_like(v) if ".temp_conv" in k and not k.startswith("controlnet_adapter.") else v) for k, v in unet_sd_np.items()}
+    c = synth.make_case_inputs("single", B=2, f=8, h=16, w=16)
+    calls = {"tconv": 0}
+    real = emu_ops.gemm
+
+    def counting(x, w, **kw):
+        if kw.get("tconv") is not None:
+            calls["tconv"] += 1
+        return real(x, w, **kw)
+
+    monkeypatch.setattr(emu_ops, "gemm", counting)
+    out = UNet2DConditionModel(sd0, device="cpu", dtype=torch.float32)(c["sample"], c["t"], c["ehs"]).sample
+    assert calls["tconv"] == 0
+    with torch.no_grad():
+        want = ref_cpu.unet_forward({k: torch.from_numpy(v) for k, v in sd0.items()}, c["sample"], c["t"], c["ehs"])
+    assert max_rel(out, want) < 2e-4
+
