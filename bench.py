@@ -110,6 +110,7 @@ def main():
                     help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
     ap.add_argument("--vae-decode", action="store_true",
                     help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     args = ap.parse_args()
@@ -171,6 +172,7 @@ def main():
     n_clips = 1 if frame_par else (world // 2 if cfg_par else world)
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (CFG-parallel) or for all ranks (frames)
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"])
+    pipe.overlap_controlnet = not args.no_overlap
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
     if frame_par:   # this rank's frames only
@@ -232,7 +234,7 @@ def main():
                "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
-                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv), "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
+                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv), "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
                                                                           f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
                                                                           if cfg_par else (f"frames{world}: one clip, {f // world} frames per GPU; RCCL all-gather of K|V (attn1, adapter, temporal attention), "

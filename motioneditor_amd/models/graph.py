@@ -301,7 +301,7 @@ def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
 
 def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
                  mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
-                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False) -> Act:
+                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False, res_ready=None) -> Act:
     """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
     ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
     Returns eps rows [(B f N), 4] as an Act."""
@@ -332,6 +332,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
         taps["skips"] = [s.t.clone() for s in skips]
 
     if down_res is not None:
+        if res_ready is not None:   # the ControlNet residuals were produced on a side stream (pipeline.overlap_controlnet)
+            torch.cuda.current_stream().wait_event(res_ready)
         motion = []
         for i, (s, r) in enumerate(zip(skips, down_res)):
             if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)

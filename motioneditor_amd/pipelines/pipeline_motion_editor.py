@@ -40,6 +40,11 @@ class MotionEditorPipeline:
         # identical latents, images and prompt pattern and produce identical residuals: compute one, use it twice.
         # Set False to execute the redundant second entry exactly as the reference does.
         self.dedup_controlnet = True
+        # ControlNet feeds the UNet only after its down path (the adapter consumes the residuals, unet_2d_condition.py:477-494):
+        # run it on a second HIP stream beside the UNet's down blocks; its small grids (24-frame batch) fill CUs the
+        # UNet's tile tails leave idle.  The UNet waits on an event right before the adapter.
+        self.overlap_controlnet = True
+        self._side_stream = None
 
     @property
     def _execution_device(self):
@@ -154,20 +159,34 @@ class MotionEditorPipeline:
         text_embeddings_input [4,77,768] = [uncond, uncond, cond_recon, cond_edit]."""
         nb = latents.shape[0]
         x4 = torch.cat([latents] * 2)                                     # :605 (scale_model_input is the identity for DDIM)
-        down = mid = None
+        down = mid = ready = None
         two = False
         if self.controlnet is not None and images is not None:
             prompt = text_embeddings_input[[1, 3]]                         # :615; .repeat(f,1,1) on "(b f)" rows -> row r reads r % 2 (:621)
             f = latents.shape[2]
-            if self.dedup_controlnet and f % 2 == 0:
-                # one entry; the UNet graph broadcasts it to both edit rows (and shares the adapter's x-only half)
-                down, mid = self.controlnet.forward_rows(x4, [1], t, prompt, images[:images.shape[0] // 2], controlnet_conditioning_scale)
+
+            def run_controlnet():
+                if self.dedup_controlnet and f % 2 == 0:
+                    # one entry; the UNet graph broadcasts it to both edit rows (and shares the adapter's x-only half)
+                    return self.controlnet.forward_rows(x4, [1], t, prompt, images[:images.shape[0] // 2], controlnet_conditioning_scale)
+                return self.controlnet.forward_rows(x4, [1, 3], t, prompt, images, controlnet_conditioning_scale)   # :613-625
+
+            if self.overlap_controlnet and x4.is_cuda and taps is None:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream()
+                main = torch.cuda.current_stream()
+                self._side_stream.wait_stream(main)
+                with torch.cuda.stream(self._side_stream):
+                    down, mid = run_controlnet()
+                ready = self._side_stream.record_event()
+                for r in list(down) + [mid]:
+                    r.record_stream(main)
             else:
-                down, mid = self.controlnet.forward_rows(x4, [1, 3], t, prompt, images, controlnet_conditioning_scale)   # :613-625
+                down, mid = run_controlnet()
             two = True                                                     # mid residual scattered as [0, m0, 0, m1] (:628-629)
             if taps is not None:
                 taps["cn_down"], taps["cn_mid"] = [d.clone() for d in down], mid.clone()
-        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps)   # :632-640
+        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps, res_ready=ready)   # :632-640
         if taps is not None:
             taps["eps_rows"] = eps.t.clone()
         ca, cb = self.scheduler.coeffs(int(t))

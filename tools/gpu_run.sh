@@ -1,9 +1,9 @@
 #!/bin/bash
 cd /root/repo
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "softmax or groupnorm" 2>&1 | tail -3
-timeout 600 python bench.py --vae-decode --steps 2 --warmup 1 2>&1 | tail -1 | python -c "
+for fl in "" "--no-overlap" "" "--no-overlap"; do
+echo "flags: $fl"
+timeout 600 python bench.py --no-cpu-baseline $fl 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_families'])"
-timeout 600 python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_families']['groupnorm'])"
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+done
+timeout 900 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "denoise_step or six" 2>&1 | tail -2
