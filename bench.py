@@ -172,7 +172,7 @@ def main():
     n_clips = 1 if frame_par else (world // 2 if cfg_par else world)
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (CFG-parallel) or for all ranks (frames)
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"])
-    pipe.overlap_controlnet = not args.no_overlap
+    pipe.overlap_controlnet = pipe.overlap_adapter = not args.no_overlap
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
     if frame_par:   # this rank's frames only

@@ -9,6 +9,7 @@ are the same buffer.
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Sequence
 
@@ -301,7 +302,7 @@ def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
 
 def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
                  mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
-                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False, res_ready=None) -> Act:
+                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False, res_ready=None, side_stream=None) -> Act:
     """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
     ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
     Returns eps rows [(B f N), 4] as an Act."""
@@ -331,35 +332,49 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     if taps is not None:
         taps["skips"] = [s.t.clone() for s in skips]
 
+    adapter_done = None
     if down_res is not None:
-        if res_ready is not None:   # the ControlNet residuals were produced on a side stream (pipeline.overlap_controlnet)
+        # The adapter (12 blocks, one per skip) feeds the UP path only, and the mid block in between runs tiny grids
+        # (M = B f 64 rows): with a side stream -- the one ControlNet already ran on, so its residuals are ordered --
+        # the adapter executes beside the mid block and the up path waits on an event.
+        side = side_stream if (side_stream is not None and taps is None and shard is None and sample.is_cuda) else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)               # every skip is complete
+            for sk in skips:
+                sk.t.record_stream(side)
+        elif res_ready is not None:              # ControlNet residuals produced on another stream
             torch.cuda.current_stream().wait_event(res_ready)
-        motion = []
-        for i, (s, r) in enumerate(zip(skips, down_res)):
-            if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
-                n = s.f * s.N
-                src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
-                for k, eb in enumerate(edit_rows):
-                    ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
-                shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard))
-            else:            # (unet_2d_condition.py:483-485)
-                motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard))
-        if taps is not None:
-            taps["motion"] = [m.clone() for m in motion]
-        new_skips = []
-        for i, (s, m) in enumerate(zip(skips, motion)):
-            tgt = s
-            if i == len(skips) - 1:  # the last skip is also the mid block's input: keep that one un-modified
-                tgt = s.like(s.t.clone())
-            if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
-                n = s.f * s.N
-                for k, eb in enumerate(edit_rows):
-                    ops.axpy_rows(tgt.rows_of(eb), tgt.rows_of(eb), m[k * n:(k + 1) * n])
-            else:
-                ops.axpy_rows(tgt.t, tgt.t, m)
-            new_skips.append(tgt)
-        skips = new_skips
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            motion = []
+            for i, (s, r) in enumerate(zip(skips, down_res)):
+                if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
+                    n = s.f * s.N
+                    src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
+                    for k, eb in enumerate(edit_rows):
+                        ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
+                    shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
+                    motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard))
+                else:            # (unet_2d_condition.py:483-485)
+                    motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard))
+            if taps is not None:
+                taps["motion"] = [m.clone() for m in motion]
+            new_skips = []
+            for i, (s, m) in enumerate(zip(skips, motion)):
+                tgt = s
+                if i == len(skips) - 1:  # the last skip is also the mid block's input: keep that one un-modified
+                    tgt = s.like(s.t.clone())
+                if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
+                    n = s.f * s.N
+                    for k, eb in enumerate(edit_rows):
+                        ops.axpy_rows(tgt.rows_of(eb), tgt.rows_of(eb), m[k * n:(k + 1) * n])
+                else:
+                    ops.axpy_rows(tgt.t, tgt.t, m)
+                new_skips.append(tgt)
+            skips = new_skips
+        if side is not None:
+            adapter_done = side.record_event()
+            skips[-1].t.record_stream(main)      # the cloned last skip was allocated on the side stream
 
     n = "mid_block.resnets.0"
     x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
@@ -377,6 +392,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     if taps is not None:
         taps["mid"] = x.t.clone()
 
+    if adapter_done is not None:
+        torch.cuda.current_stream().wait_event(adapter_done)
     for i in range(4):
         for j in range(3):
             s = skips.pop()

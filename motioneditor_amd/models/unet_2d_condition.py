@@ -68,11 +68,11 @@ class UNet2DConditionModel:
         return ops.nchw5_to_rows(res.to(self.device))
 
     def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None,
-                     normal_infer: bool = False, res_ready=None) -> graph.Act:
+                     normal_infer: bool = False, res_ready=None, side_stream=None) -> graph.Act:
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
         return graph.unet_forward(self.P, sample.to(self.device), t, encoder_hidden_states.to(self.device), down_res=down_rows, mid_res=mid_rows,
                                   two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps, shard=shard,
-                                  normal_infer=normal_infer, res_ready=res_ready)
+                                  normal_infer=normal_infer, res_ready=res_ready, side_stream=side_stream)
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None, return_dict: bool = True,
                 normal_infer: bool = False, skeleton=None, down_block_additional_residuals=None, mid_block_additional_residual=None,

@@ -42,8 +42,10 @@ class MotionEditorPipeline:
         self.dedup_controlnet = True
         # ControlNet feeds the UNet only after its down path (the adapter consumes the residuals, unet_2d_condition.py:477-494):
         # run it on a second HIP stream beside the UNet's down blocks; its small grids (24-frame batch) fill CUs the
-        # UNet's tile tails leave idle.  The UNet waits on an event right before the adapter.
+        # UNet's tile tails leave idle.  The adapter then runs on the same side stream beside the mid block (tiny grids),
+        # and the up path waits on an event.
         self.overlap_controlnet = True
+        self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
         self._side_stream = None
 
     @property
@@ -186,7 +188,8 @@ class MotionEditorPipeline:
             two = True                                                     # mid residual scattered as [0, m0, 0, m1] (:628-629)
             if taps is not None:
                 taps["cn_down"], taps["cn_mid"] = [d.clone() for d in down], mid.clone()
-        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps, res_ready=ready)   # :632-640
+        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps, res_ready=ready,
+                                     side_stream=self._side_stream if (ready is not None and self.overlap_adapter) else None)   # :632-640
         if taps is not None:
             taps["eps_rows"] = eps.t.clone()
         ca, cb = self.scheduler.coeffs(int(t))
