@@ -318,45 +318,57 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
 
     x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
                            img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
-    skips = [x]
+    # Adapter block i needs skip i and ControlNet residual i only, and its output is consumed by the UP path: with a side
+    # stream (the one ControlNet ran on, so the residuals are ordered) every block is enqueued there as soon as its skip
+    # exists and runs beside the rest of the down path and the mid block; the skips themselves are updated after the
+    # down path (main may still be reading them), and the up path waits on one event.
+    side = side_stream if (side_stream is not None and down_res is not None and taps is None and shard is None and sample.is_cuda) else None
+    main = torch.cuda.current_stream() if side is not None else None
+    motion: List[torch.Tensor] = []
+
+    def adapter_for(i: int, s: Act) -> torch.Tensor:
+        r = down_res[i]
+        if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
+            n = s.f * s.N
+            src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
+            for k, eb in enumerate(edit_rows):
+                ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
+            shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
+            return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard)
+        return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard)   # (unet_2d_condition.py:483-485)
+
+    def push_skip(s: Act) -> None:
+        skips.append(s)
+        if side is not None:
+            s.t.record_stream(side)
+            side.wait_event(main.record_event())
+            with torch.cuda.stream(side):
+                motion.append(adapter_for(len(skips) - 1, s))
+
+    skips: List[Act] = []
+    push_skip(x)
     for i in range(4):
         for j in range(2):
             n = f"down_blocks.{i}.resnets.{j}"
             x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
             if DOWN_HAS_ATTN[i]:
                 x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", **kw)
-            skips.append(x)
+            push_skip(x)
         if i < 3:
             x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
-            skips.append(x)
+            push_skip(x)
     if taps is not None:
         taps["skips"] = [s.t.clone() for s in skips]
 
     adapter_done = None
     if down_res is not None:
-        # The adapter (12 blocks, one per skip) feeds the UP path only, and the mid block in between runs tiny grids
-        # (M = B f 64 rows): with a side stream -- the one ControlNet already ran on, so its residuals are ordered --
-        # the adapter executes beside the mid block and the up path waits on an event.
-        side = side_stream if (side_stream is not None and taps is None and shard is None and sample.is_cuda) else None
         if side is not None:
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)               # every skip is complete
-            for sk in skips:
-                sk.t.record_stream(side)
+            side.wait_stream(main)               # main is past its last read of every skip: safe to add the motion in place
         elif res_ready is not None:              # ControlNet residuals produced on another stream
             torch.cuda.current_stream().wait_event(res_ready)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-            motion = []
-            for i, (s, r) in enumerate(zip(skips, down_res)):
-                if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
-                    n = s.f * s.N
-                    src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
-                    for k, eb in enumerate(edit_rows):
-                        ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
-                    shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
-                    motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard))
-                else:            # (unet_2d_condition.py:483-485)
-                    motion.append(adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard))
+            if side is None:
+                motion = [adapter_for(i, s) for i, s in enumerate(skips)]
             if taps is not None:
                 taps["motion"] = [m.clone() for m in motion]
             new_skips = []
