@@ -146,15 +146,16 @@ def _ln(P: Packed, p: str, x: torch.Tensor) -> torch.Tensor:
     return ops.layernorm(x, P.vec(p + ".weight"), P.vec(p + ".bias"))
 
 
-def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard):
+def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int = 0):
     """q, k, v row views of the self-attention projections of `n`.  Unsharded: one fused [rows, 3C] GEMM.  Frame-sharded:
-    q stays local, k|v is projected into a contiguous [rows, 2C] tensor and all-gathered over the frame shards."""
+    q stays local, k|v is projected into a contiguous [rows, 2C] tensor and completed by the shard view (all-gather over
+    the frame shards, or the previous rank's last frame only for spatial attn1)."""
     names = [p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]
     if shard is None:
         qkv = ops.gemm(n, P.fused(names))
         return qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     q = ops.gemm(n, P.mat(names[0]))
-    kv = shard.all_gather_rows(ops.gemm(n, P.fused(names[1:])))
+    kv = shard.gather_kv(ops.gemm(n, P.fused(names[1:])), B, N, ops.copy_rows)
     return q, kv[:, :C], kv[:, C:]
 
 
@@ -178,8 +179,9 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
     t, C = x.t, x.C
     dh = C // HEADS
     # --- attn1 (MotionFrameAttention / patched closure, attention_2d.py:705-768, fully_control_utils.py:113-161)
-    sh1 = shard if sc_attn else None   # plain per-frame self-attention (ControlNet) needs no other frames
-    q, k, v = _qkv(P, p + ".attn1", _ln(P, p + ".norm1", t), C, sh1)
+    # plain per-frame self-attention (ControlNet, normal_infer) needs no other frames; [prev | cur] needs ONE halo frame
+    sh1 = shard.prev_frame_view() if (shard is not None and sc_attn) else None
+    q, k, v = _qkv(P, p + ".attn1", _ln(P, p + ".norm1", t), C, sh1, x.B, x.N)
     call = AttnCall(q, k, v, x.B, x.f, x.N, dh, x.N, False, sh1)
     if spatial is not None:
         a = spatial(call=call, is_cross=False, place_in_unet=place, num_heads=HEADS)

@@ -2,9 +2,11 @@
 four batch rows, so the reconstruction -> editing K/V injection stays rank-local.  The cross-frame couplings of the
 reference become these exchanges (torch.distributed; backend "nccl" = RCCL over xGMI on MI355X, "gloo" in the CPU tests):
 
-  * spatial attn1 (previous-frame keys), adapter sparse-causal attention (first / previous frame of an 8-frame
-    chunk), temporal attention (all earlier frames): ONE all-gather of the layer's K|V rows; the attention kernels
-    address the gathered tensor part-major through their key-segment tables / kv_parts argument;
+  * spatial attn1 (keys of the previous frame only, attention_2d.py:732-740 and the edited variant): a ONE-frame halo
+    of the layer's K|V rows from the previous rank (point-to-point; `PrevFrameHalo`), 1 / f_loc of the all-gather;
+  * adapter sparse-causal attention (first / previous frame of an 8-frame chunk) and temporal attention (all earlier
+    frames): ONE all-gather of the layer's K|V rows; the attention kernels address the gathered tensor part-major
+    through their key-segment tables / kv_parts argument;
   * TemporalConv k=3: one-frame halos from both neighbours (point-to-point);
   * ResnetBlock2D / conv_norm_out GroupNorm (statistics span all frames): all-reduce of (sum, sum of squares).
 ControlNet, cross-attention, feed-forward, spatial convolutions, per-frame GroupNorm, CFG and DDIM are rank-local.
@@ -44,6 +46,15 @@ class FrameShard:
         """kv item index of (batch row b, GLOBAL frame g) inside an all-gathered [world][B*f_loc items] tensor."""
         return (g // self.f_loc) * (B * self.f_loc) + b * self.f_loc + g % self.f_loc
 
+    layout = "gather"   # part of the key-segment cache key (segments._gi)
+
+    def gather_kv(self, kv: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
+        return self.all_gather_rows(kv)
+
+    def prev_frame_view(self) -> "PrevFrameHalo":
+        """The view attn1 uses: only the previous rank's LAST frame is fetched."""
+        return PrevFrameHalo(self)
+
     # ---- one-frame halos for the temporal convolutions --------------------------------------------------
     def exchange_halos(self, x_ext: torch.Tensor, B: int, npix: int, copy_rows) -> tuple:
         """x_ext rows = [B*f_loc*npix local | B*npix halo of the previous rank | B*npix halo of the next rank].
@@ -68,3 +79,42 @@ class FrameShard:
             for r in dist.batch_isend_irecv(ops_):
                 r.wait()
         return (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)
+
+
+class PrevFrameHalo:
+    """K|V of this rank's frames preceded by a halo block with the previous rank's last frame of every batch row:
+    rows = [B halo items | B * f_loc local items] (an item = npix rows).  Spatial attn1 -- plain [prev | cur] and the
+    edited [src prev | src cur | own cur] -- reads nothing else ("1-frame halo send/recv to next rank")."""
+
+    layout = "halo"
+
+    def __init__(self, shard: FrameShard):
+        self.s = shard
+        self.world, self.rank, self.f_loc, self.f_total, self.frame0 = shard.world, shard.rank, shard.f_loc, shard.f_total, shard.frame0
+
+    def item(self, B: int, b: int, g: int) -> int:
+        if g == self.frame0 - 1 and self.rank > 0:
+            return b
+        if not (self.frame0 <= g < self.frame0 + self.f_loc):
+            raise IndexError(f"frame {g} is neither local to rank {self.rank} nor its one-frame halo")
+        return B + b * self.f_loc + (g - self.frame0)
+
+    def gather_kv(self, kv: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+        s = self.s
+        ext = torch.empty(((B + B * self.f_loc) * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
+        copy_rows(ext[B * npix:], kv)
+        ops_ = []
+        if self.rank < self.world - 1:
+            last = torch.empty((B * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
+            for b in range(B):
+                copy_rows(last[b * npix:(b + 1) * npix], kv[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
+            ops_.append(dist.P2POp(dist.isend, last, s._ranks[self.rank + 1], s.group))
+        if self.rank > 0:
+            ops_.append(dist.P2POp(dist.irecv, ext[:B * npix], s._ranks[self.rank - 1], s.group))
+        else:
+            copy_rows(ext[:B * npix], kv[:B * npix])      # never addressed (frame 0 has no predecessor); keep it finite
+        if ops_:
+            for r in dist.batch_isend_irecv(ops_):
+                r.wait()
+        return ext
+

@@ -43,10 +43,11 @@ def cross_interleaved(n_items: int, n_text: int, device, row_offset: int = 0):
 
 
 def _gi(shard, B, f):
-    """(b, GLOBAL frame) -> kv item index: plain (b*f + g) unsharded, part-major into the all-gathered K|V when sharded."""
+    """(b, GLOBAL frame) -> kv item index: plain (b*f + g) unsharded; when sharded, whatever layout the shard view gives the
+    gathered K|V (parallel.FrameShard: part-major all-gather; parallel.PrevFrameHalo: [halo | local])."""
     if shard is None:
         return (lambda b, g: b * f + g), 0, ()
-    return (lambda b, g: shard.item(B, b, g)), shard.frame0, (shard.world, shard.rank)
+    return (lambda b, g: shard.item(B, b, g)), shard.frame0, (shard.world, shard.rank, getattr(shard, "layout", "gather"))
 
 
 def prev_cur(B: int, f: int, device, shard=None):

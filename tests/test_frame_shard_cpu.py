@@ -72,3 +72,40 @@ def test_frame_sharded_step_equals_single_process(tmp_path, f):
     mp.spawn(_worker, args=(2, port, f, str(out)), nprocs=2, join=True)
     err = torch.load(out)["err"]
     assert err < 1e-4, err
+
+
+def test_prev_frame_halo_view_indexing_and_segment_tables():
+    """attn1 under frame sharding reads [halo | local] K|V, not the all-gather: item map and the key-segment tables."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from motioneditor_amd import segments
+    from motioneditor_amd.parallel import PrevFrameHalo
+
+    B, f_loc = 2, 4
+    for rank in (0, 1, 2):
+        sh = SimpleNamespace(world=3, rank=rank, f_loc=f_loc, f_total=12, frame0=rank * f_loc, group=None, _ranks=[0, 1, 2])
+        hv = PrevFrameHalo(sh)
+        assert hv.item(B, 1, rank * f_loc + 2) == B + 1 * f_loc + 2
+        if rank > 0:
+            assert hv.item(B, 1, rank * f_loc - 1) == 1          # the halo item of batch row 1
+        for bad in (rank * f_loc + f_loc, rank * f_loc - 2):
+            if bad >= 0:
+                try:
+                    hv.item(B, 0, bad)
+                    raise AssertionError("out-of-view frame accepted")
+                except IndexError:
+                    pass
+        si, sm = segments.prev_cur(B, f_loc, torch.device("cpu"), hv)
+        si = si.reshape(B, f_loc, 2)
+        for b in range(B):
+            for i in range(f_loc):
+                cur = B + b * f_loc + i
+                prev = (b if rank > 0 else cur) if i == 0 else cur - 1      # global frame 0 attends itself twice
+                assert si[b, i].tolist() == [prev, cur], (rank, b, i, si[b, i].tolist())
+    # the table cache distinguishes the two layouts of one rank
+    g = SimpleNamespace(world=3, rank=1, f_loc=f_loc, f_total=12, frame0=f_loc, layout="gather", item=lambda B_, b, gg: (gg // f_loc) * (B_ * f_loc) + b * f_loc + gg % f_loc)
+    a, _ = segments.prev_cur(B, f_loc, torch.device("cpu"), g)
+    h, _ = segments.prev_cur(B, f_loc, torch.device("cpu"), PrevFrameHalo(SimpleNamespace(world=3, rank=1, f_loc=f_loc, f_total=12, frame0=f_loc, group=None, _ranks=[0, 1, 2])))
+    assert a.tolist() != h.tolist()
