@@ -129,6 +129,8 @@ def main():
     from motioneditor_amd import capi, ops, synth
     capi.lib()  # no HIP library -> hard failure (no fallback path exists)
     if args.vae_decode:
+        if dist_on:
+            raise SystemExit("--vae-decode is a single-GPU secondary measurement")
         from motioneditor_amd.models.vae import AutoencoderKL
         vae = AutoencoderKL.from_synthetic(device)
         z = torch.from_numpy(synth.synth_normal("bench.vae", (args.frames, 4, args.latent, args.latent), 33)).to(device)
