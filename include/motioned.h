@@ -67,7 +67,10 @@ typedef struct me_gemm_args {
    * frames_total == 0 means unsharded (frame0 = 0, frames_total = frames, no halos). */
   int32_t frames, npix, chunk;
   int32_t frame0, frames_total, halo_prev, halo_next;
-  /* epilogue (all optional, applied in this order) */
+  /* epilogue (all optional, applied in this order).  Arithmetic: fp32 accumulation of alpha * (X W^T) + bias (the
+   * bias enters as the accumulators' initial value); without an activation the tile is then rounded to fp16 and
+   * rowvec / res / res2 are added in fp16 -- the roundings the reference's half-precision `conv(x) + temb`,
+   * `attn(x) + x` perform; with act != 0 every term is added in fp32 and rounded once.  res (or res2) may alias C. */
   const void* bias;   /* fp16 [N]                                              */
   const void* rowvec; /* fp16: += rowvec[(m / rows_per_vec) * ldrv + n]        */
   int32_t ldrv, rows_per_vec;
