@@ -244,7 +244,7 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_clips * args.steps / dt
         out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
-                          "denoise-steps/sec, 24f x 512^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
+                          f"denoise-steps/sec, {f}f x {8 * h}^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
