@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 1
+#define ME_ABI_VERSION 2
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -132,6 +132,11 @@ typedef struct me_attn_args {
   const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL_CUR / DUAL_PREV)     */
   float scale;
   int32_t general_dual;    /* 1 when any seg_mode is DUAL_CUR / DUAL_PREV (selects the kernel built with that path) */
+  /* Required when any seg_mode is ME_SEG_DUAL_BIN: fp32 scratch [n_kv_items][heads*dh].  me_attn fills it with the
+   * per-kv-item column sums of V (the query-independent "+1" part of every binary dual key, fully_control.py:381-413)
+   * on `stream` before the attention kernel, which adds it in its epilogue.  NULL when no segment is DUAL_BIN. */
+  void* vsum;
+  int32_t n_kv_items;      /* kv items in K / V (rows / nk); only read with vsum */
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);

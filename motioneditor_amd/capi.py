@@ -12,6 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
+ABI_VERSION = 2
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -47,6 +48,7 @@ class AttnArgs(C.Structure):
         ("heads", _i32), ("dh", _i32),
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
         ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
+        ("vsum", _vp), ("n_kv_items", _i32),
     ]
 
 
@@ -123,8 +125,8 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
-        if L.me_abi_version() != 1:
-            raise MotionedError(f"libmotioned ABI {L.me_abi_version()} != 1")
+        if L.me_abi_version() != ABI_VERSION:
+            raise MotionedError(f"libmotioned ABI {L.me_abi_version()} != {ABI_VERSION}")
         _lib = L
     return _lib
 

@@ -11,17 +11,20 @@
 // anything: a masked key has logit m*s in the foreground copy and (1-m)*s in the background copy
 // and BOTH copies carry the same (unmasked) V, so the key's total weight is exp(m s) + exp((1-m) s).
 //
-// Structure (per block: one (item, head), BQ = 64*QT queries, 4 waves x QT x 16 queries):
+// Two kernels: attn2_kernel (below the first one) serves plain and BINARY dual segments -- every launch of the model with the
+// binary masks the data ships; attn_kernel<GD = true> keeps the general, mask-reading dual modes.  Common structure
+// (per block: one (item, head), waves x QT x 16 queries):
 //   S^T = K Q^T   : MFMA A = K tile rows from LDS, B = Q fragments held in registers
 //                   -> lane (q = lane&15, g = lane>>4) holds keys t*16 + g*4 + r: row max / sum need
 //                      only 2 xor-shuffles across g; alpha and 1/l are lane-local for O^T.
-//   O^T += V^T P^T: MFMA A = V^T fragments (V is transposed into LDS while staging),
+//   O^T += V^T P^T: MFMA A = V^T fragments (attn_kernel: V transposed into LDS while staging; attn2: ds_read_b64_tr_b16),
 //                   B = P^T straight from the S^T accumulator registers (fp16), no LDS round trip:
 //                   MFMA k-slot (g, j) carries key kk*32 + (j>>2)*16 + g*4 + (j&3) for BOTH operands.
 #include "me_common.h"
 #include "../../include/motioned.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -390,6 +393,424 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   }
 }
 
+
+// =====================================================================================================================
+// attn2: the production kernel for plain and BINARY-dual segments (everything except the general, non-binary masks).
+//
+// Differences to the kernel above (measured on the L0 [prev | cur] launch, 7.2 ms: MFMA 2.95 ms + staging 2.2 ms +
+// softmax 1.6 ms, NOT overlapped -- profiles/r02_attn_ablation.txt):
+//   * K and V tiles are staged by LDS-DMA (global_load_lds_dwordx4) in their ROW-MAJOR global layout: no VGPR round trip,
+//     no ds_write, no per-element transposed b16 stores.  A lane's chunk never changes between tiles, so the per-lane
+//     source offset is one register per DMA slot and a tile costs <= 3 DMA instructions per wave (dh 40).
+//     Row pitches are an ODD number of 16-byte chunks (K: dh/8 [+1], V: dh/8 + ones / pad chunk), the pad / ones chunks
+//     are written once at kernel start and skipped by the DMA (inactive lanes do not write LDS).
+//   * V^T operand-A fragments come from ds_read_b64_tr_b16 (hardware 4x4 transpose): lane (c, g) addresses row
+//     key0 + c/4, byte (c%4)*8 of a 16-column block and receives V[key0 .. key0+3][col0 + c].
+//   * DUAL_BIN segments (binary fg/bg mask: weight exp(s) + 1 per source key) run the PLAIN tile code; the "+1" part is
+//     query-independent -- sum_j V_j over the segment's keys -- and enters once, in the epilogue, from the column
+//     sums `vsum` that me_attn computes beforehand:  O = (A f1 + f2 B) / (l f1 + f2 n),  A, l relative to the running
+//     max m, m' = max(m, 0), f1 = 2^(m - m'), f2 = 2^(-m'), B = sum over the item's dual segments of vsum, n = their keys.
+// =====================================================================================================================
+// ds_read_b64_tr_b16 through inline asm: with the builtin, hipcc treats the pending LDS-DMA of the NEXT stage as a
+// may-alias write and drains vmcnt(0) in front of the first transposed read of every tile (the DMA latency then sits
+// on the critical path of each wave).  The asm form is invisible to that pass; completion is awaited by lds_wait<N>,
+// which names the destination registers so that no consumer can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ uint2 lds_tr16(unsigned addr) {
+  uint2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(uint2& r0, uint2& r1, uint2& r2, uint2& r3) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "i"(N));
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+// One LDS-DMA instruction with a lane mask: lanes whose bit is clear neither fetch nor write LDS (pad / ones chunks keep
+// their start-up contents).  Hand-written so that (a) the exec juggling is two scalar moves instead of the compare /
+// saveexec / branch sequence hipcc builds around the builtin and (b) the transfer is invisible to hipcc's waitcnt pass --
+// completion is awaited by the explicit vmcnt(0) in front of the stage barrier, nowhere else.
+__device__ __forceinline__ void dma16_masked(unsigned lds_dst, const char* base, int voff, unsigned long long mask) {
+  unsigned keep_m0;
+  unsigned long long keep_exec;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b64 exec, %5\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %3, %4\n\t"
+      "s_mov_b64 exec, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep_m0), "=&s"(keep_exec)
+      : "s"(lds_dst), "v"(voff), "s"(base), "s"(mask)
+      : "memory");
+}
+
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB>
+__global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args a) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int D32 = (DH + 31) / 32;
+  constexpr int DT = (DH + 15) / 16;
+  constexpr int CKR = DH / 8;                         // real 16-byte chunks per K / V row
+  constexpr int CK = (CKR & 1) ? CKR : CKR + 1;       // K row pitch in chunks (odd: 16 rows x one chunk column hit distinct 16-byte slots)
+  constexpr bool ONES = DT * 16 > DH;                 // spare V^T rows: row DH = all ones -> the PV MFMA also produces the softmax denominator
+  constexpr int CV = DH == 40 ? 6 : (DH == 80 ? 10 : 22);   // V row pitch in chunks (8 consecutive rows x 32 B on distinct banks)
+  constexpr int KPB = CK * 16, VPB = CV * 16;         // pitches in bytes
+  constexpr int KBYTES = KT * KPB, VBYTES = KT * VPB, SUB = KBYTES + VBYTES;   // one 64-key sub-tile: K rows, then V rows
+  constexpr int STAGE = NSUB * SUB;                   // keys per barrier = NSUB * 64
+  constexpr int NINS = CK + CV;                       // DMA instructions per sub-tile (each 64 lanes x 16 B = 1 KB of LDS image)
+  constexpr int NSLOT = (NINS + NW - 1) / NW;         // per wave
+  constexpr int BQ = 16 * QT * NW;
+  static_assert(KBYTES % 1024 == 0 && VBYTES % 1024 == 0, "stage layout");
+
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE + 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4;
+  const int l15 = lane & 15;
+
+  const int nqb = (a.nq + BQ - 1) / BQ;
+  const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
+  const int qb = w % nqb;
+  const int rest = w / nqb;
+  const int h = rest % a.heads;
+  const int item = rest / a.heads;
+
+  const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
+  const char* __restrict__ K = reinterpret_cast<const char*>(a.K);
+  const char* __restrict__ V = reinterpret_cast<const char*>(a.V);
+  f16* __restrict__ O = reinterpret_cast<f16*>(a.O);
+
+  // LDS image: zero everywhere (pad chunks, the tail of the last row a fragment read may run into), ones chunks of V
+  for (int i = tid; i < (NBUF * STAGE + 64) / 16; i += NTHR) reinterpret_cast<uint4*>(smem)[i] = zero128();
+  __syncthreads();
+  if constexpr (ONES) {
+    for (int i = tid; i < NBUF * NSUB * KT; i += NTHR)
+      *reinterpret_cast<f16*>(smem + (i / KT) * SUB + KBYTES + (i % KT) * VPB + DH * 2) = (f16)1.f;
+  }
+
+  // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8], zero beyond dh
+  f16x8 fq[QT][D32];
+  int qrow[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
+    qrow[qt] = q < a.nq ? item * a.nq + q : -1;
+#pragma unroll
+    for (int ks = 0; ks < D32; ++ks) {
+      const int d = ks * 32 + g * 8;
+      U128 u;
+      u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
+      fq[qt][ks] = u.h;
+    }
+  }
+
+  const int ntk = (a.nk + KT - 1) / KT;          // 64-key sub-tiles per segment
+  const int nst = (ntk + NSUB - 1) / NSUB;        // stages per segment
+  // the item's segment list, read once (uniform): kv item per segment, number of valid / binary-dual segments
+  int kit3[3] = {-1, -1, -1}, dual3[3] = {0, 0, 0};
+  int nvalid = 0, ndual = 0;
+#pragma unroll
+  for (int sgi = 0; sgi < 3; ++sgi) {
+    if (sgi < a.nseg && nvalid == sgi) {
+      const int v = __builtin_amdgcn_readfirstlane(a.seg_item[item * a.nseg + sgi]);
+      if (v >= 0) {
+        kit3[sgi] = v;
+        ++nvalid;
+        dual3[sgi] = __builtin_amdgcn_readfirstlane(a.seg_mode[item * a.nseg + sgi]) == ME_SEG_DUAL_BIN;
+        ndual += dual3[sgi];
+      }
+    }
+  }
+  const int T = nvalid * nst;                     // stages in total
+  const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
+
+  // DMA slots: instruction q = wave + NW i covers image bytes [q * 1024, +1024) of a sub-tile (K rows first, then V rows);
+  // lane -> chunk q * 64 + lane of that operand.  off[i] = byte offset of the lane's source chunk from the sub-tile's base
+  // pointer; msk[i] = the lanes that carry a real chunk (pad / ones chunks and unused slots are masked off).
+  auto slot_off = [&](int i, int maxkey) -> int {
+    const int q = wave + NW * i;
+    if (q >= NINS) return -1;
+    const bool isk = q < CK;
+    const int cl = (isk ? q : q - CK) * 64 + lane;
+    const int cpr = isk ? CK : CV;
+    const int key = cl / cpr, ch = cl - key * cpr;
+    if (ch >= CKR) return -1;
+    const int kc = min(key, maxkey);   // tail sub-tile: rows past nk re-read the last key (finite; their logits are masked)
+    return (kc * (isk ? a.ldk : a.ldv) + h * DH + ch * 8) * 2;
+  };
+  int off[NSLOT];
+  unsigned long long msk[NSLOT];
+#pragma unroll
+  for (int i = 0; i < NSLOT; ++i) {
+    off[i] = slot_off(i, KT - 1);
+    msk[i] = __ballot(off[i] >= 0);
+    off[i] = max(off[i], 0);
+  }
+  const unsigned smem_base = (unsigned)(size_t)smem;
+
+  int seg_l = 0, st_l = 0;    // load cursor: segment, stage inside the segment
+  const char *kptr_l = K, *vptr_l = V;
+  auto seg_base = [&]() {
+    const int kit = seg_l == 0 ? kit3[0] : (seg_l == 1 ? kit3[1] : kit3[2]);
+    kptr_l = K + (long)kit * a.nk * a.ldk * 2;
+    vptr_l = V + (long)kit * a.nk * a.ldv * 2;
+  };
+  auto dma_stage = [&](int si) {   // fetch the load cursor's stage into buffer si % NBUF, advance the cursor
+    const unsigned st = smem_base + (si & (NBUF - 1)) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+      const int kt = st_l * NSUB + j;
+      if (kt < ntk) {
+        const bool tail = (kt + 1) * KT > a.nk;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+          const int q = wave + NW * i;
+          if (q < NINS) {
+            const char* base = (q < CK ? kptr_l : vptr_l) + (long)j * KT * (q < CK ? a.ldk : a.ldv) * 2;
+            const int o = tail ? max(slot_off(i, a.nk - 1 - kt * KT), 0) : off[i];
+            dma16_masked(st + j * SUB + q * 1024, base, o, msk[i]);
+          }
+        }
+      }
+    }
+    if (++st_l == nst) {
+      st_l = 0;
+      if (++seg_l < nvalid) seg_base();
+    } else {
+      kptr_l += (long)NSUB * KT * a.ldk * 2;
+      vptr_l += (long)NSUB * KT * a.ldv * 2;
+    }
+  };
+
+  f32x4 o[QT][DT];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = NEG_BIG;
+    lrun[qt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  __syncthreads();   // LDS image initialised before the first DMA lands
+  if (T > 0) {
+    seg_base();
+    dma_stage(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  using BT = std::integral_constant<bool, true>;
+  using BF = std::integral_constant<bool, false>;
+  auto tile = [&](auto full_c, const char* st, int kt) {
+    constexpr bool FULL = decltype(full_c)::value;
+    const char* sK = st;
+    const char* sV = st + KBYTES;
+    const int kbase = kt * KT + g * 4;  // + t*16 + r
+
+    // ---- S^T = K Q^T ----
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D32; ++ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KPB + (ks * 4 + g) * 16);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
+      }
+    }
+
+    // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
+    f16x8 pf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if constexpr (!FULL) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + t * 16 + r >= a.nk) s[qt][t][r] = NEG_BIG;   // raw logit; c < 1 keeps NEG_BIG * c finite
+      }
+      float mr = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
+      mr = fmaxf(fmaxf(mr, s[qt][0][3]), s[qt][1][0]);
+      mr = fmaxf(fmaxf(mr, s[qt][1][1]), s[qt][1][2]);
+      mr = fmaxf(fmaxf(mr, s[qt][1][3]), s[qt][2][0]);
+      mr = fmaxf(fmaxf(mr, s[qt][2][1]), s[qt][2][2]);
+      mr = fmaxf(fmaxf(mr, s[qt][2][3]), s[qt][3][0]);
+      mr = fmaxf(fmaxf(mr, s[qt][3][1]), s[qt][3][2]);
+      mr = fmaxf(mr, s[qt][3][3]);
+      mr = xor32_max(xor16_max(mr));
+      const float mnew = fmaxf(mrun[qt], mr * c);
+      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+      mrun[qt] = mnew;
+      float p[4][4];
+      float psum = 0.f;
+      const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 sv = {s[qt][t][2 * h2], s[qt][t][2 * h2 + 1]};
+          const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
+          p[t][2 * h2] = __builtin_amdgcn_exp2f(x[0]);
+          p[t][2 * h2 + 1] = __builtin_amdgcn_exp2f(x[1]);
+          if constexpr (!ONES) psum += p[t][2 * h2] + p[t][2 * h2 + 1];
+        }
+      if constexpr (!ONES) lrun[qt] = lrun[qt] * alpha + psum;
+      // rescale only when some query of the wave saw its running max move (exact: alpha == 1 otherwise)
+      if (__builtin_amdgcn_readfirstlane(__any(alpha != 1.0f))) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        union { f16x2 h[4]; f16x8 v; } f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          f.h[h2] = __builtin_convertvector((f32x2){p[2 * kk][2 * h2], p[2 * kk][2 * h2 + 1]}, f16x2);
+          f.h[2 + h2] = __builtin_convertvector((f32x2){p[2 * kk + 1][2 * h2], p[2 * kk + 1][2 * h2 + 1]}, f16x2);
+        }
+        pf[qt][kk] = f.v;
+      }
+    }
+
+    // ---- O^T += V^T P^T: operand A k-slot (g, j) = key kk*32 + (j>>2)*16 + g*4 + (j&3), as P^T above ----
+    const unsigned vlane = (unsigned)(size_t)(sV + (g * 4 + (l15 >> 2)) * VPB + (l15 & 3) * 8);
+    {
+      // transposed reads one d-block ahead of the MFMAs that consume them
+      uint2 rv[2][4];   // [parity of dt][kk*2 + j]
+      auto issue = [&](auto dt_c) {
+        constexpr int dt = decltype(dt_c)::value;
+        rv[dt & 1][0] = lds_tr16<(0) * VPB + dt * 32>(vlane);
+        rv[dt & 1][1] = lds_tr16<(16) * VPB + dt * 32>(vlane);
+        rv[dt & 1][2] = lds_tr16<(32) * VPB + dt * 32>(vlane);
+        rv[dt & 1][3] = lds_tr16<(48) * VPB + dt * 32>(vlane);
+      };
+      issue(std::integral_constant<int, 0>{});
+      static_for(std::make_integer_sequence<int, DT>{}, [&](auto dt_c) {
+        constexpr int dt = decltype(dt_c)::value;
+        if constexpr (dt + 1 < DT) {
+          issue(std::integral_constant<int, dt + 1>{});
+          lds_wait<4>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+        } else {
+          lds_wait<0>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          union { uint2 u[2]; f16x8 v; } fv;
+          fv.u[0] = rv[dt & 1][kk * 2];
+          fv.u[1] = rv[dt & 1][kk * 2 + 1];
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.v, pf[qt][kk], o[qt][dt]);
+        }
+      });
+    }
+  };
+
+  const int nfull = a.nk / KT;
+  int st_c = 0;   // compute cursor: stage inside the segment
+  for (int si = 0; si < T; ++si) {
+    if (NBUF > 1 && si + 1 < T) dma_stage(si + 1);
+    const char* st = smem + (si & (NBUF - 1)) * STAGE;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+      const int kt = st_c * NSUB + j;
+      if (kt < nfull) tile(BT{}, st + j * SUB, kt);
+      else if (kt < ntk) tile(BF{}, st + j * SUB, kt);
+    }
+    if (++st_c == nst) st_c = 0;
+    if (NBUF == 1 && si + 1 < T) {
+      __syncthreads();   // single buffer: every wave is done reading it
+      dma_stage(si + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
+    __syncthreads();                                    // ... and so have everyone else's; this stage is free
+  }
+
+  // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] ----
+  const float* __restrict__ vsum = reinterpret_cast<const float*>(a.vsum);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    float l;
+    if constexpr (ONES) {   // denominator sits in accumulator row DH: tile DH/16, lanes g == (DH%16)/4, reg (DH%16)%4
+      l = __shfl(o[qt][DH / 16][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
+    } else {
+      l = xor32_sum(xor16_sum(lrun[qt]));
+    }
+    float f1 = 1.0f, f2 = 0.f;
+    if (ndual > 0) {   // wave-uniform
+      const float mp = fmaxf(mrun[qt], 0.f);
+      f1 = __builtin_amdgcn_exp2f(mrun[qt] - mp);
+      f2 = __builtin_amdgcn_exp2f(-mp);
+      l = l * f1 + f2 * (float)(ndual * a.nk);
+    }
+    const float inv = 1.0f / l;
+    if (qrow[qt] < 0) continue;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + g * 4;
+      if (d >= DH) continue;
+      f32x4 acc = o[qt][dt];
+      if (ndual > 0) {
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sgi = 0; sgi < 3; ++sgi) {
+          if (dual3[sgi]) b += *reinterpret_cast<const f32x4*>(vsum + ((long)kit3[sgi] * a.heads + h) * DH + d);
+        }
+        acc = acc * f1 + b * f2;
+      }
+      U64 ov;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ov.e[r] = (f16)(acc[r] * inv);
+      *reinterpret_cast<uint2*>(O + (long)qrow[qt] * a.ldo + h * DH + d) = ov.u;
+    }
+  }
+}
+
+// column sums of V per kv item: vsum[kit][c] = sum_key V[kit*nk + key][c], fp32 (the query-independent "+1" part of the
+// binary dual segments).  Block = one kv item x 128 columns; 4 row groups x 64 column pairs.
+__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ V, int ldv, int nk, int C, float* __restrict__ out) {
+  __shared__ float red[4][128];
+  const int kit = blockIdx.x, c0 = blockIdx.y * 128 + (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c0 < C) {
+    const f16* p = V + (long)kit * nk * ldv + c0;
+    for (int r = rg; r < nk; r += 4) {
+      const f16x2 v = *reinterpret_cast<const f16x2*>(p + (long)r * ldv);
+      s0 += (float)v[0];
+      s1 += (float)v[1];
+    }
+  }
+  red[rg][(threadIdx.x & 63) * 2] = s0;
+  red[rg][(threadIdx.x & 63) * 2 + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c < C) out[(long)kit * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB>
+int launch_attn2(const me_attn_args* a, hipStream_t st) {
+  constexpr int BQ = 16 * QT * NW;
+  const int nqb = (a->nq + BQ - 1) / BQ;
+  const long total = (long)a->n_items * a->heads * nqb;
+  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
+  return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
+}
+
 template <int DH, int QT, bool GD, int MINW, int NBUF>
 int launch_attn(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 64 * QT;
@@ -398,15 +819,6 @@ int launch_attn(const me_attn_args* a, hipStream_t st) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW, NBUF>), dim3((unsigned)total), dim3(256), 0, st, *a);
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
-}
-
-int variant() {   // ME_ATTN_VARIANT=1: one 16-query tile per wave (fewer registers, more waves per SIMD) -- A/B knob
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("ME_ATTN_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
 }
 
 }  // namespace
@@ -420,19 +832,27 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15 || ((uintptr_t)a->O & 7)) { me_set_error("me_attn: misaligned pointer"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
-  switch (a->dh) {
-    case 40:
-      if (a->general_dual) rc = launch_attn<40, 2, true, 2, 1>(a, st);
-      else if (variant() == 1) rc = launch_attn<40, 1, false, 4, 2>(a, st);
-      else rc = launch_attn<40, 2, false, 3, 2>(a, st);
-      break;
-    case 80:
-      if (a->general_dual) rc = launch_attn<80, 2, true, 2, 1>(a, st);
-      else if (variant() == 1) rc = launch_attn<80, 1, false, 3, 2>(a, st);
-      else rc = launch_attn<80, 2, false, 2, 2>(a, st);
-      break;
-    case 160: rc = a->general_dual ? launch_attn<160, 1, true, 2, 1>(a, st) : launch_attn<160, 1, false, 2, 1>(a, st); break;
-    default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
+  if (a->general_dual) {   // non-binary masks: the mask-reading kernel
+    switch (a->dh) {
+      case 40: rc = launch_attn<40, 2, true, 2, 1>(a, st); break;
+      case 80: rc = launch_attn<80, 2, true, 2, 1>(a, st); break;
+      case 160: rc = launch_attn<160, 1, true, 2, 1>(a, st); break;
+      default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
+    }
+  } else {
+    if (a->vsum) {   // binary dual segments: per-kv-item column sums of V first (same stream)
+      if (a->n_kv_items <= 0) { me_set_error("me_attn: vsum needs n_kv_items"); return ME_EINVAL; }
+      const int C = a->heads * a->dh;
+      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)a->n_kv_items, (unsigned)((C + 127) / 128)), dim3(256), 0, st,
+                         reinterpret_cast<const f16*>(a->V), a->ldv, a->nk, C, reinterpret_cast<float*>(a->vsum));
+    }
+    // 8 waves x 32 queries when the launch has whole 256-query blocks (halves the K/V fill per query), else 4 waves
+    switch (a->dh) {
+      case 40: rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1>(a, st); break;
+      case 80: rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1>(a, st); break;
+      case 160: rc = launch_attn2<160, 1, 4, 2, 1, 1>(a, st); break;
+      default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
+    }
   }
   if (rc != ME_OK) me_set_error("me_attn: kernel launch failed");
   return rc;

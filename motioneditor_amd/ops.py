@@ -157,9 +157,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
     a.scale = dh ** -0.5 if scale is None else scale
     from . import segments
     gd = segments.GENERAL_DUAL.get(seg_mode.data_ptr())
-    if gd is None:   # table not built (and kept alive) by segments.py: inspect it, never cache a transient pointer
+    bd = segments.BINARY_DUAL.get(seg_mode.data_ptr())
+    if gd is None or bd is None:   # table not built (and kept alive) by segments.py: inspect it, never cache a transient pointer
         gd = bool(((seg_mode == 1) | (seg_mode == 2)).any().item())
+        bd = bool((seg_mode == 3).any().item())
     a.general_dual = 1 if gd else 0
+    if bd and not gd:   # binary dual keys: me_attn needs fp32 scratch for the per-kv-item column sums of V
+        n_kv = k.shape[0] // nk
+        vsum = torch.empty((n_kv, heads * dh), dtype=torch.float32, device=q.device)
+        a.vsum, a.n_kv_items = vsum.data_ptr(), n_kv
     e0 = _pb()
     capi.check(capi.lib().me_attn(C.byref(a), _stream()), "me_attn")
     if e0 is not None:

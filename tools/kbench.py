@@ -112,6 +112,18 @@ def bench_gemm_small():
         print(f"M{M} N{N} K{K} taps{taps}".ljust(36) + f" {ms:8.3f} {2.0*M*N*K*taps/ms/1e9:7.1f}")
 
 
+def bench_gemm_abl():
+    """A few big-tile shapes for the ME_GEMM_ABL main-loop ablations."""
+    B, f = 4, 24
+    print(f"{'shape':28s} {'ms':>8s} {'TF/s':>7s}")
+    for name, M, N, K in [("L0 qkv", B * f * 4096, 960, 320), ("L0 ff1", B * f * 4096, 2560, 320), ("L0 ff2", B * f * 4096, 320, 1280),
+                          ("L1 qkv", B * f * 1024, 1920, 640), ("L1 ff2", B * f * 1024, 640, 2560), ("L2 ff1", B * f * 256, 10240, 1280), ("big 8192^2 K4096", 8192, 8320, 4096)]:
+        x, w = rnd(M, K), rnd(N, 1, K)
+        ms = timeit(lambda: ops.gemm(x, w))
+        print(f"{name:28s} {ms:8.3f} {2.0*M*N*K/ms/1e9:7.1f}")
+        del x, w
+
+
 def bench_attn(only_first=False):
     B, f = 4, 24
     print(f"{'attn':28s} {'ms':>8s} {'TF/s(ref)':>9s}")
@@ -134,6 +146,18 @@ def bench_attn(only_first=False):
         units = segments.KEY_UNITS[si.data_ptr()]
         print(f"{name:28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
         del q
+
+
+def bench_attn_headmajor():
+    """Experiment: the L0 [prev|cur] launch with K/V (and Q) stored head-major (contiguous 80-byte rows per head): heads folded into the batch axis."""
+    B, f, dh, N = 4, 24, 40, 4096
+    q = rnd(B * 8 * f * N, 3 * dh)
+    k = rnd(B * 8 * f * N, dh)
+    v = rnd(B * 8 * f * N, dh)
+    si, sm = segments.prev_cur(B * 8, f, dev)
+    for name, kk, vv in (("rows of 3*dh", q[:, dh:2 * dh], q[:, 2 * dh:]), ("contiguous dh", k, v)):
+        ms = timeit(lambda: ops.attention(q[:, :dh], kk, vv, heads=1, dh=dh, n_items=B * 8 * f, nq=N, nk=N, seg_item=si, seg_mode=sm))
+        print(f"L0 prev|cur head-major K/V {name:16s} {ms:8.3f} ms {4.0*8*N*N*2*B*f*dh/ms/1e9:9.1f} TF/s(ref)")
 
 
 def bench_misc():
@@ -163,8 +187,12 @@ if __name__ == "__main__":
         bench_gemm_epi()
     if "gemmk" in what:
         bench_gemm_ksweep()
+    if "gemmabl" in what:
+        bench_gemm_abl()
     if "gemmc" in what:
         bench_gemm_cached()
+    if "attnhm" in what:
+        bench_attn_headmajor()
     if "attn1" in what:
         bench_attn(True)
     if "misc" in what:
