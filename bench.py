@@ -1,7 +1,9 @@
 """bench.py -- denoise-steps/sec of MotionEditor's two-branch DDIM step on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]                       (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+      N = 1 runs in this process.  N > 1 without WORLD_SIZE in the environment re-launches itself as
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`;
+      under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of that job.
 
 One "step" = one iteration of the reference loop body (pipeline_motion_editor.py:603-648): ControlNet on
 the two edit rows, one batch-4 UNet3D forward with the content-aware motion adapter and both attention
@@ -9,20 +11,25 @@ editors ACTIVE (steps >= 4, i.e. 46 of the 50 steps of a run), classifier-free g
 Workload = BASELINE.json configs[2]: 24 frames x 512^2 (64x64 latents), synthetic inputs, seeded random
 weights of the SD-1.5 / ControlNet-openpose / adapter architectures (no checkpoints exist offline).
 
-Multi-GPU (round 1): one process per GPU.  Even N (default `--parallel cfg`): GPUs pair up and split ONE clip along
-the classifier-free-guidance axis (rank 2i: unconditional (recon, edit) pair, rank 2i+1: conditional pair); the only
-data-path exchange is one RCCL all-gather of the 4-channel noise prediction per step; N/2 clips run side by side.
-`--parallel replicas`: every rank denoises its own clip, no collective.  value = clips*steps / max-over-ranks time.
-Frame sharding with the RCCL temporal-K/V all-gather is the next row.
+Multi-GPU: ONE clip, strong scaling (the metric is "24f x 512^2 at 1/2/4/8 MI355X"), one process per GPU, RCCL:
+  --parallel auto (default)  N = 2: cfg (the two classifier-free-guidance halves; one all-gather of the noise prediction per
+                             step); N = 4, 8: cfg-frames = CFG pair x frame shards of N/2 ranks (K|V halo /
+                             all-gather, TemporalConv halos, GroupNorm-statistic all-reduce, each at batch 2); odd N: frames
+  --parallel frames          the frame axis over all N ranks (BASELINE configs[3]/[4] as written)
+  --parallel cfg | replicas  CFG pairs x N/2 clips, or one independent clip per GPU (weak scaling, no data-path collective)
+value = clips * steps / max-over-ranks time.  `comm` in the JSON = data-path exchanges per step of rank 0.
 
-Prints ONE JSON line on rank 0 with `roofline` (dominant kernel family, HIP-event timed on the launch
-stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
+Prints ONE JSON line on rank 0 with `roofline` (the device kernel with the largest share of GPU time, HIP-event timed
+on the launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample, rank 0, N = 1).
+`--emulate` (test plumbing only) runs the product host code on tests/emu_ops.py (torch CPU, gloo) at tiny shapes.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -31,15 +38,56 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 PEAK_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
-REF_TFLOP_PER_STEP = {"c3": 145.7}  # BASELINE.md §2, reference semantics (2*MAC)
+# reference-semantics TFLOP of one two-branch step (2*MAC; edited layers count their 5N keys)
+REF_TFLOP = {(8, 32, 32): 9.3, (24, 64, 64): 145.7, (48, 96, 96): 918.1}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--parallel", choices=["auto", "cfg", "replicas", "frames", "cfg-frames"], default="auto")
+    ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
+    ap.add_argument("--editors", choices=["active", "inactive"], default="active",
+                    help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
+    ap.add_argument("--inversion", action="store_true",
+                    help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
+    ap.add_argument("--vae-decode", action="store_true",
+                    help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
+    ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
+    ap.add_argument("--no-graph", action="store_true", help="A/B: enqueue the ~1100 launches of every step from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--zero-tconv", action="store_true",
+                    help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
+    ap.add_argument("--emulate", action="store_true", help="test plumbing: torch-CPU emulation of the C ABI (tests/emu_ops.py), gloo backend")
+    return ap.parse_args()
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_self(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: become the launcher of N ranks of this very command."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
 
 
 def build_inputs(f, h, w, seed=33):
+    import numpy as np
+    import torch
     from motioneditor_amd import synth
     T = torch.from_numpy
     return dict(latents=T(synth.synth_normal("bench.latents", (2, 4, f, h, w), seed)),
@@ -49,13 +97,14 @@ def build_inputs(f, h, w, seed=33):
                 masks=T(synth.synth_masks(f, 8 * h, 8 * w)))
 
 
-def make_pipeline(device, usd, csd, masks):
+def make_pipeline(device, usd, csd, masks, dtype=None):
     from motioneditor_amd.attn_control import (FullySelfAttentionControlMask, TemporalSelfAttentionControl,
                                                regiter_fully_attention_editor_diffusers, regiter_temporal_attention_editor_diffusers)
     from motioneditor_amd.models.controlnet import ControlNetModel
     from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
     from motioneditor_amd.pipelines import MotionEditorPipeline
-    pipe = MotionEditorPipeline(unet=UNet2DConditionModel(usd, device), controlnet=ControlNetModel(csd, device))
+    kw = {} if dtype is None else {"dtype": dtype}
+    pipe = MotionEditorPipeline(unet=UNet2DConditionModel(usd, device, **kw), controlnet=ControlNetModel(csd, device, **kw))
     ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
     regiter_temporal_attention_editor_diffusers(pipe, ted)
     sed = FullySelfAttentionControlMask(start_step=4, start_layer=10, source_masks=masks)
@@ -64,14 +113,32 @@ def make_pipeline(device, usd, csd, masks):
     return pipe, sed, ted
 
 
-def cpu_baseline(usd, csd, budget_s=25.0):
-    """CPU oracle (oracle/ref_cpu.py, fp32 torch) on a bounded sample: ONE full two-branch step with editors
-    active at 8 frames x 64^2 (8x8 latents), torch's default thread count; scaled to the bench workload by the
-    reference-semantics FLOP ratio."""
+def step_tflop(f, h, w):
+    """Reference-semantics TFLOP of one two-branch step: BASELINE.md's figure for the three configurations it lists, else
+    scaled from config 3 by token count (attention scales super-linearly in h*w: approximate, labelled so)."""
+    if (f, h, w) in REF_TFLOP:
+        return REF_TFLOP[(f, h, w)], True
+    return REF_TFLOP[(24, 64, 64)] * (f * h * w) / (24 * 64 * 64), False
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(usd, csd):
+    """CPU oracle (oracle/ref_cpu.py, fp32 torch, the validated restatement of the reference step) timed on ONE full
+    two-branch step with both editors active at BASELINE configs[0] -- 8 frames x 256^2 (32x32 latents), 9.3 TFLOP --
+    and scaled to the bench workload by the reference-semantics FLOP ratio."""
+    import torch
     from oracle import ref_cpu
-    from motioneditor_amd import synth
-    cores = torch.get_num_threads()   # torch's default (physical cores); forcing every SMT thread made it 20x slower
-    f, h, w = 8, 8, 8
+    cores = torch.get_num_threads()   # torch's default (physical cores); forcing every SMT thread measured 20x slower
+    f, h, w = 8, 32, 32
     x = build_inputs(f, h, w)
     to = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}  # noqa: E731
     u, c = to(usd), to(csd)
@@ -82,54 +149,77 @@ def cpu_baseline(usd, csd, budget_s=25.0):
     t0 = time.perf_counter()
     with torch.no_grad():
         ref_cpu.denoise_step(u, c, ddim, x["latents"], ddim.timesteps[4], x["uncond"][4], x["cond"], images, sp, tp, 7.5)
-    dt = time.perf_counter() - t0
-    return dt, cores, f, h, w
+    return time.perf_counter() - t0, cores, f, h, w
 
 
-def step_tflop(f, h, w):
-    """Reference-semantics TFLOP of one two-branch step, scaled from BASELINE.md's config-3 figure by token count
-    (exact at config 3; attention terms scale super-linearly in h*w, so other sizes are approximate)."""
-    return REF_TFLOP_PER_STEP["c3"] * (f * h * w) / (24 * 64 * 64)
+def resolve_mode(args, world):
+    """-> (mode, n_cfg, n_shards, n_clips)"""
+    m = args.parallel
+    if world == 1:
+        return "single", 1, 1, 1
+    if m == "auto":
+        m = "cfg" if world == 2 else ("cfg-frames" if world % 2 == 0 else "frames")
+    if m == "cfg":
+        if world % 2:
+            raise SystemExit("--parallel cfg needs an even number of GPUs")
+        return m, 2, 1, world // 2
+    if m == "cfg-frames":
+        if world % 2 or world < 4:
+            raise SystemExit("--parallel cfg-frames needs an even number of GPUs >= 4")
+        return m, 2, world // 2, 1
+    if m == "frames":
+        return m, 1, world, 1
+    return "replicas", 1, 1, world
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=24)
-    ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--parallel", choices=["cfg", "replicas", "frames"], default="cfg",
-                    help="N > 1: CFG-parallel GPU pairs (even N), independent replicas, or ONE clip with its frames sharded over all N ranks")
-    ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
-    ap.add_argument("--editors", choices=["active", "inactive"], default="active",
-                    help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
-    ap.add_argument("--inversion", action="store_true",
-                    help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
-    ap.add_argument("--vae-decode", action="store_true",
-                    help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
-    ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
-    ap.add_argument("--zero-tconv", action="store_true",
-                    help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_self(args))
+
+    import numpy as np
+    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
+    if args.emulate:
+        device = "cpu"
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    else:
+        torch.cuda.set_device(local)
+        device = f"cuda:{local}"
+    dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if args.emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
-    from motioneditor_amd import capi, ops, synth
-    capi.lib()  # no HIP library -> hard failure (no fallback path exists)
+    def sync():
+        if not args.emulate:
+            torch.cuda.synchronize()
+
+    from motioneditor_amd import ops, synth
+    emu_dtype = None
+    if args.emulate:
+        import emu_ops
+        import motioneditor_amd.models.unet_2d_condition as u_mod
+        import motioneditor_amd.pipelines.pipeline_motion_editor as pm_mod
+        from motioneditor_amd import schedulers as sch_mod
+        from motioneditor_amd.models import graph as graph_mod
+        for m in (graph_mod, u_mod, pm_mod, sch_mod):
+            m.ops = emu_ops
+        emu_dtype = torch.float32
+    else:
+        from motioneditor_amd import capi
+        capi.lib()  # no HIP library -> hard failure (no fallback path exists)
+
     if args.vae_decode:
-        if dist_on:
+        if dist_on or args.emulate:
             raise SystemExit("--vae-decode is a single-GPU secondary measurement")
         from motioneditor_amd.models.vae import AutoencoderKL
         vae = AutoencoderKL.from_synthetic(device)
@@ -145,39 +235,56 @@ def main():
         dt = time.perf_counter() - t0
         prof, ops.PROFILE = ops.PROFILE, None
         fam = {}
-        for name, fl, by, e0, e1, detail in prof:
-            d = fam.setdefault(name, [0.0, 0.0])
-            d[0] += e0.elapsed_time(e1) * 1e-3
-            d[1] += fl
+        for rec in prof:
+            d = fam.setdefault(rec[0], [0.0, 0.0])
+            d[0] += rec[3].elapsed_time(rec[4]) * 1e-3
+            d[1] += rec[1]
         assert torch.isfinite(img).all()
         print(json.dumps({"metric": "vae-decode frames/sec (SD-1.5 AutoencoderKL decoder)", "value": round(args.frames * args.steps / dt, 3), "unit": "frames/s",
                           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
                           "dtype": "f16", "data": "synthetic", "config": {"workload": f"{args.frames} latent frames {args.latent}x{args.latent} -> {8 * args.latent}x{8 * args.latent} images"},
                           "kernel_families": {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0} for k, v in sorted(fam.items())}}))
         return
+
     usd = synth.synth_state_dict(synth.unet_schema())
     csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
     if args.zero_tconv:
         usd = {k: (np.zeros_like(v) if ".temp_conv" in k and not k.startswith("controlnet_adapter.") else v) for k, v in usd.items()}
     f, h, w = args.frames, args.latent, args.latent
-    cfg_par = dist_on and args.parallel == "cfg" and world % 2 == 0
-    group = None
-    if cfg_par:
-        pairs = [dist.new_group([2 * i, 2 * i + 1]) for i in range(world // 2)]   # every rank creates every group
-        group = pairs[rank // 2]
-    frame_par = dist_on and args.parallel == "frames"
+    mode, n_cfg, n_shards, n_clips = resolve_mode(args, world)
+    if f % n_shards:
+        raise SystemExit(f"{f} frames do not split over {n_shards} frame shards")
+    # rank layout: rank = (clip * n_shards + shard) * n_cfg + cfg half  (CFG pairs are neighbouring ranks)
+    cfg_r = rank % n_cfg
+    shard_i = (rank // n_cfg) % n_shards
+    clip = rank // (n_cfg * n_shards)
+    cfg_group = shard_group = None
+    if dist_on:   # every rank creates every group, in the same order
+        if n_cfg == 2:
+            for c in range(n_clips):
+                for s_ in range(n_shards):
+                    ranks = [(c * n_shards + s_) * 2 + k for k in range(2)]
+                    g = dist.new_group(ranks)
+                    if rank in ranks:
+                        cfg_group = g
+        if n_shards > 1:
+            for c in range(n_clips):
+                for k in range(n_cfg):
+                    ranks = [(c * n_shards + s_) * n_cfg + k for s_ in range(n_shards)]
+                    g = dist.new_group(ranks)
+                    if rank in ranks:
+                        shard_group = g
     shard = None
-    if frame_par:
+    if n_shards > 1:
         from motioneditor_amd import parallel
-        shard = parallel.FrameShard(f)               # f / world frames per rank
-    clip = 0 if frame_par else (rank // 2 if cfg_par else rank)
-    n_clips = 1 if frame_par else (world // 2 if cfg_par else world)
-    x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (CFG-parallel) or for all ranks (frames)
-    pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"])
-    pipe.overlap_controlnet = pipe.overlap_adapter = not args.no_overlap
+        shard = parallel.FrameShard(f, shard_group)               # f / n_shards frames per rank
+        assert shard.rank == shard_i
+    x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (cfg), or for all ranks
+    pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"], emu_dtype)
+    pipe.overlap_controlnet = pipe.overlap_adapter = not (args.no_overlap or args.emulate)
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
-    if frame_par:   # this rank's frames only
+    if shard is not None:   # this rank's frames only
         lo, hi = shard.frame0, shard.frame0 + shard.f_loc
         images = images[lo:hi].contiguous()
         lat = lat[:, :, lo:hi].contiguous()
@@ -190,48 +297,58 @@ def main():
         pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
         lat = lat[:1].contiguous()
 
+    use_graph = not (args.no_graph or args.emulate or args.inversion or dist_on) and hasattr(pipe, "denoise_step_graphed")
+
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
             return util.ddim_loop(pipe, pipe.scheduler, lat, 1, normal_infer=True, text_embeddings=cond[:1])[-1]
         if args.editors == "inactive":
             sed.cur_step = ted.cur_step = 0      # the editors count steps themselves: hold them before start_step
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
-        if frame_par:
-            return pipe.denoise_step_frame_sharded(lat, ts[i], emb, images, 7.5, shard)
-        if cfg_par:
-            return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=group)
+        if shard is not None:
+            return pipe.denoise_step_frame_sharded(lat, ts[i], emb, images, 7.5, shard, cfg_group=cfg_group)
+        if n_cfg == 2:
+            return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=cfg_group)
+        if use_graph and ops.PROFILE is None:
+            return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
     sed.cur_step = ted.cur_step = 4 if args.editors == "active" else 0   # active: the steady-state step (46 of 50)
     i0 = 4
     for k in range(args.warmup):
         lat = run_step(i0 + k, lat)
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+        from motioneditor_amd import parallel
+        parallel.reset_stats()
+    sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         lat = run_step(i0 + args.warmup + k, lat)
-    torch.cuda.synchronize()
+    sync()
     if dist_on:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
-    # Roofline pass: the SAME steps once more, with a HIP event pair around every launch and on a single stream.  It is
-    # not folded into the timed region because (a) ~1100 event pairs per step cost ~6 % of the step and (b) the timed
-    # region overlaps two streams (ControlNet + adapter beside the UNet), which stretches every kernel's own duration
-    # by whatever shares the GPU with it.  profiles/*kernel_stats* is the rocprofv3 trace of `--no-overlap`.
+    comm = None
+    if dist_on:
+        from motioneditor_amd import parallel
+        comm = parallel.stats_summary(args.steps)
+    # Roofline pass: the SAME steps once more, eagerly, with a HIP event pair around every launch and on a single stream.
+    # It is not folded into the timed region because (a) the timed region replays a captured hipGraph, (b) ~1100 event pairs
+    # per step cost ~6 % of the step and (c) the timed region overlaps two streams (ControlNet + adapter beside the UNet),
+    # which stretches every kernel's own duration by whatever shares the GPU with it.
     prof = None
-    if not args.no_profile:
-        ov = (getattr(pipe, "overlap_controlnet", False), getattr(pipe, "overlap_adapter", False))
+    if not args.no_profile and not args.emulate:
+        ov = (pipe.overlap_controlnet, pipe.overlap_adapter)
         pipe.overlap_controlnet = pipe.overlap_adapter = False
         if rank == 0:
             ops.PROFILE = []
         lat2 = lat
         for k in range(args.steps):
             lat2 = run_step(i0 + args.warmup + k, lat2)
-        torch.cuda.synchronize()
+        sync()
         prof, ops.PROFILE = ops.PROFILE, None
         pipe.overlap_controlnet, pipe.overlap_adapter = ov
     if dist_on:
@@ -243,60 +360,85 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = n_clips * args.steps / dt
+        tf_ref, tf_exact = step_tflop(f, h, w)
+        desc = {"single": "single GPU",
+                "cfg": f"cfg2 x dp{n_clips}: each GPU pair splits one clip along the classifier-free-guidance axis (one RCCL all-gather of the noise prediction per step)"
+                       + (f", {n_clips} clips side by side" if n_clips > 1 else ""),
+                "cfg-frames": f"cfg2 x frames{n_shards}: one clip; GPU pairs split the CFG axis, {f // max(n_shards, 1)} frames per GPU; per layer: attn1 one-frame K|V halo (p2p), "
+                              f"RCCL all-gather of K|V (adapter sparse-causal + temporal attention), TemporalConv halos, GroupNorm-statistic all-reduce, all at batch 2",
+                "frames": f"frames{n_shards}: one clip, {f // max(n_shards, 1)} frames per GPU; per layer: attn1 one-frame K|V halo (p2p), RCCL all-gather of K|V (adapter sparse-causal + "
+                          f"temporal attention), TemporalConv halos, GroupNorm-statistic all-reduce",
+                "replicas": f"dp{world}: one independent clip per GPU, no data-path collective"}[mode]
         out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
                           f"denoise-steps/sec, {f}f x {8 * h}^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "strong" if (frame_par or (cfg_par and world == 2)) else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak" if (n_clips > 1 or world == 1) else "strong", "vs_baseline": None,
+               "dtype": "f32 (CPU emulation of the C ABI: plumbing test, not a measurement)" if args.emulate else "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
-                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv), "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
-                          "parallelism": "single GPU" if world == 1 else (f"cfg2 x dp{world // 2}: each GPU pair splits one clip along the CFG axis "
-                                                                          f"(one RCCL all-gather of the noise prediction per step), {world // 2} clip(s) side by side"
-                                                                          if cfg_par else (f"frames{world}: one clip, {f // world} frames per GPU; RCCL all-gather of K|V (attn1, adapter, temporal attention), "
-                                                                                           f"TemporalConv halos, GroupNorm-statistic all-reduce" if frame_par
-                                                                                           else f"dp{world}: one independent clip per GPU, no data-path collective"))},
-               "step_tflop_reference_semantics": round(step_tflop(f, h, w), 2),
-               "achieved_tflops_whole_job": round(step_tflop(f, h, w) * n_clips * args.steps / dt, 1)}
+                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
+                          "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
+                          "hip_graph_replay": bool(use_graph), "parallel_mode": mode, "parallelism": desc,
+                          "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; the ControlNet restatement (diffusers, not in the reference tree) is unpinned"},
+               "step_tflop_reference_semantics": round(tf_ref, 2), "step_tflop_is_baseline_md_figure": tf_exact,
+               "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1)}
+        if comm is not None:
+            out["comm"] = comm
         if prof:
-            fam = {}
-            shapes = {}
-            for name, fl, by, e0, e1, detail in prof:
-                d = fam.setdefault(name, [0.0, 0.0, 0.0, 0])
-                d[0] += e0.elapsed_time(e1) * 1e-3
-                d[1] += fl
-                d[2] += by
-                d[3] += 1
+            fam, kern, shapes = {}, {}, {}
+            for name, fl, by, e0, e1, detail, kname, xfl in prof:
+                sec = e0.elapsed_time(e1) * 1e-3
+                for table, key in ((fam, name), (kern, kname)):
+                    d = table.setdefault(key, [0.0, 0.0, 0.0, 0, 0.0])
+                    d[0] += sec
+                    d[1] += fl
+                    d[2] += by
+                    d[3] += 1
+                    d[4] += xfl
                 if detail:
-                    sd = shapes.setdefault(detail, [0.0, 0.0, 0])
-                    sd[0] += e0.elapsed_time(e1) * 1e-3
+                    sd = shapes.setdefault(detail + " " + kname, [0.0, 0.0, 0])
+                    sd[0] += sec
                     sd[1] += fl
                     sd[2] += 1
             if args.shapes:
-                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:60]:
-                    print(f"[shape] {k:44s} {v[0] / args.steps * 1e3:8.2f} ms/step {v[2] // args.steps:4d} launches {v[1] / v[0] / 1e12:7.1f} TF/s", file=sys.stderr)
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:70]:
+                    print(f"[shape] {k:64s} {v[0] / args.steps * 1e3:8.2f} ms/step {v[2] // args.steps:4d} launches {v[1] / v[0] / 1e12:7.1f} TF/s", file=sys.stderr)
             tot = sum(v[0] for v in fam.values())
-            dom = max(fam, key=lambda k: fam[k][0])
-            tsec, fl, by, n = fam[dom]
+            exec_tf = sum(v[4] for v in fam.values()) / args.steps / 1e12
+            out["executed_tflop_per_step"] = round(exec_tf, 2)
+            out["achieved_tflops_executed"] = round(exec_tf * n_clips * args.steps / dt, 1)
+            out["mfma_frac_reference_semantics"] = round(tf_ref * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4)
+            out["mfma_frac_executed"] = round(exec_tf * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4)
+            dom = max(kern, key=lambda k: kern[k][0])
+            tsec, fl, by, n, xfl = kern[dom]
             traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_summary.py), same workload only
             pmc = ROOT / "profiles" / "pmc_traffic.json"
-            if pmc.exists() and (f, h, w) == (24, 64, 64):
-                traffic = json.loads(pmc.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+            if pmc.exists() and (f, h, w) == (24, 64, 64) and world == 1:
+                pt = json.loads(pmc.read_text())
+                traffic = (pt.get(dom) or pt.get(dom.split("<")[0]) or {}).get("hbm_bytes_per_launch")
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None if traffic is None else round(traffic),
-                               "algorithmic_bytes_per_launch": round(by / n),
-                               "launches_per_step": n // args.steps, "avg_launch_ms": round(tsec / n * 1e3, 4),
-                               "share_of_gpu_time": round(tsec / tot, 3)}
-            out["roofline"]["measured_in"] = ("event-instrumented single-stream pass of the same steps inside this run, right after the timed region "
-                                              "(the timed region is un-instrumented and overlaps two streams)")
+                               "achieved_executed": round(xfl / tsec / 1e12, 1), "frac_executed": round(xfl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4),
+                               "flops_counted": "achieved = reference-semantics FLOPs of the launches (SURVEY 8d: a binary dual segment counts its 2 nk materialised keys); "
+                                                "achieved_executed = FLOPs the kernel multiplies (without MFMA tile padding)",
+                               "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n // args.steps, "avg_launch_ms": round(tsec / n * 1e3, 4),
+                               "share_of_gpu_time": round(tsec / tot, 3),
+                               "measured_in": "event-instrumented single-stream eager pass of the same steps inside this run, right after the timed region "
+                                              "(the timed region is un-instrumented, replays a hipGraph and overlaps two streams)"}
+            out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
+                                  "tflops_executed": round(v[4] / v[0] / 1e12, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps}
+                              for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:8]}
             out["kernel_families"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
                                           "gbs": round(v[2] / v[0] / 1e9, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps} for k, v in sorted(fam.items())}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.emulate:
             cdt, cores, cf, ch, cw = cpu_baseline(usd, csd)
-            scale = step_tflop(f, h, w) / step_tflop(cf, ch, cw)
-            out["cpu_baseline"] = {"value": round(1.0 / (cdt * scale), 6), "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": f"oracle/ref_cpu.py (fp32 torch CPU restatement of the reference step) timed on ONE full two-branch step at {cf} frames x "
-                                             f"{8*ch}x{8*cw} ({cdt:.1f} s on {cores} threads), scaled to the bench workload by the token ratio x{scale:.0f}",
-                                   "sample_seconds": round(cdt, 2)}
+            ctf, _ = step_tflop(cf, ch, cw)
+            scale = tf_ref / ctf
+            out["cpu_baseline"] = {"value": round(1.0 / (cdt * scale), 6), "unit": "steps/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+                                   "sample": f"oracle/ref_cpu.py (fp32 torch CPU restatement of the reference step) timed on ONE full two-branch step, editors active, at BASELINE "
+                                             f"configs[0] = {cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents, {ctf} TFLOP): {cdt:.1f} s on {cores} threads = {ctf / cdt:.2f} TFLOP/s; "
+                                             f"scaled to the bench workload by the reference-semantics FLOP ratio x{scale:.1f}",
+                                   "sample_seconds": round(cdt, 2), "sample_steps_per_s": round(1.0 / cdt, 5)}
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

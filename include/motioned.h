@@ -37,6 +37,9 @@ extern "C" {
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
 const char* me_last_error(void);
+/* name of the device kernel the last compute call of this thread launched, e.g. "gemm_kernel<256,320>",
+ * "attn2_kernel<40,2,8>" -- the names rocprofv3 reports; used by bench.py's per-kernel roofline */
+const char* me_last_kernel(void);
 /* number of CUs / XCD-count etc. of the current device; returns ME_EHIP if no gfx950 device */
 int me_device_info(int* cus, int* lds_bytes, char* arch, int arch_len);
 

@@ -82,6 +82,7 @@ class LayerNormArgs(C.Structure):
 SYMBOLS = {
     "me_abi_version": (C.c_int, []),
     "me_last_error": (C.c_char_p, []),
+    "me_last_kernel": (C.c_char_p, []),
     "me_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "me_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "me_conv_small": (C.c_int, [C.POINTER(ConvSmallArgs), _vp]),

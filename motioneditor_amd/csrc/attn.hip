@@ -22,9 +22,12 @@
 //                   MFMA k-slot (g, j) carries key kk*32 + (j>>2)*16 + g*4 + (j&3) for BOTH operands.
 #include "me_common.h"
 #include "../../include/motioned.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
+
+extern "C" void me_set_kernel(const char* name);
 
 namespace {
 
@@ -808,6 +811,11 @@ int launch_attn2(const me_attn_args* a, hipStream_t st) {
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
   hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d>", DH, QT, NW);
+    me_set_kernel(nm);
+  }
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }
 
@@ -818,6 +826,11 @@ int launch_attn(const me_attn_args* a, hipStream_t st) {
   const long total = (long)a->n_items * a->heads * nqb;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL((attn_kernel<DH, QT, GD, MINW, NBUF>), dim3((unsigned)total), dim3(256), 0, st, *a);
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "attn_kernel<%d,%d,general-dual>", DH, QT);
+    me_set_kernel(nm);
+  }
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
 }
 

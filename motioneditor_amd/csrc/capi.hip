@@ -6,7 +6,15 @@
 
 namespace {
 thread_local char g_err[512] = "";
+thread_local char g_kernel[96] = "";
 }
+
+// name of the device kernel the last compute entry point of this thread launched (bench.py: per-kernel roofline)
+extern "C" void me_set_kernel(const char* name) {
+  strncpy(g_kernel, name ? name : "", sizeof(g_kernel) - 1);
+  g_kernel[sizeof(g_kernel) - 1] = 0;
+}
+extern "C" const char* me_last_kernel(void) { return g_kernel; }
 
 extern "C" void me_set_error(const char* msg) {
   strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);

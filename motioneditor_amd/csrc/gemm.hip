@@ -22,6 +22,7 @@
 // STAGE_REG keeps the first implementation (global -> VGPR -> padded LDS) for A/B runs.
 #include "me_common.h"
 #include "../../include/motioned.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -640,6 +641,7 @@ bool tile160() {
 }  // namespace
 
 extern "C" void me_set_error(const char* msg);
+extern "C" void me_set_kernel(const char* name);
 
 template <int BM, int BN, int STAGE, int WM = 64>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
@@ -655,6 +657,11 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn), dim3(BM / WM * 128), lds, st, *a);
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>", BM, BN, STAGE == STAGE_GLDS ? "" : ",reg");
+    me_set_kernel(nm);
+  }
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");
     return ME_EHIP;
@@ -675,6 +682,7 @@ static int launch_conv_halo(const me_gemm_args* a, hipStream_t st) {
   const long blocks = (long)(a->M / 256) * (a->N / 320);
   (void)hipGetLastError();
   hipLaunchKernelGGL(conv3_halo_kernel, dim3((unsigned)blocks), dim3(512), lds, st, *a);
+  me_set_kernel("conv3_halo_kernel");
   if (hipGetLastError() != hipSuccess) {
     me_set_error("me_gemm: kernel launch failed");
     return ME_EHIP;

@@ -155,7 +155,9 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
         qkv = ops.gemm(n, P.fused(names))
         return qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     q = ops.gemm(n, P.mat(names[0]))
-    kv = shard.gather_kv(ops.gemm(n, P.fused(names[1:])), B, N, ops.copy_rows)
+    ext, loc = shard.kv_buffer(n.shape[0], 2 * C, B, N, n)     # the K|V GEMM writes straight into its slot of the exchanged tensor
+    ops.gemm(n, P.fused(names[1:]), out=loc)
+    kv = shard.complete_kv(ext, B, N, ops.copy_rows)
     return q, kv[:, :C], kv[:, C:]
 
 

@@ -43,12 +43,18 @@ def _pb():
     return e
 
 
-def _pe(e0, family: str, flops: float, nbytes: float, detail: str = "") -> None:
+def _pe(e0, family: str, flops: float, nbytes: float, detail: str = "", kernel: str = "", exec_flops=None) -> None:
+    """flops = reference-semantics work of the call (what the reference's own ops would execute), exec_flops = what the
+    kernel actually multiplies (a binary dual segment is computed once, not as 2 nk materialised keys)."""
     if e0 is None:
         return
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    PROFILE.append((family, flops, nbytes, e0, e1, detail))
+    PROFILE.append((family, flops, nbytes, e0, e1, detail, kernel or family, flops if exec_flops is None else exec_flops))
+
+
+def _last_kernel() -> str:
+    return capi.lib().me_last_kernel().decode()
 
 
 def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
@@ -112,8 +118,9 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.alpha = alpha
     e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
-    _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
-        f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}")
+    if e0 is not None:
+        _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (M * K + N * K * taps + M * n_out), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
+            f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
     return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
 
 
@@ -175,7 +182,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
             sm, si = seg_mode.tolist(), seg_item.tolist()
             units = sum((2 if m != 0 else 1) for ri, rm in zip(si, sm) for i_, m in zip(ri, rm) if i_ >= 0)
         keys = nk * units
-        _pe(e0, f"attn_dh{dh}", 4.0 * heads * nq * keys * dh, 2.0 * 4 * n_items * nq * heads * dh)
+        nseg_exec = segments.SEG_COUNT.get(seg_item.data_ptr())
+        if nseg_exec is None:
+            nseg_exec = int((seg_item >= 0).sum().item())
+        _pe(e0, f"attn_dh{dh}", 4.0 * heads * nq * keys * dh, 2.0 * 4 * n_items * nq * heads * dh, "", _last_kernel(),
+            4.0 * heads * nq * nk * nseg_exec * dh)
     return out
 
 

@@ -18,6 +18,25 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+# data-path exchange accounting (bench.py reports it per step): kind -> [calls, payload bytes this rank sends or contributes]
+STATS = {}
+
+
+def _count(kind: str, t: torch.Tensor) -> None:
+    c = STATS.setdefault(kind, [0, 0])
+    c[0] += 1
+    c[1] += t.numel() * t.element_size()
+
+
+def reset_stats() -> None:
+    STATS.clear()
+
+
+def stats_summary(steps: int = 1) -> dict:
+    out = {k: {"calls_per_step": v[0] / steps, "mbytes_per_step": round(v[1] / steps / 1e6, 3)} for k, v in sorted(STATS.items())}
+    out["total"] = {"calls_per_step": sum(v[0] for v in STATS.values()) / steps, "mbytes_per_step": round(sum(v[1] for v in STATS.values()) / steps / 1e6, 3)}
+    return out
+
 
 class FrameShard:
     def __init__(self, f_total: int, group=None):
@@ -33,14 +52,28 @@ class FrameShard:
 
     # ---- GroupNorm statistics -------------------------------------------------------------------------
     def allreduce_(self, t: torch.Tensor) -> None:
+        _count("all_reduce(groupnorm stats)", t)
         dist.all_reduce(t, group=self.group)
 
     # ---- K|V rows of all frame shards, part-major -----------------------------------------------------
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        _count("all_gather(K|V rows)", t)
         dist.all_gather(list(out.unbind(0)), t, group=self.group)
         return out.reshape(self.world * t.shape[0], *t.shape[1:])
+
+    def kv_buffer(self, rows: int, cols: int, B: int, npix: int, like: torch.Tensor):
+        """(buffer for the completed K|V, the view of it this rank's projection GEMM writes into): the GEMM output lands in
+        its slot of the gathered tensor, so no copy precedes the exchange."""
+        ext = torch.empty((self.world, rows, cols), dtype=like.dtype, device=like.device)
+        return ext, ext[self.rank]
+
+    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
+        loc = ext[self.rank]
+        _count("all_gather(K|V rows)", loc)
+        dist.all_gather_into_tensor(ext.reshape(-1, ext.shape[-1]), loc, group=self.group)   # in place: input = this rank's slot
+        return ext.reshape(self.world * ext.shape[1], ext.shape[2])
 
     def item(self, B: int, b: int, g: int) -> int:
         """kv item index of (batch row b, GLOBAL frame g) inside an all-gathered [world][B*f_loc items] tensor."""
@@ -69,11 +102,13 @@ class FrameShard:
             first = torch.empty_like(prev_blk)
             for b in range(B):
                 copy_rows(first[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc) * npix:(b * self.f_loc + 1) * npix])
+            _count("p2p(TemporalConv halo)", first)
             ops_ += [dist.P2POp(dist.isend, first, self._ranks[self.rank - 1], self.group), dist.P2POp(dist.irecv, prev_blk, self._ranks[self.rank - 1], self.group)]
         if self.rank < self.world - 1:
             last = torch.empty_like(next_blk)
             for b in range(B):
                 copy_rows(last[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
+            _count("p2p(TemporalConv halo)", last)
             ops_ += [dist.P2POp(dist.isend, last, self._ranks[self.rank + 1], self.group), dist.P2POp(dist.irecv, next_blk, self._ranks[self.rank + 1], self.group)]
         if ops_:
             for r in dist.batch_isend_irecv(ops_):
@@ -99,15 +134,20 @@ class PrevFrameHalo:
             raise IndexError(f"frame {g} is neither local to rank {self.rank} nor its one-frame halo")
         return B + b * self.f_loc + (g - self.frame0)
 
-    def gather_kv(self, kv: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+    def kv_buffer(self, rows: int, cols: int, B: int, npix: int, like: torch.Tensor):
+        """[B halo items | local items]: the projection GEMM writes the local part in place (no whole-tensor copy)."""
+        ext = torch.empty((B * npix + rows, cols), dtype=like.dtype, device=like.device)
+        return ext, ext[B * npix:]
+
+    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
         s = self.s
-        ext = torch.empty(((B + B * self.f_loc) * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
-        copy_rows(ext[B * npix:], kv)
+        kv = ext[B * npix:]
         ops_ = []
         if self.rank < self.world - 1:
             last = torch.empty((B * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
             for b in range(B):
                 copy_rows(last[b * npix:(b + 1) * npix], kv[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
+            _count("p2p(attn1 K|V halo)", last)
             ops_.append(dist.P2POp(dist.isend, last, s._ranks[self.rank + 1], s.group))
         if self.rank > 0:
             ops_.append(dist.P2POp(dist.irecv, ext[:B * npix], s._ranks[self.rank - 1], s.group))
@@ -118,3 +158,7 @@ class PrevFrameHalo:
                 r.wait()
         return ext
 
+    def gather_kv(self, kv: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+        ext, loc = self.kv_buffer(kv.shape[0], kv.shape[1], B, npix, kv)
+        copy_rows(loc, kv)
+        return self.complete_kv(ext, B, npix, copy_rows)

@@ -86,13 +86,41 @@ class MotionEditorPipeline:
             image = torch.cat([image] * 2)
         return image
 
-    def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_cfg, negative_prompt, text_embeddings=None):
+    def _encode_prompt(self, prompt, device, num_videos_per_prompt, do_cfg, negative_prompt, text_embeddings=None, negative_text_embeddings=None):
+        """Reference :270-333: with classifier-free guidance and no per-step `uncond_embeddings`, the result is
+        cat([uncond, text]) = 2 * len(prompt) rows.  Without a text encoder the embeddings come in as tensors:
+        text_embeddings [len(prompt),77,768] (+ negative_text_embeddings [1 or len(prompt),77,768]), or text_embeddings
+        that already hold all 2 * len(prompt) rows."""
+        n = 1 if isinstance(prompt, str) else len(prompt)
         if text_embeddings is not None:
-            return text_embeddings.to(device)
+            cond = text_embeddings.to(device)
+            if not do_cfg or cond.shape[0] == 2 * n:
+                return cond
+            if negative_text_embeddings is None:
+                raise ValueError("classifier-free guidance without `uncond_embeddings` needs the unconditional rows: pass "
+                                 "negative_text_embeddings=[1 or len(prompt),77,768] (the encoding of the negative / empty prompt) or "
+                                 f"text_embeddings with {2 * n} rows = cat([uncond, text]) (reference :296-333)")
+            unc = negative_text_embeddings.to(device)
+            return torch.cat([unc.expand(cond.shape[0], -1, -1) if unc.shape[0] == 1 else unc, cond])
         if self.text_encoder is None or self.tokenizer is None:
             raise ValueError("no text_encoder/tokenizer: pass text_embeddings=[len(prompt),77,768] (CLIP encoding is out of scope)")
-        ids = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt").input_ids
-        return self.text_encoder(ids.to(self.text_encoder.device))[0].to(device)
+
+        def enc(texts):
+            ids = self.tokenizer(texts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True, return_tensors="pt").input_ids
+            return self.text_encoder(ids.to(self.text_encoder.device))[0].to(device)
+
+        cond = enc(prompt)
+        if not do_cfg:
+            return cond
+        if negative_prompt is None:
+            neg = [""] * n
+        elif isinstance(negative_prompt, str):
+            neg = [negative_prompt] * n
+        else:
+            if len(negative_prompt) != n:
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {n}")   # reference :309-314
+            neg = list(negative_prompt)
+        return torch.cat([enc(neg), cond])
 
     def decode_latents(self, latents):
         if self.vae is None:
@@ -105,27 +133,50 @@ class MotionEditorPipeline:
 
     @torch.no_grad()
     def denoise_step_frame_sharded(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
-                                   guidance_scale: float, shard, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
+                                   guidance_scale: float, shard, controlnet_conditioning_scale: float = 1.0, cfg_group=None) -> torch.Tensor:
         """The same step with the FRAME axis sharded over the ranks of `shard` (parallel.FrameShard; SURVEY.md 8e, BASELINE
         config 4).  latents fp32 [2,4,f_loc,h,w] and images [2*f_loc,3,H,W] (or [f_loc,...]) hold this rank's frames only.
-        Exchanges per layer: all-gather of K|V for attn1 / adapter sparse-causal / temporal attention, one-frame halos for the
-        temporal convolutions, all-reduce of the 5-D GroupNorm statistics.  ControlNet, CFG and DDIM are rank-local."""
+        Exchanges per layer: one-frame K|V halo for attn1, all-gather of K|V for adapter sparse-causal / temporal attention,
+        one-frame halos for the temporal convolutions, all-reduce of the 5-D GroupNorm statistics.  ControlNet, CFG and DDIM
+        are rank-local.
+
+        cfg_group (a 2-rank process group of the ranks that hold the SAME frames): hybrid CFG x frame sharding -- this rank
+        additionally runs only one classifier-free-guidance half (rank 0 of the pair: the unconditional (recon, edit) rows,
+        rank 1: the conditional ones), which halves every frame-shard exchange (batch 2 instead of 4); the pair trades its
+        4-channel noise predictions with one all-gather before the fused CFG + DDIM update."""
         if shard.f_total % 2:
             raise NotImplementedError("frame sharding relies on the ControlNet batch-entry identity, which needs an even frame count")
         f = latents.shape[2]
         assert f == shard.f_loc, (f, shard.f_loc)
-        x4 = torch.cat([latents] * 2)
+        r = 0
+        if cfg_group is None:
+            x = torch.cat([latents] * 2)
+            emb = text_embeddings_input
+        else:
+            import torch.distributed as dist
+            assert dist.get_world_size(cfg_group) == 2, "CFG parallelism is a 2-way split"
+            r = dist.get_rank(cfg_group)
+            x = latents                                   # both CFG halves see the same [recon, edit] latents (:605)
+            emb = text_embeddings_input[2 * r:2 * r + 2]
         down = mid = None
         two = False
         if self.controlnet is not None and images is not None:
             prompt = text_embeddings_input[[1, 3]]
             img = images[:f] if images.shape[0] == 2 * f else images
-            # row r of the full "(b f)" ControlNet batch reads prompt r % 2: this rank's first row is global frame frame0
-            down, mid = self.controlnet.forward_rows(x4, [1], t, prompt, img, controlnet_conditioning_scale, row_offset=shard.frame0)
+            # row of the full "(b f)" ControlNet batch = entry * f_total + global frame, and it reads prompt row % 2
+            # (pipeline :615,621): this rank's first row is entry r (its CFG half), global frame frame0
+            down, mid = self.controlnet.forward_rows(x, [1], t, prompt, img, controlnet_conditioning_scale, row_offset=r * shard.f_total + shard.frame0)
             two = True
-        eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, shard=shard)
+        eps = self.unet.forward_rows(x, t, emb, down, mid, two, shard=shard).t
+        if cfg_group is not None:
+            import torch.distributed as dist
+            from .. import parallel
+            both = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
+            parallel._count("all_gather(noise prediction, CFG pair)", eps)
+            dist.all_gather(list(both.unbind(0)), eps.contiguous(), group=cfg_group)   # rows: [uncond (rec, edit) | cond (rec, edit)]
+            eps = both.reshape(-1, eps.shape[1])
         ca, cb = self.scheduler.coeffs(int(t))
-        return ops.cfg_ddim(latents, eps.t, guidance=guidance_scale, ca=ca, cb=cb)
+        return ops.cfg_ddim(latents, eps, guidance=guidance_scale, ca=ca, cb=cb)
 
     @torch.no_grad()
     def denoise_step_cfg_parallel(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
@@ -150,6 +201,8 @@ class MotionEditorPipeline:
             two = True
         eps = self.unet.forward_rows(x2, t, emb, down, mid, two).t       # [(2 f N), 4]
         both = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
+        from .. import parallel
+        parallel._count("all_gather(noise prediction, CFG pair)", eps)
         dist.all_gather(list(both.unbind(0)), eps.contiguous(), group=group)   # rows: [uncond (rec, edit) | cond (rec, edit)]
         ca, cb = self.scheduler.coeffs(int(t))
         return ops.cfg_ddim(latents, both.reshape(-1, eps.shape[1]), guidance=guidance_scale, ca=ca, cb=cb)
@@ -214,7 +267,10 @@ class MotionEditorPipeline:
         if not do_cfg or batch_size != 2:
             raise NotImplementedError("the two-branch hot path needs guidance_scale > 1 and prompts = [source, target] (inference.py:296-323)")
         with_uncond = do_cfg if uncond_embeddings is None else False
-        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, with_uncond, negative_prompt, kwargs.get("text_embeddings"))
+        text_embeddings = self._encode_prompt(prompt, device, num_videos_per_prompt, with_uncond, negative_prompt, kwargs.get("text_embeddings"),
+                                              kwargs.get("negative_text_embeddings"))
+        if video_length is not None and self.controlnet is not None and video_length % 8:
+            raise ValueError(f"video_length must be a multiple of 8 with the motion adapter (controlnet_adapter.py:414 hard-codes chunks of 8 frames), got {video_length}")
 
         images = None
         if self.controlnet is not None:
@@ -235,6 +291,8 @@ class MotionEditorPipeline:
                 emb = torch.cat([uncond_embeddings[i].to(device).expand(*text_embeddings.shape), text_embeddings])   # :608-609
             else:
                 emb = text_embeddings
+            if emb.shape[0] != 2 * batch_size:
+                raise ValueError(f"expected {2 * batch_size} text-embedding rows [uncond x {batch_size}, cond x {batch_size}], got {emb.shape[0]}")
             latents = self.denoise_step(latents, t, emb, images, guidance_scale, 1.0)   # the loop hard-codes scale 1.0 (:616)
             if callback is not None and i % callback_steps == 0:
                 callback(i, t, latents)

@@ -14,6 +14,7 @@ from .capi import SEG_DUAL_BIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_PLAIN
 _cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
 GENERAL_DUAL: Dict[int, bool] = {}  # seg_mode.data_ptr() -> table uses the general (mask-reading) dual modes
 BINARY_DUAL: Dict[int, bool] = {}   # seg_mode.data_ptr() -> table has DUAL_BIN segments (me_attn then needs the vsum scratch)
+SEG_COUNT: Dict[int, int] = {}  # seg_item.data_ptr() -> number of valid (item, segment) entries = key segments actually multiplied
 KEY_UNITS: Dict[int, int] = {}  # seg_item.data_ptr() -> sum over items of (1 per plain, 2 per dual segment); FLOP accounting only
 
 
@@ -24,6 +25,7 @@ def _mk(key, rows_item, rows_mode, device):
         _cache[(key, str(device))] = hit
         GENERAL_DUAL[hit[1].data_ptr()] = any(m in (SEG_DUAL_CUR, SEG_DUAL_PREV) for rm in rows_mode for m in rm)
         BINARY_DUAL[hit[1].data_ptr()] = any(m == SEG_DUAL_BIN for rm in rows_mode for m in rm)
+        SEG_COUNT[hit[0].data_ptr()] = sum(1 for ri in rows_item for i_ in ri if i_ >= 0)
         KEY_UNITS[hit[0].data_ptr()] = sum((2 if m != SEG_PLAIN else 1) for ri, rm in zip(rows_item, rows_mode) for i_, m in zip(ri, rm) if i_ >= 0)
     return hit
 

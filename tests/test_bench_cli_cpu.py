@@ -1,0 +1,41 @@
+"""bench.py launch contract: `python bench.py --gpus N` with no WORLD_SIZE in the environment must start N ranks by itself
+(torch.distributed.run) and print ONE JSON line with n_gpus == N and the per-step exchange budget.  Runs the product host
+code on the CPU emulation of the C ABI (gloo) at a tiny shape."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--emulate", "--frames", "8", "--latent", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong"
+    assert d["config"]["parallel_mode"] == "cfg"
+    assert d["comm"]["total"]["calls_per_step"] == 1      # one all-gather of the noise prediction per step
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
+        assert k in d
+
+
+def test_mode_resolution():
+    sys.path.insert(0, str(ROOT))
+    import bench
+    A = type("A", (), {})
+    a = A()
+    a.parallel = "auto"
+    assert bench.resolve_mode(a, 1) == ("single", 1, 1, 1)
+    assert bench.resolve_mode(a, 2) == ("cfg", 2, 1, 1)
+    assert bench.resolve_mode(a, 4) == ("cfg-frames", 2, 2, 1)
+    assert bench.resolve_mode(a, 8) == ("cfg-frames", 2, 4, 1)
+    a.parallel = "frames"
+    assert bench.resolve_mode(a, 8) == ("frames", 1, 8, 1)
+    a.parallel = "replicas"
+    assert bench.resolve_mode(a, 4) == ("replicas", 1, 1, 4)

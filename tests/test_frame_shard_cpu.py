@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, f, out_path):
+def _worker(rank, world, port, f, out_path, hybrid=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -48,13 +48,31 @@ def _worker(rank, world, port, f, out_path):
     H = x["skeleton"].shape[-1]
     images = x["skeleton"].reshape(f, 3, H, H)
     emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]])
-    shard = parallel.FrameShard(f)
+    cfg_group = shard_group = None
+    if hybrid:   # rank = shard * 2 + cfg half (bench.py's layout): CFG pairs {0,1},{2,3}; frame-shard groups {0,2},{1,3}
+        ns = world // 2
+        for s_ in range(ns):
+            g = dist.new_group([2 * s_, 2 * s_ + 1])
+            if rank // 2 == s_:
+                cfg_group = g
+        for k in range(2):
+            g = dist.new_group([2 * s_ + k for s_ in range(ns)])
+            if rank % 2 == k:
+                shard_group = g
+    parallel.reset_stats()
+    shard = parallel.FrameShard(f, shard_group)
     lo, hi = shard.frame0, shard.frame0 + shard.f_loc
     ted.cur_step = sed.cur_step = step
-    got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard)
+    got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_group)
     assert (sed.cur_step, ted.cur_step, sed.cur_att_layer, ted.cur_att_layer) == (step + 1, step + 1, 0, 0)
+    st = parallel.stats_summary()
+    # exchange budget of one step: 16 attn1 halos, 28 + 12 K|V all-gathers, 45 GroupNorm all-reduces
+    assert st["all_gather(K|V rows)"]["calls_per_step"] == 40 and st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
     parts = [torch.empty_like(got) for _ in range(world)]
     dist.all_gather(parts, got)
+    if hybrid:   # both members of a CFG pair hold the same frames and must agree exactly
+        assert torch.equal(parts[rank], parts[rank ^ 1])
+        parts = parts[0::2]
     full = torch.cat(parts, dim=2)
     if rank == 0:   # single-process reference of the same step
         ted.reset(); sed.reset()
@@ -70,6 +88,16 @@ def test_frame_sharded_step_equals_single_process(tmp_path, f):
     out = tmp_path / "r.pt"
     port = 29700 + (os.getpid() % 2000) + f
     mp.spawn(_worker, args=(2, port, f, str(out)), nprocs=2, join=True)
+    err = torch.load(out)["err"]
+    assert err < 1e-4, err
+
+
+def test_hybrid_cfg_x_frame_sharded_step_equals_single_process(tmp_path):
+    """4 ranks = CFG pair x 2 frame shards (the 8-GPU layout at half size): every frame-shard exchange runs at batch 2 and the
+    pair trades its noise predictions once; the result must be the single-process step."""
+    out = tmp_path / "r.pt"
+    port = 29700 + (os.getpid() % 2000) + 77
+    mp.spawn(_worker, args=(4, port, 16, str(out), True), nprocs=4, join=True)
     err = torch.load(out)["err"]
     assert err < 1e-4, err
 
