@@ -62,7 +62,9 @@ def parse_args():
     ap.add_argument("--vae-decode", action="store_true",
                     help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
-    ap.add_argument("--no-graph", action="store_true", help="A/B: enqueue the ~1100 launches of every step from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="A/B: replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from "
+                         "Python; measured neutral at config 3 and at the 8-frame 256^2 shape (the GPU, not the host, paces both), so it is off by default")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     ap.add_argument("--emulate", action="store_true", help="test plumbing: torch-CPU emulation of the C ABI (tests/emu_ops.py), gloo backend")
@@ -297,7 +299,7 @@ def main():
         pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
         lat = lat[:1].contiguous()
 
-    use_graph = not (args.no_graph or args.emulate or args.inversion or dist_on) and hasattr(pipe, "denoise_step_graphed")
+    use_graph = args.graph and not (args.emulate or args.inversion or dist_on)
 
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
@@ -336,8 +338,8 @@ def main():
         from motioneditor_amd import parallel
         comm = parallel.stats_summary(args.steps)
     # Roofline pass: the SAME steps once more, eagerly, with a HIP event pair around every launch and on a single stream.
-    # It is not folded into the timed region because (a) the timed region replays a captured hipGraph, (b) ~1100 event pairs
-    # per step cost ~6 % of the step and (c) the timed region overlaps two streams (ControlNet + adapter beside the UNet),
+    # It is not folded into the timed region because (a) ~1100 event pairs per step cost ~6 % of the step and (b) the timed
+    # region overlaps two streams (ControlNet + adapter beside the UNet),
     # which stretches every kernel's own duration by whatever shares the GPU with it.
     prof = None
     if not args.no_profile and not args.emulate:
@@ -424,7 +426,7 @@ def main():
                                "algorithmic_bytes_per_launch": round(by / n), "launches_per_step": n // args.steps, "avg_launch_ms": round(tsec / n * 1e3, 4),
                                "share_of_gpu_time": round(tsec / tot, 3),
                                "measured_in": "event-instrumented single-stream eager pass of the same steps inside this run, right after the timed region "
-                                              "(the timed region is un-instrumented, replays a hipGraph and overlaps two streams)"}
+                                              "(the timed region is un-instrumented and overlaps two streams)"}
             out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
                                   "tflops_executed": round(v[4] / v[0] / 1e12, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps}
                               for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:8]}

@@ -179,7 +179,10 @@ typedef struct me_groupnorm_args {
   void* Y;         /* fp16 [rows, ldy]                                        */
   const void* gamma;
   const void* beta;
-  float* stats;    /* device scratch fp32 [n_groups_of_rows][32][2], zeroed by the call */
+  void* stats;     /* device scratch of me_groupnorm_scratch_bytes(rows, rows_per_group, groups) bytes, 16-byte aligned.  It starts
+                      with the statistics proper, fp64 [rows / rows_per_group][groups][2] = (sum, sum of squares) -- the part a
+                      frame-sharded caller all-reduces between me_groupnorm_stats and me_groupnorm_apply -- followed by the
+                      per-chunk partial sums of the deterministic (fixed-order, atomic-free) reduction */
   int32_t rows, rows_per_group;
   int32_t C, ldx, ldy;
   int32_t groups;  /* 32 */
@@ -188,8 +191,10 @@ typedef struct me_groupnorm_args {
 } me_groupnorm_args;
 
 int me_groupnorm(const me_groupnorm_args* a, void* stream);
+int64_t me_groupnorm_scratch_bytes(int32_t rows, int32_t rows_per_group, int32_t groups);
 /* The two halves of me_groupnorm, for frame-sharded runs: stats zeroes a->stats and accumulates this rank's
- * (sum, sum of squares); the host all-reduces a->stats over the ranks; apply normalises with the GLOBAL element
+ * (sum, sum of squares) in fp64; the host all-reduces the first rows / rows_per_group * groups * 2 doubles of a->stats over the
+ * ranks; apply normalises with the GLOBAL element
  * count rows_per_group_total * (C / groups). */
 int me_groupnorm_stats(const me_groupnorm_args* a, void* stream);
 int me_groupnorm_apply(const me_groupnorm_args* a, int64_t rows_per_group_total, void* stream);
@@ -225,6 +230,12 @@ int me_timestep_embed(void* out, int32_t rows, int32_t dim, float t, void* strea
  * latents fp32 in the reference layout [nb, C, frames, npix];  out = ca*x + cb*(eu + g*(ec-eu)). */
 int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C,
                 int32_t frames, int32_t npix, float guidance, float ca, float cb, void* stream);
+/* The same two calls with their per-step scalars in DEVICE memory -- step_params = fp32 [4] {t, guidance, ca, cb} -- so that a
+ * whole denoising step captured into a hipGraph (MotionEditorPipeline.denoise_step_graphed) replays for every timestep:
+ * the host writes the four floats, then launches the graph. */
+int me_timestep_embed_dev(void* out, int32_t rows, int32_t dim, const float* step_params, void* stream);
+int me_cfg_ddim_dev(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C,
+                    int32_t frames, int32_t npix, const float* step_params, void* stream);
 /* fp32 [n_img, C, H*W] (img/channel strides in elements) -> fp16 channels-last [n_img*H*W, ldy] */
 int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride,
                     int32_t n_img, int32_t C, int32_t npix, void* stream);

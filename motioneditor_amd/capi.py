@@ -89,6 +89,7 @@ SYMBOLS = {
     "me_attn": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "me_tattn": (C.c_int, [C.POINTER(TAttnArgs), _vp]),
     "me_groupnorm": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "me_groupnorm_scratch_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "me_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "me_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), _i64, _vp]),
     "me_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), _vp]),
@@ -99,6 +100,8 @@ SYMBOLS = {
     "me_relu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "me_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f32, _vp]),
     "me_cfg_ddim": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
+    "me_timestep_embed_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "me_cfg_ddim_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "me_nchw_to_rows": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "me_rows_to_nchw": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
 }

@@ -103,7 +103,9 @@ __global__ __launch_bounds__(256) void unary_kernel(f16* Y, const f16* X, long n
   }
 }
 
-__global__ void timestep_embed_kernel(f16* out, int rows, int dim, float t) {
+// tp != nullptr: the timestep is read from device memory (hipGraph replay: the captured launch stays valid across steps)
+__global__ void timestep_embed_kernel(f16* out, int rows, int dim, float t, const float* __restrict__ tp) {
+  if (tp) t = tp[0];
   const int half = dim / 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= rows * dim) return;
@@ -115,7 +117,12 @@ __global__ void timestep_embed_kernel(f16* out, int rows, int dim, float t) {
 }
 
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(float* lat_out, const float* lat_in, const f16* eps, int lde, int nb, int C, int frames,
-                                                       int npix, float guidance, float ca, float cb) {
+                                                       int npix, float guidance, float ca, float cb, const float* __restrict__ pp) {
+  if (pp) {   // device-resident step parameters [t, guidance, ca, cb]
+    guidance = pp[1];
+    ca = pp[2];
+    cb = pp[3];
+  }
   const long total = (long)nb * C * frames * npix;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
@@ -227,8 +234,16 @@ extern "C" int me_timestep_embed(void* out, int32_t rows, int32_t dim, float t, 
   if (!out || rows <= 0 || dim <= 0 || dim % 2) { me_set_error("me_timestep_embed: bad arguments"); return ME_EINVAL; }
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(timestep_embed_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(out), rows,
-                     dim, t);
+                     dim, t, (const float*)nullptr);
   ME_CHECK_LAUNCH("me_timestep_embed")
+}
+
+extern "C" int me_timestep_embed_dev(void* out, int32_t rows, int32_t dim, const float* step_params, void* stream) {
+  if (!out || !step_params || rows <= 0 || dim <= 0 || dim % 2) { me_set_error("me_timestep_embed_dev: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((rows * dim + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(out), rows,
+                     dim, 0.f, step_params);
+  ME_CHECK_LAUNCH("me_timestep_embed_dev")
 }
 
 extern "C" int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C, int32_t frames, int32_t npix,
@@ -237,8 +252,18 @@ extern "C" int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps,
   const long total = (long)nb * C * frames * npix;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lat_out, lat_in,
-                     reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, guidance, ca, cb);
+                     reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, guidance, ca, cb, (const float*)nullptr);
   ME_CHECK_LAUNCH("me_cfg_ddim")
+}
+
+extern "C" int me_cfg_ddim_dev(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C, int32_t frames, int32_t npix,
+                               const float* step_params, void* stream) {
+  if (!lat_out || !lat_in || !eps || !step_params || nb <= 0 || C <= 0 || frames <= 0 || npix <= 0 || lde < C) { me_set_error("me_cfg_ddim_dev: bad arguments"); return ME_EINVAL; }
+  const long total = (long)nb * C * frames * npix;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lat_out, lat_in,
+                     reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, 0.f, 0.f, 0.f, step_params);
+  ME_CHECK_LAUNCH("me_cfg_ddim_dev")
 }
 
 extern "C" int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride, int32_t n_img, int32_t C, int32_t npix,

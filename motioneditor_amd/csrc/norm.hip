@@ -1,8 +1,8 @@
 // GroupNorm(+SiLU) and LayerNorm on channels-last fp16 activations (HBM-bound kernels, gfx950).
 //
 // GroupNorm: pass 1 accumulates (sum, sum of squares) per (row-group, channel-group) with 16-byte
-// loads, register accumulation down the rows, LDS float atomics across the block and one global
-// atomic per (block, group); pass 2 re-reads X, normalises, applies gamma/beta (+SiLU), writes Y.
+// loads and register accumulation down the rows, reduces them in a fixed order (no atomics: bitwise
+// reproducible) into fp64 statistics; pass 2 re-reads X, normalises, applies gamma/beta (+SiLU), writes Y.
 // Algorithmic bytes per call: rows*C*2 (read) + rows*C*2 (write); the statistics pass re-reads X.
 // LayerNorm: one wave per row, two-pass mean/variance in registers.
 #include "me_common.h"
@@ -10,13 +10,18 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X, float* __restrict__ stats, int rows_per_group,
+// Pass 1, deterministic and cancellation-free: every block reduces its row chunk to one (S1, S2) pair per channel group,
+// S1 = sum(x - K), S2 = sum((x - K)^2) with the shift K = the group's first element of the chunk (so the sums stay small
+// however large the group mean is: fp32 partial sums of raw x^2 lose the variance of SD-like activations whose mean is 1e2 -
+// 1e3 times their spread), in a FIXED summation order -- per-thread register sums down the rows, a fixed-order sum over the
+// block's row lanes per channel, a fixed-order sum over the group's channels -- and writes (S1, S2, K) to
+// part[chunk][sample-group][group].  gn_finalize_kernel merges the chunks in index order in fp64 (Chan's update of
+// (count, mean, M2)).  Round 1 used LDS / global float atomics on raw sums: run-to-run differences of 1.2e-3 rel-L2.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X, float4* __restrict__ part, int rows_per_group,
                                                        int chunk_rows, int C, int ldx, int groups) {
-  __shared__ float sacc[64][2];
+  extern __shared__ __attribute__((aligned(16))) float2 red[];   // [row lane][channel of the pass]
+  __shared__ float2 chan[2560];                                    // per-channel sums of the block (C <= 2560: the widest skip concat)
   const int tid = threadIdx.x;
-  if (tid < 64) { sacc[tid][0] = 0.f; sacc[tid][1] = 0.f; }
-  __syncthreads();
-
   const int sg = blockIdx.y;
   const int r0 = blockIdx.x * chunk_rows;
   const int r1 = min(r0 + chunk_rows, rows_per_group);
@@ -26,48 +31,75 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
   const int RL = 256 / tprc;                   // row lanes
   const int cg = C / groups;
   const f16* base = X + (long)sg * rows_per_group * ldx;
+  const f16* first = base + (long)r0 * ldx;    // the chunk's first row: source of the shifts
 
-  if (rl < RL) {
-    for (int vc = vc0; vc < tpr; vc += tprc) {
-      float s[8], q[8];
+  for (int pass0 = 0; pass0 < tpr; pass0 += tprc) {
+    const int vc = pass0 + vc0;
+    if (rl < RL && vc < tpr) {
+      float s[8], q[8], K[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int e = 0; e < 8; ++e) {
+        s[e] = 0.f;
+        q[e] = 0.f;
+        K[e] = (float)first[((vc * 8 + e) / cg) * cg];
+      }
 #pragma unroll 4
       for (int r = r0 + rl; r < r1; r += RL) {   // 4 independent 16-byte loads in flight per thread
         U128 u;
         u.u = ldg128(base + (long)r * ldx + vc * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float v = (float)u.e[e];
+          const float v = (float)u.e[e] - K[e];
           s[e] += v;
           q[e] += v * v;
         }
       }
-      // fold the 8 channels into their (at most two when cg >= 8, else more) groups
-      int gcur = (vc * 8) / cg;
-      float ss = 0.f, qq = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ge = (vc * 8 + e) / cg;
-        if (ge != gcur) {
-          atomicAdd(&sacc[gcur][0], ss);
-          atomicAdd(&sacc[gcur][1], qq);
-          gcur = ge;
-          ss = 0.f;
-          qq = 0.f;
-        }
-        ss += s[e];
-        qq += q[e];
-      }
-      atomicAdd(&sacc[gcur][0], ss);
-      atomicAdd(&sacc[gcur][1], qq);
+      for (int e = 0; e < 8; ++e) red[rl * (tprc * 8) + vc0 * 8 + e] = make_float2(s[e], q[e]);
     }
+    __syncthreads();
+    for (int cidx = tid; cidx < tprc * 8 && pass0 * 8 + cidx < C; cidx += 256) {   // fixed order over the row lanes
+      float2 a = red[cidx];
+      for (int l = 1; l < RL; ++l) {
+        const float2 b = red[l * (tprc * 8) + cidx];
+        a.x += b.x;
+        a.y += b.y;
+      }
+      chan[pass0 * 8 + cidx] = a;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < groups) {
-    atomicAdd(&stats[((long)sg * groups + tid) * 2 + 0], sacc[tid][0]);
-    atomicAdd(&stats[((long)sg * groups + tid) * 2 + 1], sacc[tid][1]);
+  if (tid < groups) {                                                               // fixed order over the group's channels
+    float2 a = chan[tid * cg];
+    for (int cc = 1; cc < cg; ++cc) {
+      const float2 b = chan[tid * cg + cc];
+      a.x += b.x;
+      a.y += b.y;
+    }
+    part[((long)blockIdx.x * gridDim.y + sg) * groups + tid] = make_float4(a.x, a.y, (float)first[tid * cg], 0.f);
   }
+}
+
+// stats[sg][g] = (sum, sum of squares) in fp64 from the chunks' shifted partial sums, merged in chunk order:
+// chunk mean = K + S1 / n, chunk M2 = S2 - S1^2 / n, then Chan's pairwise update of (n, mean, M2)
+__global__ void gn_finalize_kernel(const float4* __restrict__ part, double* __restrict__ stats, int chunks, int chunk_rows, int rows_per_group,
+                                   int nsg, int groups, int cg) {
+  const int sg = blockIdx.x, g = threadIdx.x;
+  if (g >= groups) return;
+  double n = 0.0, mean = 0.0, M2 = 0.0;
+  for (int c = 0; c < chunks; ++c) {
+    const float4 p = part[((long)c * nsg + sg) * groups + g];
+    const int rows_c = min((c + 1) * chunk_rows, rows_per_group) - c * chunk_rows;
+    const double nb = (double)rows_c * (double)cg;
+    const double mb = (double)p.z + (double)p.x / nb;
+    const double M2b = fmax((double)p.y - (double)p.x * (double)p.x / nb, 0.0);
+    const double delta = mb - mean, nt = n + nb;
+    mean += delta * (nb / nt);
+    M2 += M2b + delta * delta * (n * nb / nt);
+    n = nt;
+  }
+  stats[((long)sg * groups + g) * 2 + 0] = n * mean;
+  stats[((long)sg * groups + g) * 2 + 1] = M2 + n * mean * mean;
 }
 
 // y = x * A[c] + B[c] (+ SiLU) with A = rstd * gamma, B = beta - mean * rstd * gamma.  A thread owns ONE 16-byte
@@ -75,13 +107,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
 // registers and the inner loop is load - 8 FMA - store (the first version re-derived row, group, mean and rstd with
 // integer divisions and an rsqrt for every vector and ran at 2 TB/s).  blockDim.x = vectors per row handled by the
 // block (a divisor of C/8, <= 256), blockDim.y rows in flight: a wave covers whole contiguous row segments.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, const float* __restrict__ stats,
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, const double* __restrict__ stats,
                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta, long rows,
                                                        int rows_per_group, long rows_per_group_total, int C, int ldx, int ldy, int groups,
                                                        float eps, int silu, int chunk) {
   const int vc = blockIdx.y * blockDim.x + threadIdx.x;   // 16-byte vector column
   const int cg = C / groups;
-  const float inv_cnt = 1.0f / ((float)rows_per_group_total * (float)cg);   // global count when frame-sharded
+  const double inv_cnt = 1.0 / ((double)rows_per_group_total * (double)cg);   // global count when frame-sharded
   U128 gm, bt;
   gm.u = ldg128(gamma + vc * 8);
   bt.u = ldg128(beta + vc * 8);
@@ -96,8 +128,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, con
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int ge = (vc * 8 + e) / cg;
-      const float mean = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
-      const float var = fmaxf(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean * mean, 0.f);
+      // E[x^2] - mean^2 in fp64: exact to ~1e-16 * mean^2, so a group whose mean dwarfs its spread keeps its variance
+      const double mean_d = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
+      const float var = fmaxf((float)(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean_d * mean_d), 0.f);
+      const float mean = (float)mean_d;
       A[e] = rsqrtf(var + eps) * (float)gm.e[e];
       B[e] = (float)bt.e[e] - mean * A[e];
     }
@@ -233,23 +267,45 @@ static int gn_validate(const me_groupnorm_args* a) {
   return ME_OK;
 }
 
-extern "C" int me_groupnorm_stats(const me_groupnorm_args* a, void* stream) {
-  if (int rc = gn_validate(a)) return rc;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// chunk geometry of the statistics pass (shared by me_groupnorm_scratch_bytes): ~1024 blocks in total, at most 512 per sample-group
+static void gn_chunks(const me_groupnorm_args* a, int* chunks_out, int* chunk_rows_out) {
   const int nsg = a->rows / a->rows_per_group;
-  if (hipMemsetAsync(a->stats, 0, (size_t)nsg * a->groups * 2 * sizeof(float), st) != hipSuccess) { me_set_error("me_groupnorm: memset failed"); return ME_EHIP; }
-  // ~1024 blocks in total, at most 512 per sample-group: every block ends with one global float atomic per channel
-  // group on the same groups * 2 addresses of its sample-group, and with 2048 blocks on ONE sample (DDIM inversion,
-  // B = 1) those atomics, not the 250 MB read, set the time (4.6 -> 3.0 ms per inversion step)
   int chunks = 1024 / nsg;
   if (chunks > 512) chunks = 512;
   if (chunks < 1) chunks = 1;
   int chunk_rows = (a->rows_per_group + chunks - 1) / chunks;
   if (chunk_rows < 8) chunk_rows = 8;
   chunks = (a->rows_per_group + chunk_rows - 1) / chunk_rows;
+  *chunks_out = chunks;
+  *chunk_rows_out = chunk_rows;
+}
+
+extern "C" int64_t me_groupnorm_scratch_bytes(int32_t rows, int32_t rows_per_group, int32_t groups) {
+  if (rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || groups <= 0) return 0;
+  me_groupnorm_args a{};
+  a.rows = rows;
+  a.rows_per_group = rows_per_group;
+  int chunks, chunk_rows;
+  gn_chunks(&a, &chunks, &chunk_rows);
+  const int64_t nsg = rows / rows_per_group;
+  return nsg * groups * 2 * (int64_t)sizeof(double) + (int64_t)chunks * nsg * groups * (int64_t)sizeof(float4);
+}
+
+extern "C" int me_groupnorm_stats(const me_groupnorm_args* a, void* stream) {
+  if (int rc = gn_validate(a)) return rc;
+  if (a->C > 2560) { me_set_error("me_groupnorm: C must be <= 2560"); return ME_EINVAL; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nsg = a->rows / a->rows_per_group;
+  int chunks, chunk_rows;
+  gn_chunks(a, &chunks, &chunk_rows);
+  double* stats = reinterpret_cast<double*>(a->stats);
+  float4* part = reinterpret_cast<float4*>(stats + (size_t)nsg * a->groups * 2);
+  const int tpr = a->C / 8, tprc = tpr < 256 ? tpr : 256;
+  const size_t lds = (size_t)(256 / tprc) * tprc * 8 * sizeof(float2);
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), 0, st, reinterpret_cast<const f16*>(a->X), a->stats, a->rows_per_group,
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), lds, st, reinterpret_cast<const f16*>(a->X), part, a->rows_per_group,
                      chunk_rows, a->C, a->ldx, a->groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(64), 0, st, part, stats, chunks, chunk_rows, a->rows_per_group, nsg, a->groups, a->C / a->groups);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_stats: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }
@@ -270,7 +326,7 @@ extern "C" int me_groupnorm_apply(const me_groupnorm_args* a, int64_t rows_per_g
   const long nbx = (a->rows + chunk - 1) / chunk;
   (void)hipGetLastError();
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, (unsigned)ny), dim3(bx, by), 0, st, reinterpret_cast<const f16*>(a->X), reinterpret_cast<f16*>(a->Y),
-                     a->stats, reinterpret_cast<const f16*>(a->gamma), reinterpret_cast<const f16*>(a->beta), (long)a->rows, a->rows_per_group,
+                     reinterpret_cast<const double*>(a->stats), reinterpret_cast<const f16*>(a->gamma), reinterpret_cast<const f16*>(a->beta), (long)a->rows, a->rows_per_group,
                      (long)rows_per_group_total, a->C, a->ldx, a->ldy, a->groups, a->eps, a->silu, (int)chunk);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_apply: kernel launch failed"); return ME_EHIP; }
   return ME_OK;

@@ -225,10 +225,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_
     if out is None:
         out = empty(rows, Cc, x)
     nsg = rows // rows_per_group
-    key = (x.device, nsg * groups)
+    nbytes = capi.lib().me_groupnorm_scratch_bytes(rows, rows_per_group, groups)
+    # per stream (two streams never share a statistics buffer) and per capture (a buffer born inside a hipGraph's pool stays there)
+    key = (x.device, nbytes, _stream(), torch.cuda.is_current_stream_capturing())
     stats = _gn_scratch.get(key)
     if stats is None:
-        stats = _gn_scratch[key] = torch.empty(nsg * groups * 2, dtype=torch.float32, device=x.device)
+        stats = _gn_scratch[key] = torch.empty(nbytes // 8, dtype=torch.float64, device=x.device)
     a = GroupNormArgs()
     a.X, a.Y, a.gamma, a.beta, a.stats = x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr()
     a.rows, a.rows_per_group, a.C, a.ldx, a.ldy = rows, rows_per_group, Cc, x.stride(0), out.stride(0)
@@ -238,7 +240,7 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_
         capi.check(capi.lib().me_groupnorm(C.byref(a), _stream()), "me_groupnorm")
     else:
         capi.check(capi.lib().me_groupnorm_stats(C.byref(a), _stream()), "me_groupnorm_stats")
-        reduce(stats[:nsg * groups * 2])
+        reduce(stats[:nsg * groups * 2])   # fp64 (sum, sum of squares) of every (sample-group, channel group)
         capi.check(capi.lib().me_groupnorm_apply(C.byref(a), rows_per_group_total or rows_per_group, _stream()), "me_groupnorm_apply")
     _pe(e0, "groupnorm", 8.0 * rows * Cc, 4.0 * rows * Cc)
     return out
@@ -296,8 +298,17 @@ def relu(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# Device-resident step scalars {t, guidance, ca, cb} (fp32 [4]) while a denoising step is captured into / replayed from a
+# hipGraph: the launches below then read them from memory instead of baking this step's values into the captured kernel
+# arguments.  Set by pipelines.MotionEditorPipeline.denoise_step_graphed; None = plain scalar arguments.
+STEP_PARAMS: Optional[torch.Tensor] = None
+
+
 def timestep_embed(rows: int, dim: int, t: float, device) -> torch.Tensor:
     out = torch.empty((rows, dim), dtype=F16, device=device)
+    if STEP_PARAMS is not None:
+        capi.check(capi.lib().me_timestep_embed_dev(out.data_ptr(), rows, dim, STEP_PARAMS.data_ptr(), _stream()), "me_timestep_embed_dev")
+        return out
     capi.check(capi.lib().me_timestep_embed(out.data_ptr(), rows, dim, float(t), _stream()), "me_timestep_embed")
     return out
 
@@ -308,6 +319,10 @@ def cfg_ddim(latents: torch.Tensor, eps_rows: torch.Tensor, *, guidance: float, 
     if latents.dtype != torch.float32 or not latents.is_contiguous():
         raise ValueError("cfg_ddim: latents must be contiguous fp32")
     out = torch.empty_like(latents)
+    if STEP_PARAMS is not None:
+        capi.check(capi.lib().me_cfg_ddim_dev(out.data_ptr(), latents.data_ptr(), eps_rows.data_ptr(), eps_rows.stride(0), nb, Cc, f, h * w,
+                                              STEP_PARAMS.data_ptr(), _stream()), "me_cfg_ddim_dev")
+        return out
     capi.check(capi.lib().me_cfg_ddim(out.data_ptr(), latents.data_ptr(), eps_rows.data_ptr(), eps_rows.stride(0), nb, Cc, f, h * w,
                                       guidance, ca, cb, _stream()), "me_cfg_ddim")
     return out

@@ -47,6 +47,7 @@ class MotionEditorPipeline:
         self.overlap_controlnet = True
         self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
         self._side_stream = None
+        self._graphs = {}               # denoise_step_graphed: (shapes, editor gating) -> captured step
 
     @property
     def _execution_device(self):
@@ -161,7 +162,7 @@ class MotionEditorPipeline:
         down = mid = None
         two = False
         if self.controlnet is not None and images is not None:
-            prompt = text_embeddings_input[[1, 3]]
+            prompt = text_embeddings_input[1::2]
             img = images[:f] if images.shape[0] == 2 * f else images
             # row of the full "(b f)" ControlNet batch = entry * f_total + global frame, and it reads prompt row % 2
             # (pipeline :615,621): this rank's first row is entry r (its CFG half), global frame frame0
@@ -195,7 +196,7 @@ class MotionEditorPipeline:
         down = mid = None
         two = False
         if self.controlnet is not None and images is not None:
-            prompt = text_embeddings_input[[1, 3]]                         # the interleave r % 2 needs BOTH prompts on every rank (:615,621)
+            prompt = text_embeddings_input[1::2]                         # the interleave r % 2 needs BOTH prompts on every rank (:615,621)
             nimg = images.shape[0] // 2
             down, mid = self.controlnet.forward_rows(x2, [1], t, prompt, images[r * nimg:(r + 1) * nimg], controlnet_conditioning_scale, row_offset=r * f)
             two = True
@@ -217,7 +218,7 @@ class MotionEditorPipeline:
         down = mid = ready = None
         two = False
         if self.controlnet is not None and images is not None:
-            prompt = text_embeddings_input[[1, 3]]                         # :615; .repeat(f,1,1) on "(b f)" rows -> row r reads r % 2 (:621)
+            prompt = text_embeddings_input[1::2]                         # :615; .repeat(f,1,1) on "(b f)" rows -> row r reads r % 2 (:621)
             f = latents.shape[2]
 
             def run_controlnet():
@@ -247,6 +248,58 @@ class MotionEditorPipeline:
             taps["eps_rows"] = eps.t.clone()
         ca, cb = self.scheduler.coeffs(int(t))
         return ops.cfg_ddim(latents, eps.t, guidance=guidance_scale, ca=ca, cb=cb)         # :643-648
+
+    # ---- hipGraph replay of the step -------------------------------------------------------------------------------------
+    def _editor_gate(self):
+        """What the editors will do during the coming step: a pure function of their step counters (fully_control.py:434,
+        temporal_control.py:74), so two captured graphs (editors inactive / active) cover a whole run."""
+        sed, ted = self.unet.spatial_editor, self.unet.temporal_editor
+        return (None if sed is None else sed.cur_step in sed.step_idx, None if ted is None else ted.cur_step in ted.step_idx)
+
+    @torch.no_grad()
+    def denoise_step_graphed(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
+                             guidance_scale: float, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
+        """denoise_step with its ~1100 kernel launches (both HIP streams) captured ONCE into a hipGraph and replayed: shapes and
+        key-segment tables are static, the editors' gating is a function of the step index, and the per-step scalars
+        (timestep, guidance, DDIM coefficients) live in device memory (ops.STEP_PARAMS), so a replay needs four host writes
+        and one launch.  The first call per (shape, gating) runs the step eagerly (warm-up: allocations, tables, function
+        attributes) and captures it; editors' counters advance exactly as in the eager step."""
+        sed, ted = self.unet.spatial_editor, self.unet.temporal_editor
+        key = (tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr()),
+               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.overlap_controlnet, self.overlap_adapter)
+        ca, cb = self.scheduler.coeffs(int(t))
+        host = torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32)
+        ent = self._graphs.get(key)
+        if ent is None:
+            counters = [(e.cur_step, e.cur_att_layer) for e in (sed, ted) if e is not None]
+            st = dict(lat=latents.clone(), emb=text_embeddings_input.clone(), params=host.to(latents.device))
+            self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)   # warm-up, eager
+            torch.cuda.synchronize()
+            for e, (cs, cl) in zip([e for e in (sed, ted) if e is not None], counters):
+                e.cur_step, e.cur_att_layer = cs, cl
+            g = torch.cuda.CUDAGraph()
+            ops.STEP_PARAMS = st["params"]
+            try:
+                with torch.cuda.graph(g):
+                    st["out"] = self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)
+            finally:
+                ops.STEP_PARAMS = None
+            st["graph"] = g
+            st["images"] = images      # keep the captured conditioning tensor alive
+            st["counters"] = [(e.cur_step, e.cur_att_layer) for e in (sed, ted) if e is not None]   # state after one step
+            for e, (cs, cl) in zip([e for e in (sed, ted) if e is not None], counters):
+                e.cur_step, e.cur_att_layer = cs, cl
+            ent = self._graphs[key] = st
+        ent["lat"].copy_(latents)
+        ent["emb"].copy_(text_embeddings_input)
+        ent["params"].copy_(host, non_blocking=False)
+        ent["graph"].replay()
+        for e in (sed, ted):
+            if e is not None:      # what MutualAttentionBase.__call__ does over the step's attention layers
+                e.cur_att_layer = 0
+                e.cur_step += 1
+                e.after_step()
+        return ent["out"].clone()
 
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,

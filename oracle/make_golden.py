@@ -208,6 +208,22 @@ def main():
     np.savez_compressed(GOLD / "unet_single.npz", out=ref.numpy().astype(np.float32), out_stats=stats(ref),
                         skip_stats=np.stack([stats(s) for s in taps["skips"]]), mid_stats=stats(taps["mid"]), oracle_relerr=e)
 
+    # ---- case A32: the same at 32x32 latents (level 0 = 1024 tokens, level 3 = 4x4): a golden whose attention launches have
+    # several query blocks and 16+ key tiles per segment ----
+    if "--skip-32" not in sys.argv:
+        c32 = make_case_inputs("single32", B=2, f=8, h=32, w=32)
+        with torch.no_grad():
+            t0 = time.time()
+            ref = quiet(unet, c32["sample"], torch.tensor(c32["t"]), c32["ehs"]).sample
+            print(f"reference single-branch 32x32 forward {time.time()-t0:.1f}s")
+            mine = ref_cpu.unet_forward(sd, c32["sample"], c32["t"], c32["ehs"])
+        e = relerr(mine, ref)
+        print("single-branch 32x32 oracle vs reference rel err", e)
+        assert e < 2e-4, e
+        np.savez_compressed(GOLD / "unet_single_32.npz", out=ref.numpy().astype(np.float16), out_stats=stats(ref), oracle_relerr=e)
+    if "--only-32" in sys.argv:
+        return
+
     if "--skip-two-branch" in sys.argv:
         return
 

@@ -230,6 +230,37 @@ def test_attention_edited_binary_fast_path_equals_general_dual(ops, dh, N):
     check(got, want, f"attn edited binary fast path dh={dh} N={N}")
 
 
+@pytest.mark.parametrize("dh,N,kind", [(40, 4096, "pc"), (40, 4096, "ed_bin"), (40, 4096, "ed_gen"), (80, 1024, "pc"), (80, 1024, "ed_bin"), (80, 1024, "ed_gen")])
+def test_attention_production_size(ops, dh, N, kind):
+    """The benchmarked launch geometry (level 0: 4096 queries x 2 / 3 segments of 4096 keys = 128 / 192 key tiles, 16 query
+    blocks of 256; level 1: 1024 x 1024): every query block and every rescale of the online softmax is exercised; the fp32
+    reference is evaluated on a random subset of 192 query rows per item (the full score matrix of one edited item is 2.7 GB)."""
+    from motioneditor_amd import segments
+    C = 8 * dh
+    if kind == "pc":
+        B, f = 1, 2
+        si, sm = segments.prev_cur(B, f, "cpu")
+        n_items, mask = B * f, None
+    else:
+        B, f = 2, 1                                    # one (recon, edit) pair, one frame: the edit item attends 3 segments (5N reference keys)
+        si, sm = segments.edited_spatial(f, "cpu", binary_mask=(kind == "ed_bin"), B=B)
+        g = torch.Generator().manual_seed(11)
+        mask = (torch.rand(8, N, generator=g) > 0.5).half() if kind == "ed_bin" else torch.rand(8, N, generator=g).half()
+        n_items = B * f
+    qkv = rnd(n_items * N, 3 * C, seed=3)
+    qkv[N // 2 + 5, C:2 * C] *= 4.0                    # a few dominant keys: late jumps of the running max
+    qkv[N - 3, C:2 * C] *= 6.0
+    args = dict(heads=8, dh=dh, n_items=n_items, nk=N)
+    got = ops.attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), mask=None if mask is None else cu(mask), nq=N, **args)
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:192].sort().values
+    rows = torch.cat([it * N + idx for it in range(n_items)])
+    want = emu.attention(qkv[rows, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, mask=mask, nq=idx.numel(), **args)
+    # averaging over thousands of keys makes the typical output tiny next to the rows a dominant key pulls to |V| ~ 0.5: bound the
+    # largest error by the largest output (fp16 rounding of the output is 5e-4 of it) rather than by the mean
+    peak = float(want.float().abs().max() / want.float().abs().mean())
+    check(got.cpu()[rows], want, f"attn production size dh={dh} N={N} {kind}", mx=2e-3 * peak)
+
+
 def test_attention_large_logits_online_softmax_rescale(ops):
     """Force the running max to jump late (a spiked key in the LAST tile) so the rescale path matters."""
     dh, nq, nk, C = 40, 64, 300, 320
@@ -270,6 +301,25 @@ def test_groupnorm(ops, C, rows, rpg, silu):
     gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
     got = ops.groupnorm(cu(x), cu(gm), cu(bt), rows_per_group=rpg, eps=1e-5, silu=silu)
     check(got, emu.groupnorm(x, gm, bt, rows_per_group=rpg, eps=1e-5, silu=silu), f"groupnorm C={C}")
+
+
+@pytest.mark.parametrize("C,rows,rpg,mean", [(320, 4096, 2048, 100.0), (640, 6 * 1024, 6 * 1024, 300.0), (1280, 512, 64, 40.0)])
+def test_groupnorm_large_mean_small_spread(ops, C, rows, rpg, mean):
+    """Activations whose group mean dwarfs their spread (SD feature maps: |x| ~ 1e2 with sub-unit variation): E[x^2] - mean^2
+    cancels catastrophically in fp32; the kernel keeps the statistics in fp64."""
+    x = (mean + 0.25 * rnd(rows, C, seed=1)).half()     # fp16 resolution at 300 is 0.25: the data itself is coarse, the reference sees the same
+    gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
+    got = ops.groupnorm(cu(x), cu(gm), cu(bt), rows_per_group=rpg, eps=1e-5, silu=False)
+    want = emu.groupnorm(x.double(), gm.double(), bt.double(), rows_per_group=rpg, eps=1e-5, silu=False)
+    check(got, want.float(), f"groupnorm large mean C={C} mean={mean}")
+
+
+def test_groupnorm_is_bitwise_reproducible(ops):
+    x = cu((rnd(4 * 96 * 64, 320, seed=1) * 2 + 0.7).half())
+    gm, bt = cu((1 + 0.1 * rnd(320, seed=2)).half()), cu((0.1 * rnd(320, seed=3)).half())
+    outs = [ops.groupnorm(x, gm, bt, rows_per_group=96 * 64, eps=1e-5, silu=True).clone() for _ in range(5)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("C,rows", [(320, 1000), (640, 77), (1280, 130)])

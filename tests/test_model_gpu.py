@@ -71,6 +71,19 @@ def test_unet_single_branch_vs_reference_golden(unet):
     assert e <= UNET_TOL, e
 
 
+def test_unet_single_branch_32x32_vs_reference_golden(unet):
+    """The reference UNet's own output at 32x32 latents (level 0: 1024 tokens = 4 query blocks x 2 x 16 key tiles per attn1
+    launch, level 3: 4x4), oracle/make_golden.py case A32."""
+    from motioneditor_amd import synth
+    unet.spatial_editor = unet.temporal_editor = None
+    g = np.load(GOLD / "unet_single_32.npz")
+    c = synth.make_case_inputs("single32", B=2, f=8, h=32, w=32)
+    out = unet(c["sample"].cuda(), c["t"], c["ehs"].cuda()).sample
+    e = rel_l2(out, torch.from_numpy(g["out"].astype(np.float32)))
+    record("unet_single_32", e)
+    assert e <= UNET_TOL, e
+
+
 @pytest.mark.parametrize("tag,step", [("inactive", 0), ("active", 4)])
 def test_unet_two_branch_editors_vs_reference_golden(unet, tag, step):
     from motioneditor_amd import synth
@@ -85,8 +98,8 @@ def test_unet_two_branch_editors_vs_reference_golden(unet, tag, step):
     assert (sed.cur_step, sed.cur_att_layer, ted.cur_step, ted.cur_att_layer) == (step + 1, 0, step + 1, 0)
     for i, s in enumerate(taps["skips"]):   # stage checksums localise a failure
         assert abs(float(s.float().abs().mean()) - g["skip_stats"][i, 1]) < 2e-2 * g["skip_stats"][i, 1], f"skip {i}"
-    for i, s in enumerate(taps["motion"]):
-        assert abs(float(s.float().abs().mean()) - g["motion_stats"][i, 1] * 0.5) < 2e-2 * g["motion_stats"][i, 1] or True
+    for i, s in enumerate(taps["motion"]):   # adapter outputs [(2 f N), C] (edit rows only); the golden statistics are over [0, m0, 0, m1]
+        assert abs(0.5 * float(s.float().abs().mean()) - g["motion_stats"][i, 1]) < 3e-2 * g["motion_stats"][i, 1], f"motion {i}"
     e = rel_l2(out, torch.from_numpy(g["out"]))
     record(f"unet_two_{tag}", e)
     assert e <= UNET_TOL, e
@@ -137,6 +150,106 @@ def test_denoise_step_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch
     record(f"step{step}_latents", e)
     assert e_np <= 2 * UNET_TOL, e_np   # CFG amplifies (cond - uncond) by 7.5
     assert e <= STEP_TOL, e
+
+
+def test_denoise_step_24_frames_16x16_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch):
+    """The benchmark's frame count at 16x16 latents: three adapter chunks of 8 frames, tattn_kernel<24> inside the graph,
+    level 3 = 2x2 pixels; one full two-branch step with both editors active vs the CPU oracle."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    from test_step_cpu import step_inputs
+    x = step_inputs(f=24, h=16, w=16)
+    f, step = 24, 4
+    ddim = ref_cpu.DDIM()
+    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+    sp.cur_step = tp.cur_step = step
+    t = ddim.timesteps[step]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 128, 128)
+    want = ref_cpu.denoise_step(unet_sd_torch, cn_sd_torch, ddim, x["latents"], t, x["uncond"], x["cond"], images, sp, tp, 7.5)
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    sed, ted = editors(unet, x["masks"])
+    sed.cur_step = ted.cur_step = step
+    pipe.scheduler.set_timesteps(50)
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images.cuda(), 7.5)
+    unet.spatial_editor = unet.temporal_editor = None
+    e = rel_l2(got, want)
+    record("step4_f24_16x16_latents", e)
+    assert e <= STEP_TOL, e
+
+
+def test_graph_replay_six_steps_equals_eager(unet, controlnet):
+    """denoise_step_graphed (one captured hipGraph per editor gating, device-resident step scalars) over steps 0..5 --
+    across the editors' start at step 4, with a different unconditional embedding and timestep every step -- must
+    reproduce the eager loop bit for bit (same kernels, same order, deterministic reductions)."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    x = step_inputs()
+    f = x["latents"].shape[2]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64).cuda()
+    g = torch.Generator().manual_seed(5)
+    uncs = [x["uncond"] + 0.05 * i * torch.randn(x["uncond"].shape, generator=g) for i in range(6)]
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    pipe.scheduler.set_timesteps(50)
+    outs = {}
+    for mode in ("eager", "graph"):
+        sed, ted = editors(unet, x["masks"])
+        lat = x["latents"].cuda()
+        for i in range(6):
+            emb = torch.cat([uncs[i].expand(2, 77, 768), x["cond"]]).cuda()
+            fn = pipe.denoise_step if mode == "eager" else pipe.denoise_step_graphed
+            lat = fn(lat, pipe.scheduler.timesteps[i], emb, images, 7.5)
+            assert sed.cur_step == ted.cur_step == i + 1 and sed.cur_att_layer == ted.cur_att_layer == 0
+        outs[mode] = lat.clone()
+    unet.spatial_editor = unet.temporal_editor = None
+    assert len(pipe._graphs) == 2                      # editors inactive / active
+    e = rel_l2(outs["graph"], outs["eager"])
+    record("graph_replay_vs_eager_six_steps", e)
+    assert e == 0.0, e
+
+
+def test_high_gain_weights_step_vs_cpu_oracle():
+    """A weight set that drives the activations to SD-like magnitudes (|x| ~ 1e2 - 1e3 after conv_in, large per-channel
+    means in front of the GroupNorms): GroupNorm variance (fp64 statistics) and the fp16 range of the residual stream,
+    one two-branch step vs the CPU oracle run on the same weights."""
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    from test_step_cpu import step_inputs
+    usd = dict(synth.synth_state_dict(synth.unet_schema()))
+    csd = dict(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."))
+    for sd in (usd, csd):
+        sd["conv_in.weight"] = sd["conv_in.weight"] * 60.0
+        sd["conv_in.bias"] = sd["conv_in.bias"] + 80.0 * np.sign(np.arange(sd["conv_in.bias"].shape[0]) % 3 - 0.5).astype(np.float32)
+        for k in list(sd):
+            if k.endswith(".conv_shortcut.bias") or k.endswith("proj_out.bias"):
+                sd[k] = sd[k] + 20.0
+    x = step_inputs()
+    f, step = x["latents"].shape[2], 4
+    ddim = ref_cpu.DDIM()
+    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+    sp.cur_step = tp.cur_step = step
+    t = ddim.timesteps[step]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64)
+    to = lambda d: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in d.items()}  # noqa: E731
+    otaps = {}
+    want = ref_cpu.denoise_step(to(usd), to(csd), ddim, x["latents"], t, x["uncond"], x["cond"], images, sp, tp, 7.5, taps=otaps)
+    u, c = UNet2DConditionModel(usd, device="cuda"), ControlNetModel(csd, device="cuda")
+    pipe = MotionEditorPipeline(unet=u, controlnet=c)
+    sed, ted = editors(u, x["masks"])
+    sed.cur_step = ted.cur_step = step
+    pipe.scheduler.set_timesteps(50)
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    taps = {}
+    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images.cuda(), 7.5, taps=taps)
+    amax = max(float(s.float().abs().max()) for s in taps["skips"])
+    record("high_gain_skip_absmax", amax)
+    assert amax > 100.0, amax                          # the case really is high-gain
+    e = rel_l2(got, want)
+    record("high_gain_step_latents", e)
+    assert torch.isfinite(got).all() and e <= STEP_TOL, e
 
 
 def test_six_consecutive_steps_cross_the_editor_start(unet, controlnet, unet_sd_torch, cn_sd_torch):
@@ -231,11 +344,10 @@ def test_properties_at_larger_size(unet):
 
     o1, _ = run(c["sample"], c["down_res"])
     o2, _ = run(c["sample"], c["down_res"])
-    # run-to-run: GroupNorm statistics are accumulated with float atomics, so the fp32 sums differ in the last
-    # bits between runs and fp16 roundings downstream flip -- the spread equals the fp16 noise floor (~1e-3)
+    # run-to-run: every reduction has a fixed order (GroupNorm statistics: per-chunk partials added in index order) -> bitwise equal
     noise = rel_l2(o1, o2)
     record("run_to_run", noise)
-    assert noise < 3e-3
+    assert noise == 0.0, noise
     s2 = c["sample"].clone()
     s2[1] += 0.5                                          # perturb the uncond EDIT row only
     o3, _ = run(s2, c["down_res"])
