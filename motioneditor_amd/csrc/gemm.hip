@@ -28,7 +28,10 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int STAGE_REG = 0, STAGE_GLDS = 1;
+#ifndef WIDE_TERMS
+#define WIDE_TERMS 0
+#endif
+constexpr int STAGE_REG = 0, STAGE_GLDS = 1, STAGE_BUF = 2;
 
 __device__ uint4 g_zero16;  // zero-initialised: source of every padded 16-byte chunk in the GLDS path
 
@@ -138,6 +141,70 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
       o[i][j].h[1] = __builtin_convertvector((f32x2){acc[j][i][2] * a.alpha, acc[j][i][3] * a.alpha}, f16x2);
     }
   }
+  // Wide path (sC == nullptr): pairs of n tiles (j, j+1) trade halves between lanes l and l ^ 16 with v_permlane16_swap, after
+  // which a lane holds 8 CONSECUTIVE output columns -- even quarter-rows g: tile j, columns 4g .. 4g+7; odd g: tile j+1, columns
+  // 4(g-1) .. 4(g-1)+7 -- so every term load and the store move 16 bytes per lane (64 contiguous bytes per output row and
+  // instruction instead of 32): the direct epilogue of the 256 x 320 tile is issue-bound on its 40 stores per lane.
+  const bool wide = (F == 0 || WIDE_TERMS) && sC == nullptr && a.N % 8 == 0 && a.ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0 &&
+                    (!has_rv || (a.ldrv % 8 == 0 && (reinterpret_cast<uintptr_t>(a.rowvec) & 15) == 0)) &&
+                    (!has_res || (a.ldr % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res) & 15) == 0)) &&
+                    (!has_res2 || (a.ldr2 % 8 == 0 && (reinterpret_cast<uintptr_t>(a.res2) & 15) == 0));
+  constexpr int NP = NT / 2;   // tile pairs; an odd last tile keeps the 8-byte path
+  const int gq = lane >> 4;
+  if (wide) {
+    union P8 { f16x2 h[4]; uint4 u; };
+    const int nw = n0 + wn * WN + ((gq & 1) ? 16 + 4 * (gq - 1) : 4 * gq);   // first of this lane's 8 columns inside pair 0; pair jp adds 32 jp
+    P8 w[MT][NP > 0 ? NP : 1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {
+        const auto rx = __builtin_amdgcn_permlane16_swap(o[i][2 * jp].u.x, o[i][2 * jp + 1].u.x, false, false);
+        const auto ry = __builtin_amdgcn_permlane16_swap(o[i][2 * jp].u.y, o[i][2 * jp + 1].u.y, false, false);
+        w[i][jp].u = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+      }
+    auto add_wide = [&](const f16* src, auto rowoff) {
+      P8 t[MT][NP > 0 ? NP : 1];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const f16* p = src + rowoff(mrow[i] < 0 ? 0 : mrow[i]) + nw;
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) t[i][jp].u = nw + 32 * jp + 7 < a.N ? *reinterpret_cast<const uint4*>(p + 32 * jp) : make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[i][jp].h[q] += t[i][jp].h[q];
+    };
+    auto add_narrow_last = [&](const f16* src, auto rowoff) {   // the unpaired last tile (NT odd)
+      if constexpr (NT % 2 == 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          P4 t;
+          t.u = nb + 16 * (NT - 1) < a.N ? *reinterpret_cast<const uint2*>(src + rowoff(mrow[i] < 0 ? 0 : mrow[i]) + nb + 16 * (NT - 1)) : make_uint2(0u, 0u);
+          o[i][NT - 1].h[0] += t.h[0];
+          o[i][NT - 1].h[1] += t.h[1];
+        }
+      }
+    };
+    if constexpr (has_rv) { add_wide(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); add_narrow_last(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); }
+    if constexpr (has_res) { add_wide(res, [&](int m) { return (long)m * a.ldr; }); add_narrow_last(res, [&](int m) { return (long)m * a.ldr; }); }
+    if constexpr (has_res2) { add_wide(res2, [&](int m) { return (long)m * a.ldr2; }); add_narrow_last(res2, [&](int m) { return (long)m * a.ldr2; }); }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if (mrow[i] < 0) continue;
+      f16* crow = C + (long)mrow[i] * a.ldc;
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp)
+        if (nw + 32 * jp + 7 < a.N) *reinterpret_cast<uint4*>(crow + nw + 32 * jp) = w[i][jp].u;
+      if constexpr (NT % 2 == 1) {
+        if (nb + 16 * (NT - 1) < a.N) *reinterpret_cast<uint2*>(crow + nb + 16 * (NT - 1)) = o[i][NT - 1].u;
+      }
+    }
+    return;
+  }
   // o += src[row(i) * ld + column]: all 40 loads, then 80 packed adds
   auto add_term = [&](const f16* src, auto rowoff) {
     P4 t[MT][NT];
@@ -230,25 +297,52 @@ __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
   f16* C = reinterpret_cast<f16*>(a.C);
+  constexpr int NO = NT / 2;                     // 16-column output tiles per wave
   const int nb = n0 + wn * WN + (lane >> 4) * 4;
   const int nob = (n0 + wn * WN) / 2 + (lane >> 4) * 4;
+  const int Nout = a.N / 2;
+  union P4 { f16x2 h[2]; uint2 u; };
+  P4 o[MT][NO];
+  int mrow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = rowfn(i);
+    mrow[i] = rowfn(i);
+#pragma unroll
+    for (int jj = 0; jj < NO; ++jj) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * a.alpha * gelu_erf_fast(acc[2 * jj + 1][i][r] * a.alpha);
+      o[i][jj].h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
+      o[i][jj].h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+    }
+  }
+  // wide path as in epilogue_rows: pairs of output tiles trade halves across lanes l ^ 16 -> 16-byte stores
+  const bool wide = sC == nullptr && Nout % 8 == 0 && a.ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(a.C) & 15) == 0;
+  constexpr int NP = NO / 2;
+  const int gq = lane >> 4;
+  const int nw = (n0 + wn * WN) / 2 + ((gq & 1) ? 16 + 4 * (gq - 1) : 4 * gq);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mrow[i];
+    if (wide) {
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) {   // the swaps run in every lane (uniform control flow), only the stores are predicated
+        const auto rx = __builtin_amdgcn_permlane16_swap(o[i][2 * jp].u.x, o[i][2 * jp + 1].u.x, false, false);
+        const auto ry = __builtin_amdgcn_permlane16_swap(o[i][2 * jp].u.y, o[i][2 * jp + 1].u.y, false, false);
+        if (m >= 0 && nw + 32 * jp + 7 < Nout) *reinterpret_cast<uint4*>(C + (long)m * a.ldc + nw + 32 * jp) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+      }
+      if constexpr (NO % 2 == 1) {
+        if (m >= 0 && nob + 16 * (NO - 1) < Nout) *reinterpret_cast<uint2*>(C + (long)m * a.ldc + nob + 16 * (NO - 1)) = o[i][NO - 1].u;
+      }
+      continue;
+    }
     if (m < 0) continue;
 #pragma unroll
-    for (int jj = 0; jj < NT / 2; ++jj) {
+    for (int jj = 0; jj < NO; ++jj) {
       if (nb + 32 * jj >= a.N) continue;
       const int no = nob + 16 * jj;  // output column
-      U64 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float va = acc[2 * jj][i][r] * a.alpha;
-        const float vg = acc[2 * jj + 1][i][r] * a.alpha;
-        o.e[r] = (f16)(va * gelu_erf_fast(vg));
-      }
-      if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o.u;
-      else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o.u;
+      if (sC) *reinterpret_cast<uint2*>(sC + (m - m0) * CLD + (no - n0 / 2)) = o[i][jj].u;
+      else *reinterpret_cast<uint2*>(C + (long)m * a.ldc + no) = o[i][jj].u;
     }
   }
 }
@@ -278,7 +372,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   constexpr int MT = WM / 16;     // 16-wide m tiles per wave
   constexpr int XROWS = BM / RSTR;  // X rows staged per thread
   constexpr int WROWS = BN / RSTR;  // W rows staged per thread
-  constexpr int LD = STAGE == STAGE_GLDS ? BK : BK + 8;  // LDS row stride in halves
+  constexpr int LD = STAGE != STAGE_REG ? BK : BK + 8;  // LDS row stride in halves
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* sX = reinterpret_cast<f16*>(smem);  // [2][BM][LD]
@@ -304,7 +398,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   // into ONE K axis of 9 K -- the weights [N][9][K] are contiguous in exactly that order -- instead of nine 64-wide
   // slabs that are 75 % / 50 % zero padding: 3 / 5 slabs instead of 9.  A lane's 16-byte chunk then belongs to
   // the tap (slab * 64 + chunk offset) / K, different lanes gather different taps of their rows.
-  const bool packk = STAGE == STAGE_GLDS && a.gather == ME_GATHER_CONV3 && a.K < BK && BK % a.K == 0;
+  const bool packk = STAGE == STAGE_GLDS && a.gather == ME_GATHER_CONV3 && a.K < BK && BK % a.K == 0;   // (STAGE_BUF is only launched with K % 64 == 0)
   const int nit = packk ? (9 * a.K + BK - 1) / BK : taps * nkc;
 
   // staging assignment
@@ -312,7 +406,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   //   GLDS: wave instruction q = wave + 4*i covers rows 8q..8q+7; lane -> row 8q + lane/8, LDS chunk slot lane%8,
   //         which holds source chunk (lane%8) ^ swz, swz = (row >> 1) & 7 = (4*(wave&1) + (lane>>4)) & 7 for every i
   int srow, scol;
-  if (STAGE == STAGE_GLDS) {
+  if (STAGE != STAGE_REG) {
     srow = wave * 8 + (lane >> 3);
     scol = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
   } else {
@@ -352,13 +446,13 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int row = wm * WM + i * 16 + frow;
-        const int ch = STAGE == STAGE_GLDS ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
+        const int ch = STAGE != STAGE_REG ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
         fx[i] = *reinterpret_cast<const f16x8*>(bx + row * LD + ch * 8);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int row = wn * WN + j * 16 + frow;
-        const int ch = STAGE == STAGE_GLDS ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
+        const int ch = STAGE != STAGE_REG ? ((ks * 4 + fg) ^ ((row >> 1) & 7)) : (ks * 4 + fg);
         fw[j] = *reinterpret_cast<const f16x8*>(bw + row * LD + ch * 8);
       }
 #pragma unroll
@@ -368,7 +462,55 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
     }
   };
 
-  if constexpr (STAGE == STAGE_GLDS) {
+  if constexpr (STAGE == STAGE_BUF) {
+    // Staging through buffer_load_dwordx4 ... lds (K % 64 == 0): the operands are addressed as "buffer resource + per-lane
+    // 32-bit byte offset + scalar slab offset".  The lane offsets change only with the tap, the slab advance is ONE scalar add,
+    // and padding taps / tail rows are offsets past the resource's range, which the hardware turns into zeros in LDS -- the
+    // global_load_lds path above spends ~250 VALU instructions per 64-wide slab (64-bit per-lane pointers, selects against a zero
+    // buffer, an integer division) next to its 80 MFMAs, and on this chip VALU time adds to MFMA time.
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr unsigned OOB = 0x80000000u;
+    // X window: rows are addressed relative to the block's lowest source row, so the 32-bit offsets stay below 2 GB on any tensor
+    long brow = m0;
+    if (a.gather == ME_GATHER_CONV3) brow = (long)(m0 / (a.Hout * a.Wout)) * a.Hin * a.Win;
+    else if (a.gather == ME_GATHER_TCONV) brow = m0 > a.npix ? m0 - a.npix : 0;
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(X + brow * a.ldx), 0, OOB, 0x00020000);
+    const int wrows = min(a.N - n0, BN);
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W + (long)n0 * taps * a.K), 0, (unsigned)((long)wrows * taps * a.K * 2), 0x00020000);
+    unsigned xo[XROWS], wo[WROWS];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) wo[i] = (unsigned)(((long)(srow + RSTR * i) * taps * a.K + scol) * 2);
+    auto set_tap_off = [&](int tap) {
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) {
+        const int sr = src_row(a, rinfo[i], tap);
+        xo[i] = sr < 0 ? OOB : (unsigned)(((long)(sr - brow) * a.ldx + scol) * 2);
+      }
+    };
+    int tap_l = 0, kc_l = 0;   // load cursor
+    set_tap_off(0);
+    auto gload = [&](int buf) {
+      char* dx = reinterpret_cast<char*>(sX + buf * BM * LD) + wave * 1024;
+      char* dw = reinterpret_cast<char*>(sW + buf * BN * LD) + wave * 1024;
+      const int sx = kc_l * (BK * 2), sw = (tap_l * a.K + kc_l * BK) * 2;
+#pragma unroll
+      for (int i = 0; i < XROWS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(dx + i * (RSTR * 128)), 16, (int)xo[i], sx, 0, 0);
+#pragma unroll
+      for (int i = 0; i < WROWS; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(dw + i * (RSTR * 128)), 16, (int)wo[i], sw, 0, 0);
+      if (++kc_l == nkc) {
+        kc_l = 0;
+        if (++tap_l < taps) set_tap_off(tap_l);
+      }
+    };
+    gload(0);
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const int buf = it & 1;
+      if (it + 1 < nit) gload(buf ^ 1);
+      compute(buf);
+      __syncthreads();  // LDS-DMA pending -> the compiler drains vmcnt(0) here: next slab landed, this slab free
+    }
+  } else if constexpr (STAGE == STAGE_GLDS) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const f16* zsrc = reinterpret_cast<const f16*>(&g_zero16);
@@ -483,8 +625,6 @@ constexpr int HALO_BYTES = HALO_INSTR * 1024, CONVW_BYTES = 320 * 128;
 
 __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a) {
   constexpr int BN = 320, WN = 160, NT = 10, MT = 4;
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sH = smem;                 // [HALO_INSTR * 8 halo pixels][64 ch], single buffer
   char* sWt = smem + HALO_BYTES;   // [2][320][64 ch]
@@ -505,40 +645,43 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a
 
   const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
   const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
-  const f16* zsrc = reinterpret_cast<const f16*>(&g_zero16);
 
   // DMA lane mapping as in gemm_kernel: instruction q = wave + 8*i covers LDS rows 8q..8q+7
   const int srow = wave * 8 + (lane >> 3);
   const int scol = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
-  int hsrc[6];  // source row of halo pixel srow + 64*i, -1 = zero padding
+  // buffer-resource addressing as in gemm_kernel<STAGE_BUF>: per-lane byte offsets relative to the image, scalar slab / tap
+  // offsets, zero padding = offsets past the resource range
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr unsigned OOB = 0x80000000u;
+  const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(X + (long)img * hw * a.ldx), 0, OOB, 0x00020000);
+  const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W + (long)n0 * 9 * a.K), 0, (unsigned)((long)BN * 9 * a.K * 2), 0x00020000);
+  unsigned hoff[6];  // byte offset of halo pixel srow + 64*i inside the image, OOB = zero padding
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     const int hr = srow + 64 * i;
-    int s = -1;
+    unsigned o = OOB;
     if (hr < HALO_ROWS) {
       const int hy = hr / HALO_W, hx = hr - hy * HALO_W;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) s = img * hw + iy * a.Win + ix;
+      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) o = (unsigned)(((long)(iy * a.Win + ix) * a.ldx + scol) * 2);
     }
-    hsrc[i] = s;
+    hoff[i] = o;
   }
   auto load_halo = [&](int kc) {
-    const int c = kc * BK + scol;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-      if (wave + 8 * i < HALO_INSTR) {
-        const f16* src = hsrc[i] >= 0 ? X + (long)hsrc[i] * a.ldx + c : zsrc;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sH + (wave + 8 * i) * 1024), 16, 0, 0);
-      }
+      if (wave + 8 * i < HALO_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(sH + (wave + 8 * i) * 1024), 16, (int)hoff[i], kc * (BK * 2), 0, 0);
     }
   };
-  const f16* wbase = W + ((long)(n0 + srow) * 9) * a.K + scol;
-  auto load_w = [&](int tap, int kc, int buf) {
-    const f16* src = wbase + (long)tap * a.K + kc * BK;
-    char* dw = sWt + buf * CONVW_BYTES + wave * 1024;
+  unsigned woff[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + (long)i * 64 * 9 * a.K), (lptr_t)(dw + i * 8192), 16, 0, 0);
+  for (int i = 0; i < 5; ++i) woff[i] = (unsigned)(((long)(srow + 64 * i) * 9 * a.K + scol) * 2);
+  auto load_w = [&](int tap, int kc, int buf) {
+    char* dw = sWt + buf * CONVW_BYTES + wave * 1024;
+    const int so = (tap * a.K + kc * BK) * 2;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(dw + i * 8192), 16, (int)woff[i], so, 0, 0);
   };
 
   f32x4 acc[NT][MT];
@@ -629,6 +772,15 @@ bool conv_halo() {   // ME_CONV_HALO=0 sends 3x3 convolutions back to the gather
   return on == 1;
 }
 
+bool buf_stage() {   // ME_GEMM_BUF=0: keep the global_load_lds staging for every shape (A/B)
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ME_GEMM_BUF");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on == 1;
+}
+
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -645,7 +797,7 @@ extern "C" void me_set_kernel(const char* name);
 
 template <int BM, int BN, int STAGE, int WM = 64>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * (STAGE == STAGE_GLDS ? BK : BK + 8) * sizeof(f16);
+  const size_t lds = (size_t)2 * (BM + BN) * (STAGE != STAGE_REG ? BK : BK + 8) * sizeof(f16);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, STAGE, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -659,7 +811,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn), dim3(BM / WM * 128), lds, st, *a);
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>", BM, BN, STAGE == STAGE_GLDS ? "" : ",reg");
+    snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>", BM, BN, STAGE == STAGE_REG ? ",reg" : "");
     me_set_kernel(nm);
   }
   if (hipGetLastError() != hipSuccess) {
@@ -721,14 +873,16 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
     if (a->gather == ME_GATHER_CONV3 && a->stride == 1 && a->ups == 0 && a->N % 320 == 0 && a->K % 64 == 0 && a->Hin % 16 == 0 &&
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);
+    const bool buf = a->K % 64 == 0 && buf_stage();   // scalar-offset buffer staging (no K tail, no packed-tap mode)
     if (a->N % 320 == 0 && big_blocks >= big_min_blocks())
-      return launch_gemm<256, 320, STAGE_GLDS>(a, st);
+      return buf ? launch_gemm<256, 320, STAGE_BUF>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
     const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);
-    if (a->N % 128 == 0 && blocks160 < 512) return launch_gemm<128, 128, STAGE_GLDS>(a, st);
-    if (!a->geglu && a->N % 160 == 0 && tile160()) return launch_gemm<128, 160, STAGE_GLDS>(a, st);
-    return wide ? launch_gemm<128, 128, STAGE_GLDS>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
+    if (a->N % 128 == 0 && blocks160 < 512) return buf ? launch_gemm<128, 128, STAGE_BUF>(a, st) : launch_gemm<128, 128, STAGE_GLDS>(a, st);
+    if (!a->geglu && a->N % 160 == 0 && tile160()) return buf ? launch_gemm<128, 160, STAGE_BUF>(a, st) : launch_gemm<128, 160, STAGE_GLDS>(a, st);
+    if (wide) return buf ? launch_gemm<128, 128, STAGE_BUF>(a, st) : launch_gemm<128, 128, STAGE_GLDS>(a, st);
+    return launch_gemm<128, 64, STAGE_GLDS>(a, st);
   }
   return wide ? launch_gemm<128, 128, STAGE_REG>(a, st) : launch_gemm<128, 64, STAGE_REG>(a, st);
 }

@@ -80,26 +80,39 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
   }
 }
 
-// stats[sg][g] = (sum, sum of squares) in fp64 from the chunks' shifted partial sums, merged in chunk order:
-// chunk mean = K + S1 / n, chunk M2 = S2 - S1^2 / n, then Chan's pairwise update of (n, mean, M2)
-__global__ void gn_finalize_kernel(const float4* __restrict__ part, double* __restrict__ stats, int chunks, int chunk_rows, int rows_per_group,
-                                   int nsg, int groups, int cg) {
-  const int sg = blockIdx.x, g = threadIdx.x;
-  if (g >= groups) return;
-  double n = 0.0, mean = 0.0, M2 = 0.0;
-  for (int c = 0; c < chunks; ++c) {
-    const float4 p = part[((long)c * nsg + sg) * groups + g];
-    const int rows_c = min((c + 1) * chunk_rows, rows_per_group) - c * chunk_rows;
-    const double nb = (double)rows_c * (double)cg;
-    const double mb = (double)p.z + (double)p.x / nb;
-    const double M2b = fmax((double)p.y - (double)p.x * (double)p.x / nb, 0.0);
-    const double delta = mb - mean, nt = n + nb;
-    mean += delta * (nb / nt);
-    M2 += M2b + delta * delta * (n * nb / nt);
-    n = nt;
+// stats[sg][g] = (sum, sum of squares) in fp64 from the chunks' shifted partial sums: chunk mean = K + S1 / n, chunk
+// M2 = S2 - S1^2 / n, merged with Chan's update of (n, mean, M2) in a FIXED tree: slice s of the block merges chunks
+// s, s + S, s + 2S, ... in order, then slice 0 merges the S slice results in order (bitwise reproducible).
+struct Moments { double n, mean, M2; };
+__device__ __forceinline__ void merge(Moments& a, double nb, double mb, double M2b) {
+  const double delta = mb - a.mean, nt = a.n + nb;
+  a.mean += delta * (nb / nt);
+  a.M2 += M2b + delta * delta * (a.n * nb / nt);
+  a.n = nt;
+}
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float4* __restrict__ part, double* __restrict__ stats, int chunks, int chunk_rows,
+                                                          int rows_per_group, int nsg, int groups, int cg) {
+  __shared__ Moments sm[256];
+  const int sg = blockIdx.x, g = threadIdx.x % groups, slice = threadIdx.x / groups, S = 256 / groups;
+  Moments m{0.0, 0.0, 0.0};
+  if (slice < S) {
+    for (int c = slice; c < chunks; c += S) {
+      const float4 p = part[((long)c * nsg + sg) * groups + g];
+      const int rows_c = min((c + 1) * chunk_rows, rows_per_group) - c * chunk_rows;
+      const double nb = (double)rows_c * (double)cg;
+      merge(m, nb, (double)p.z + (double)p.x / nb, fmax((double)p.y - (double)p.x * (double)p.x / nb, 0.0));
+    }
   }
-  stats[((long)sg * groups + g) * 2 + 0] = n * mean;
-  stats[((long)sg * groups + g) * 2 + 1] = M2 + n * mean * mean;
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  if (slice == 0) {
+    for (int s2 = 1; s2 < S; ++s2) {
+      const Moments o = sm[s2 * groups + g];
+      if (o.n > 0.0) merge(m, o.n, o.mean, o.M2);
+    }
+    stats[((long)sg * groups + g) * 2 + 0] = m.n * m.mean;
+    stats[((long)sg * groups + g) * 2 + 1] = m.M2 + m.n * m.mean * m.mean;
+  }
 }
 
 // y = x * A[c] + B[c] (+ SiLU) with A = rstd * gamma, B = beta - mean * rstd * gamma.  A thread owns ONE 16-byte
@@ -305,7 +318,7 @@ extern "C" int me_groupnorm_stats(const me_groupnorm_args* a, void* stream) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), lds, st, reinterpret_cast<const f16*>(a->X), part, a->rows_per_group,
                      chunk_rows, a->C, a->ldx, a->groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(64), 0, st, part, stats, chunks, chunk_rows, a->rows_per_group, nsg, a->groups, a->C / a->groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(256), 0, st, part, stats, chunks, chunk_rows, a->rows_per_group, nsg, a->groups, a->C / a->groups);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_stats: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }
