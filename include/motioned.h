@@ -64,6 +64,8 @@ typedef struct me_gemm_args {
   int32_t gather;     /* ME_GATHER_*                                           */
   /* CONV3: M = n_img * Hout * Wout */
   int32_t Hin, Win, Hout, Wout, stride, ups;
+  int32_t pad0;       /* CONV3: 0 = padding 1 on every side; 1 = no padding at the top / left, one row / column at the bottom /
+                         right (diffusers Downsample2D(padding=0) of the VAE encoder: F.pad(x, (0,1,0,1)) + stride-2 conv) */
   /* TCONV: row m = ((b * frames + fr) * npix + p).  Frame-sharded operation: this rank holds
    * `frames` consecutive frames starting at global frame `frame0` of `frames_total`; taps that leave the local
    * range read the one-frame halos the host appended to X at rows halo_prev / halo_next (+ b*npix + p).
@@ -236,6 +238,10 @@ int me_cfg_ddim(float* lat_out, const float* lat_in, const void* eps, int32_t ld
 int me_timestep_embed_dev(void* out, int32_t rows, int32_t dim, const float* step_params, void* stream);
 int me_cfg_ddim_dev(float* lat_out, const float* lat_in, const void* eps, int32_t lde, int32_t nb, int32_t C,
                     int32_t frames, int32_t npix, const float* step_params, void* stream);
+/* DiagonalGaussianDistribution.sample of the VAE encoder (inference.py:262: vae.encode(x).latent_dist.sample() * 0.18215):
+ * moments fp16 channels-last rows (img*npix + p) x [mean 0..3 | logvar 4..7]; noise, out fp32 [n_img, 4, npix];
+ * out = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale */
+int me_gaussian_sample(float* out, const void* moments, int32_t ldm, const float* noise, int32_t n_img, int32_t npix, float scale, void* stream);
 /* fp32 [n_img, C, H*W] (img/channel strides in elements) -> fp16 channels-last [n_img*H*W, ldy] */
 int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride,
                     int32_t n_img, int32_t C, int32_t npix, void* stream);

@@ -24,7 +24,7 @@ class GemmArgs(C.Structure):
         ("X", _vp), ("W", _vp), ("C", _vp),
         ("M", _i32), ("N", _i32), ("K", _i32),
         ("ldx", _i32), ("ldc", _i32), ("gather", _i32),
-        ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
+        ("Hin", _i32), ("Win", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32), ("pad0", _i32),
         ("frames", _i32), ("npix", _i32), ("chunk", _i32),
         ("frame0", _i32), ("frames_total", _i32), ("halo_prev", _i32), ("halo_next", _i32),
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
@@ -102,6 +102,7 @@ SYMBOLS = {
     "me_cfg_ddim": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp]),
     "me_timestep_embed_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "me_cfg_ddim_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "me_gaussian_sample": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
     "me_nchw_to_rows": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "me_rows_to_nchw": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
 }
@@ -135,7 +136,15 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_SYNC = bool(__import__("os").environ.get("ME_SYNC"))   # debugging aid: synchronise after every call so that a device fault names its launch
+
+
 def check(rc: int, what: str = "") -> None:
+    if _SYNC and rc == ME_OK:
+        import sys
+        import torch
+        print(f"[ME_SYNC] {what} {lib().me_last_kernel().decode()}", file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
     if rc != ME_OK:
         msg = lib().me_last_error().decode(errors="replace")
         if rc == ME_EINVAL:

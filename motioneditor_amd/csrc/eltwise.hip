@@ -140,6 +140,17 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(float* lat_out, const flo
   lat_out[idx] = ca * lat_in[idx] + cb * e;
 }
 
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(float* out, const f16* __restrict__ mom, int ldm, const float* __restrict__ noise, int n_img, int npix, float scale) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;     // (img, c, p)
+  if (idx >= (long)n_img * 4 * npix) return;
+  const int p = (int)(idx % npix);
+  const int c = (int)((idx / npix) % 4);
+  const long row = (idx / (4L * npix)) * npix + p;
+  const float mean = (float)mom[row * ldm + c];
+  const float logvar = fminf(fmaxf((float)mom[row * ldm + 4 + c], -30.f), 20.f);
+  out[idx] = (mean + __expf(0.5f * logvar) * noise[idx]) * scale;
+}
+
 __global__ __launch_bounds__(256) void nchw_to_rows_kernel(f16* Y, int ldy, const float* X, long img_stride, long ch_stride, int n_img, int C, int npix) {
   const long total = (long)n_img * npix * C;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -264,6 +275,15 @@ extern "C" int me_cfg_ddim_dev(float* lat_out, const float* lat_in, const void* 
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), lat_out, lat_in,
                      reinterpret_cast<const f16*>(eps), lde, nb, C, frames, npix, 0.f, 0.f, 0.f, step_params);
   ME_CHECK_LAUNCH("me_cfg_ddim_dev")
+}
+
+extern "C" int me_gaussian_sample(float* out, const void* moments, int32_t ldm, const float* noise, int32_t n_img, int32_t npix, float scale, void* stream) {
+  if (!out || !moments || !noise || n_img <= 0 || npix <= 0 || ldm < 8) { me_set_error("me_gaussian_sample: bad arguments"); return ME_EINVAL; }
+  const long total = (long)n_img * 4 * npix;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out,
+                     reinterpret_cast<const f16*>(moments), ldm, noise, n_img, npix, scale);
+  ME_CHECK_LAUNCH("me_gaussian_sample")
 }
 
 extern "C" int me_nchw_to_rows(void* Y, int32_t ldy, const float* X, int64_t img_stride, int64_t ch_stride, int32_t n_img, int32_t C, int32_t npix,

@@ -57,8 +57,8 @@ __device__ __forceinline__ RowInfo make_row(const me_gemm_args& a, int m) {
     const int oy = rem / a.Wout;
     const int ox = rem - oy * a.Wout;
     r.base = img * a.Hin * a.Win;
-    r.y0 = oy * a.stride - 1;
-    r.x0 = ox * a.stride - 1;
+    r.y0 = oy * a.stride - (a.pad0 ? 0 : 1);
+    r.x0 = ox * a.stride - (a.pad0 ? 0 : 1);
   } else if (a.gather == ME_GATHER_TCONV) {
     const int bf = m / a.npix;
     r.y0 = bf % a.frames;                                  // local frame
@@ -798,7 +798,10 @@ extern "C" void me_set_kernel(const char* name);
 template <int BM, int BN, int STAGE, int WM = 64>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * (STAGE != STAGE_REG ? BK : BK + 8) * sizeof(f16);
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};   // the attribute is per device: a process that drives several GPUs sets it on each
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, STAGE, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -823,7 +826,10 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
 
 static int launch_conv_halo(const me_gemm_args* a, hipStream_t st) {
   const int lds = HALO_BYTES + 2 * CONVW_BYTES;
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};   // the attribute is per device: a process that drives several GPUs sets it on each
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -850,7 +856,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->gather < 0 || a->gather > 2) { me_set_error("me_gemm: bad gather mode"); return ME_EINVAL; }
   if (a->gather == ME_GATHER_CONV3) {
     if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0 || (a->stride != 1 && a->stride != 2) || (a->ups != 0 && a->ups != 1) ||
-        a->M % (a->Hout * a->Wout)) { me_set_error("me_gemm: bad conv geometry"); return ME_EINVAL; }
+        (a->pad0 != 0 && a->pad0 != 1) || a->M % (a->Hout * a->Wout)) { me_set_error("me_gemm: bad conv geometry"); return ME_EINVAL; }
   }
   if (a->gather == ME_GATHER_TCONV) {
     const int ftot = a->frames_total > 0 ? a->frames_total : a->frames;
@@ -870,7 +876,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (stage_impl() == STAGE_GLDS) {
     // big tile when the grid still fills the chip: every model width is a multiple of 320
     const long big_blocks = (long)((a->M + 255) / 256) * (a->N / 320);
-    if (a->gather == ME_GATHER_CONV3 && a->stride == 1 && a->ups == 0 && a->N % 320 == 0 && a->K % 64 == 0 && a->Hin % 16 == 0 &&
+    if (a->gather == ME_GATHER_CONV3 && a->stride == 1 && a->ups == 0 && !a->pad0 && a->N % 320 == 0 && a->K % 64 == 0 && a->Hin % 16 == 0 &&
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);
     const bool buf = a->K % 64 == 0 && buf_stage();   // scalar-offset buffer staging (no K tail, no packed-tap mode)

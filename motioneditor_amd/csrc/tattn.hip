@@ -117,7 +117,10 @@ int launch_tattn(const me_tattn_args* a, hipStream_t st) {
   const int threads = ((hps * (a->q_frames > 0 ? a->q_frames : F) + 63) / 64) * 64;
   const long blocks = (long)a->batch * a->npix * nslice;
   const size_t lds = (size_t)2 * F * SLD * sizeof(f16);
-  static bool attr_set = false;
+  static bool attr_set_dev[64] = {};   // per device: a process that drives several GPUs sets the attribute on each
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set && lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ME_EHIP;
     attr_set = true;

@@ -41,7 +41,7 @@ class ControlNetModel:
         n, _, h, w = sample.shape
         lat = sample.to(self.device).float().reshape(n, 4, 1, h, w)
         down, mid = self.forward_rows(lat, list(range(n)), timestep, encoder_hidden_states, controlnet_cond, conditioning_scale)
-        sizes = [(h, w)] * 4 + [(h // 2, w // 2)] * 3 + [(h // 4, w // 4)] * 3 + [(h // 8, w // 8)] * 2
+        sizes = [(h, w)] * 3 + [(h // 2, w // 2)] * 3 + [(h // 4, w // 4)] * 3 + [(h // 8, w // 8)] * 3   # conv_in, 2 resnets, then each downsampler + 2 resnets
         outs = [ops.rows_to_nchw(d, n, d.shape[1], hh * ww).reshape(n, d.shape[1], hh, ww) for d, (hh, ww) in zip(down, sizes)]
         m = ops.rows_to_nchw(mid, n, 1280, (h // 8) * (w // 8)).reshape(n, 1280, h // 8, w // 8)
         return outs, m

@@ -70,8 +70,12 @@ class UNet2DConditionModel:
     def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None,
                      normal_infer: bool = False, res_ready=None, side_stream=None) -> graph.Act:
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
+        # normal_infer = the plain SD forward of the inversion (attention_2d.py:770-777 bypasses the patched closures' edits):
+        # registered editors neither act nor count there, so a later denoising run starts from un-advanced counters
+        spatial = None if normal_infer else self.spatial_editor
+        temporal = None if normal_infer else self.temporal_editor
         return graph.unet_forward(self.P, sample.to(self.device), t, encoder_hidden_states.to(self.device), down_res=down_rows, mid_res=mid_rows,
-                                  two_branch=two_branch, spatial=self.spatial_editor, temporal=self.temporal_editor, taps=taps, shard=shard,
+                                  two_branch=two_branch, spatial=spatial, temporal=temporal, taps=taps, shard=shard,
                                   normal_infer=normal_infer, res_ready=res_ready, side_stream=side_stream)
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None, return_dict: bool = True,
@@ -80,8 +84,8 @@ class UNet2DConditionModel:
         if class_labels is not None or attention_mask is not None or skeleton is not None:
             raise NotImplementedError("class_labels / attention_mask / skeleton are not on the inference hot path "
                                       "(pipeline_motion_editor.py:632-640 passes none of them)")
-        if normal_infer and (self.spatial_editor is not None or down_block_additional_residuals is not None):
-            raise NotImplementedError("normal_infer is the DDIM-inversion forward (util.py:89-96): single branch, no editors, no ControlNet")
+        if normal_infer and down_block_additional_residuals is not None:
+            raise NotImplementedError("normal_infer is the DDIM-inversion forward (util.py:89-96): single branch, no ControlNet residuals")
         down = mid = None
         two = False
         if down_block_additional_residuals is not None:

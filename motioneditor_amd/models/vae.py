@@ -1,5 +1,6 @@
-"""AutoencoderKL decoder on libmotioned: the step behind the denoising loop,
-`pipeline_motion_editor.py:346-355` -> `vae.decode(latents).sample` per frame.
+"""AutoencoderKL on libmotioned: the steps either side of the denoising loop --
+`inference.py:262-265` `vae.encode(pixels).latent_dist.sample() * 0.18215` in front of the inversion, and
+`pipeline_motion_editor.py:346-355` -> `vae.decode(latents).sample` per frame behind the loop.
 
 The reference takes the class from diffusers 0.15.1 (`AutoencoderKL`; not in the reference tree -> parity unpinned, the
 oracle `oracle/ref_cpu.py::vae_decode` restates the published decoder).  Same constructor contract as the other
@@ -102,9 +103,62 @@ def decode(P: Packed, z: torch.Tensor) -> torch.Tensor:
     return ops.rows_to_nchw(out, n, 3, x.N).reshape(n, 3, x.h, x.w)
 
 
+def encode_moments(P: Packed, x: torch.Tensor) -> Act:
+    """x fp32 [n, 3, H, W] in [-1, 1] -> distribution parameters as fp16 rows [(n h w), 8] = (mean | logvar), h = H/8.
+    diffusers Encoder: conv_in, four DownEncoderBlock2D (two resnets, Downsample2D(padding=0) = pad (0,1,0,1) + stride-2 conv on
+    the first three), mid block (resnet, one-head attention, resnet), GroupNorm + SiLU, conv_out, then quant_conv (1x1)."""
+    n, c, H, W = x.shape
+    if c != 3 or H % 8 or W % 8:
+        raise ValueError(f"expected [n, 3, H, W] with H, W multiples of 8, got {tuple(x.shape)}")
+    x = x.to(P.device, torch.float32).contiguous()
+    a = Act(ops.conv_small(x, P.mat32("encoder.conv_in.weight"), P.vec32("encoder.conv_in.bias"), n_img=n, Cin=3, H=H, Wd=W,
+                           img_stride=3 * H * W, ch_stride=H * W), n, 1, H, W)
+    for i in range(4):
+        for j in range(2):
+            a = resnet(P, f"encoder.down_blocks.{i}.resnets.{j}", a)
+        if i < 3:
+            name = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            ho, wo = a.h // 2, a.w // 2
+            out = ops.gemm(a.t, P.mat(name + ".weight"), M=n * ho * wo, bias=P.vec(name + ".bias"), conv=(a.h, a.w, ho, wo, 2, 0, 1))
+            a = a.like(out, ho, wo)
+    a = resnet(P, "encoder.mid_block.resnets.0", a)
+    a = attention(P, "encoder.mid_block.attentions.0", a)
+    a = resnet(P, "encoder.mid_block.resnets.1", a)
+    y = _gn(P, "encoder.conv_norm_out", a, True)
+    m = conv3x3(P, "encoder.conv_out", a.like(y))
+    return a.like(ops.gemm(m.t, P.mat("quant_conv.weight"), bias=P.vec("quant_conv.bias")))
+
+
+class DiagonalGaussianDistribution:
+    """What `AutoencoderKL.encode(x).latent_dist` returns: sample() = mean + std * noise (diffusers' class draws the noise with
+    torch.randn; pass `generator` for a reproducible draw, or `noise` to supply it), mode() = mean."""
+
+    def __init__(self, moments: Act):
+        self._m = moments
+
+    def _shape(self):
+        return (self._m.B, 4, self._m.h, self._m.w)
+
+    def sample(self, generator=None, noise: torch.Tensor = None, scale: float = 1.0) -> torch.Tensor:
+        m = self._m
+        if noise is None:
+            dev = generator.device if generator is not None else m.t.device
+            noise = torch.randn(self._shape(), generator=generator, device=dev, dtype=torch.float32)
+        noise = noise.to(m.t.device, torch.float32).contiguous()
+        return ops.gaussian_sample(m.t, noise, m.B, m.N, scale).reshape(self._shape())
+
+    def mode(self) -> torch.Tensor:
+        return ops.rows_to_nchw(self._m.t, self._m.B, 4, self._m.N).reshape(self._shape())
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: DiagonalGaussianDistribution
+
+
 class AutoencoderKL:
-    """Decoder half of the SD-1.5 VAE; `decode(z).sample` like diffusers' class (encode is out of scope: the
-    inversion pre-pass receives latents)."""
+    """SD-1.5 VAE: `encode(x).latent_dist.sample()` and `decode(z).sample` like diffusers' class.  A state dict may hold either
+    half (or both): the missing half raises on use."""
 
     scaling_factor = 0.18215
 
@@ -116,7 +170,16 @@ class AutoencoderKL:
     @classmethod
     def from_synthetic(cls, device: str = "cuda", seed: int = 33) -> "AutoencoderKL":
         from .. import synth
-        return cls(synth.synth_state_dict(synth.vae_decoder_schema(), seed, salt="vae."), device)
+        sd = synth.synth_state_dict(synth.vae_decoder_schema(), seed, salt="vae.")
+        sd.update(synth.synth_state_dict(synth.vae_encoder_schema(), seed, salt="vae."))
+        return cls(sd, device)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        if not self.P.has("encoder.conv_in.weight"):
+            raise KeyError("this AutoencoderKL was built without encoder.* weights")
+        d = DiagonalGaussianDistribution(encode_moments(self.P, x))
+        return AutoencoderKLOutput(latent_dist=d) if return_dict else (d,)
 
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):

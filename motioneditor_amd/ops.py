@@ -78,7 +78,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.gather = capi.GATHER_DENSE
     if conv is not None:
         a.gather = capi.GATHER_CONV3
-        a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.ups = conv
+        a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.ups = conv[:6]
+        a.pad0 = conv[6] if len(conv) > 6 else 0     # 1: pad (0,1,0,1) instead of 1 all round (VAE encoder downsampling)
         if taps != 9:
             raise ValueError("gemm: conv needs 9 taps")
     elif tconv is not None:
@@ -325,6 +326,15 @@ def cfg_ddim(latents: torch.Tensor, eps_rows: torch.Tensor, *, guidance: float, 
         return out
     capi.check(capi.lib().me_cfg_ddim(out.data_ptr(), latents.data_ptr(), eps_rows.data_ptr(), eps_rows.stride(0), nb, Cc, f, h * w,
                                       guidance, ca, cb, _stream()), "me_cfg_ddim")
+    return out
+
+
+def gaussian_sample(moments: torch.Tensor, noise: torch.Tensor, n_img: int, npix: int, scale: float = 1.0) -> torch.Tensor:
+    """moments fp16 rows [(n_img*npix), >= 8] = (mean | logvar); noise fp32 [n_img, 4, npix] -> fp32 [n_img, 4, npix]."""
+    if noise.dtype != torch.float32 or not noise.is_contiguous():
+        raise ValueError("gaussian_sample: noise must be contiguous fp32")
+    out = torch.empty((n_img, 4, npix), dtype=torch.float32, device=moments.device)
+    capi.check(capi.lib().me_gaussian_sample(out.data_ptr(), moments.data_ptr(), moments.stride(0), noise.data_ptr(), n_img, npix, float(scale), _stream()), "me_gaussian_sample")
     return out
 
 

@@ -30,7 +30,15 @@ class MotionEditorPipeline:
             raise ValueError("unet is required")
         self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer
         self.unet, self.controlnet = unet, controlnet
-        self.scheduler = scheduler if scheduler is not None else DDIMScheduler()
+        if scheduler is None:
+            scheduler = DDIMScheduler()
+        elif not isinstance(scheduler, DDIMScheduler):
+            # a diffusers DDIMScheduler as inference.py:187-197 passes it: adopt its configuration (clip_sample is forced off,
+            # reference :108-119); schedulers this path cannot reproduce are rejected here, not deep inside the loop
+            if not hasattr(scheduler, "config"):
+                raise TypeError(f"scheduler must be a DDIMScheduler or carry a DDIM `.config`, got {type(scheduler).__name__}")
+            scheduler = DDIMScheduler.from_config(scheduler.config)
+        self.scheduler = scheduler
         if getattr(self.scheduler.config, "clip_sample", False):  # reference forces clip_sample False (:108-119)
             self.scheduler.config["clip_sample"] = False
         self.vae_scale_factor = 8
@@ -69,10 +77,11 @@ class MotionEditorPipeline:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
                              f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
         if latents is None:
+            gdev = lambda g: g.device if g is not None else "cpu"  # noqa: E731  (the reference draws on a CUDA generator, inference.py:272)
             if isinstance(generator, list):
-                latents = torch.cat([torch.randn((1,) + shape[1:], generator=generator[i], dtype=torch.float32) for i in range(batch_size)], dim=0)
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=generator[i], device=gdev(generator[i]), dtype=torch.float32) for i in range(batch_size)], dim=0)
             else:
-                latents = torch.randn(shape, generator=generator, dtype=torch.float32)
+                latents = torch.randn(shape, generator=generator, device=gdev(generator), dtype=torch.float32)
         elif tuple(latents.shape) != shape:
             raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
         return (latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma).contiguous()

@@ -40,6 +40,17 @@ class DDIMScheduler:
         self.num_inference_steps = None
         self.timesteps: List[int] = []
 
+    @classmethod
+    def from_config(cls, config) -> "DDIMScheduler":
+        """Adopt a foreign scheduler's configuration (diffusers' DDIMScheduler as inference.py:187-197 builds it: `.config` is a
+        FrozenDict): only the scaled-linear, eta = 0 DDIM the reference runs is supported; anything else raises."""
+        get = (lambda k, d: config.get(k, d)) if hasattr(config, "get") else (lambda k, d: getattr(config, k, d))
+        if get("prediction_type", "epsilon") != "epsilon":
+            raise NotImplementedError(f"prediction_type {get('prediction_type', None)!r}")
+        return cls(num_train_timesteps=get("num_train_timesteps", 1000), beta_start=get("beta_start", 0.00085), beta_end=get("beta_end", 0.012),
+                   beta_schedule=get("beta_schedule", "scaled_linear"), clip_sample=False, set_alpha_to_one=get("set_alpha_to_one", False),
+                   steps_offset=get("steps_offset", 1))
+
     def set_timesteps(self, num_inference_steps: int, device=None):
         self.num_inference_steps = num_inference_steps
         ratio = self.config.num_train_timesteps // num_inference_steps

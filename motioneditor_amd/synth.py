@@ -223,6 +223,48 @@ def vae_decoder_schema() -> "OrderedDict[str, Shape]":
     return s
 
 
+def vae_encoder_schema() -> "OrderedDict[str, Shape]":
+    """Key -> shape of the encoder half of diffusers 0.15.1 ``AutoencoderKL`` (SD-1.5 VAE: block_out_channels
+    (128, 256, 512, 512), layers_per_block 2, double_z -> 8 output channels) plus ``quant_conv``."""
+    s: "OrderedDict[str, Shape]" = OrderedDict()
+
+    def conv(p, cout, cin, k):
+        s[p + ".weight"] = (cout, cin, k, k)
+        s[p + ".bias"] = (cout,)
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cout, cin, 3)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout, 3)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cout, cin, 1)
+
+    conv("encoder.conv_in", 128, 3, 3)
+    prev = 128
+    for i, c in enumerate((128, 256, 512, 512)):
+        for j in range(2):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else c, c)
+        if i < 3:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", c, c, 3)
+        prev = c
+    resnet("encoder.mid_block.resnets.0", 512, 512)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", 512)
+    for n in ("query", "key", "value", "proj_attn"):
+        s[f"{a}.{n}.weight"] = (512, 512)
+        s[f"{a}.{n}.bias"] = (512,)
+    resnet("encoder.mid_block.resnets.1", 512, 512)
+    norm("encoder.conv_norm_out", 512)
+    conv("encoder.conv_out", 8, 512, 3)
+    conv("quant_conv", 8, 8, 1)
+    return s
+
+
 # ---------------------------------------------------------------------------------------------
 # deterministic synthetic tensors
 # ---------------------------------------------------------------------------------------------

@@ -608,6 +608,32 @@ def vae_decode(sd: SD, z: torch.Tensor) -> torch.Tensor:
     return _conv2d(sd, "decoder.conv_out", x)
 
 
+def vae_encode_moments(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    """AutoencoderKL.encode up to the distribution parameters (diffusers 0.15.1 `models/vae.py` Encoder + quant_conv; NOT in
+    the reference tree, PARITY UNPINNED; call site inference.py:262): x [n,3,H,W] in [-1,1] -> moments [n,8,H/8,W/8]
+    = (mean | logvar).  DownEncoderBlock2D's Downsample2D pads (0,1,0,1) and convolves with stride 2, padding 0."""
+    x = _conv2d(sd, "encoder.conv_in", x)
+    for i in range(4):
+        for j in range(2):
+            x = vae_resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", x)
+        if i < 3:
+            p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2)
+    x = vae_resnet(sd, "encoder.mid_block.resnets.0", x)
+    x = vae_attention(sd, "encoder.mid_block.attentions.0", x)
+    x = vae_resnet(sd, "encoder.mid_block.resnets.1", x)
+    x = F.silu(F.group_norm(x, 32, sd["encoder.conv_norm_out.weight"], sd["encoder.conv_norm_out.bias"], 1e-6))
+    x = _conv2d(sd, "encoder.conv_out", x)
+    return _conv2d(sd, "quant_conv", x, padding=0)
+
+
+def vae_encode_sample(sd: SD, x: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """DiagonalGaussianDistribution.sample with the noise supplied: mean + exp(0.5 * clamp(logvar, -30, 20)) * noise."""
+    m = vae_encode_moments(sd, x)
+    mean, logvar = m[:, :4], m[:, 4:].clamp(-30.0, 20.0)
+    return mean + torch.exp(0.5 * logvar) * noise
+
+
 def decode_latents(sd: SD, latents: torch.Tensor) -> torch.Tensor:
     """pipeline_motion_editor.py:346-355: [b,4,f,h,w] latents -> [b,3,f,8h,8w] video in [0,1]."""
     b, c, f, h, w = latents.shape

@@ -30,13 +30,14 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
     N, taps, K = w.shape
     xf, wf = x.float()[:, :K], w.float()
     if conv is not None:
-        Hin, Win, Hout, Wout, stride, ups = conv
+        Hin, Win, Hout, Wout, stride, ups = conv[:6]
+        pad0 = conv[6] if len(conv) > 6 else 0
         n_img = x.shape[0] // (Hin * Win)
         img = xf.reshape(n_img, Hin, Win, K).permute(0, 3, 1, 2)
         if ups:
             img = img.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
         wk = wf.reshape(N, 3, 3, K).permute(0, 3, 1, 2)
-        y = F.conv2d(img, wk, None, stride=stride, padding=1)
+        y = F.conv2d(F.pad(img, (0, 1, 0, 1)), wk, None, stride=stride) if pad0 else F.conv2d(img, wk, None, stride=stride, padding=1)
         assert y.shape[2] == Hout and y.shape[3] == Wout
         acc = y.permute(0, 2, 3, 1).reshape(-1, N)
     elif tconv is not None and len(tconv) > 3:
@@ -235,6 +236,11 @@ def cfg_ddim(latents, eps_rows, *, guidance, ca, cb):
     e = eps_rows.float()[:, :C].reshape(2 * nb, f, h * w, C).permute(0, 3, 1, 2).reshape(2 * nb, C, f, h, w)
     eu, ec = e[:nb], e[nb:]
     return ca * latents + cb * (eu + guidance * (ec - eu))
+
+
+def gaussian_sample(moments, noise, n_img, npix, scale=1.0):
+    m = moments.float()[:, :8].reshape(n_img, npix, 8).permute(0, 2, 1)
+    return (m[:, :4] + torch.exp(0.5 * m[:, 4:].clamp(-30.0, 20.0)) * noise.float().reshape(n_img, 4, npix)) * scale
 
 
 def nchw5_to_rows(x):

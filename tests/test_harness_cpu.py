@@ -1,0 +1,65 @@
+"""P0 of SURVEY 8a: the harness call sequence (inference.py:296-323).  The synthetic inputs of examples/run_edit.py are pinned by
+tests/golden/harness_inputs.npz (shapes + checksums), the tensor conventions by direct assertions."""
+import sys
+
+import numpy as np
+import torch
+
+from conftest import GOLD, ROOT
+
+sys.path.insert(0, str(ROOT / "examples"))
+
+
+def test_harness_inputs_match_the_fixture():
+    import run_edit
+    g = np.load(GOLD / "harness_inputs.npz")
+    x = run_edit.harness_inputs(8, 64, 64)
+    assert set(k.split(".")[0] for k in g.files) == set(x)
+    for k, v in x.items():
+        a = v.numpy().astype(np.float64)
+        assert tuple(g[k + ".shape"]) == a.shape, k
+        np.testing.assert_allclose([a.sum(), np.abs(a).sum(), a.min(), a.max()], g[k + ".stats"], rtol=1e-9, atol=1e-9, err_msg=k)
+    assert float(x["pixel_values"].abs().max()) <= 1.0 and set(np.unique(x["source_masks"].numpy())) <= {0.0, 1.0}
+    assert 0.0 <= float(x["target_skeleton"].min()) and float(x["target_skeleton"].max()) <= 1.0
+
+
+def test_skeleton_convention_only_the_last_entry_is_used():
+    """inference.py:300-302 builds cat([0, target, 0, target]); the pipeline takes skeleton[-1] (pipeline_motion_editor.py:556),
+    repeats it for the batch and doubles it for classifier-free guidance -> [2 f, 3, H, W]."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+
+    class U:   # the constructor only reads .device
+        device = torch.device("cpu")
+
+    pipe = MotionEditorPipeline(unet=U())
+    tgt = torch.rand(1, 4, 3, 16, 16)
+    skeleton = torch.cat([torch.zeros_like(tgt), tgt, torch.zeros_like(tgt), tgt])
+    img = pipe.prepare_image(torch.unsqueeze(skeleton[-1], 0), 16, 16, 1, 1, "cpu", torch.float32, True)
+    assert img.shape == (2, 4, 3, 16, 16) and torch.equal(img[0], tgt[0]) and torch.equal(img[1], tgt[0])
+
+
+def test_foreign_scheduler_config_is_adopted_and_bad_ones_rejected():
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from motioneditor_amd.schedulers import DDIMScheduler
+
+    class U:
+        device = torch.device("cpu")
+
+    class Frozen(dict):   # diffusers' FrozenDict refuses item assignment
+        def __setitem__(self, k, v):
+            raise RuntimeError("frozen")
+        __getattr__ = dict.__getitem__
+
+    class Foreign:
+        config = Frozen(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=True,
+                        set_alpha_to_one=False, steps_offset=1)
+
+    p = MotionEditorPipeline(unet=U(), scheduler=Foreign())
+    assert isinstance(p.scheduler, DDIMScheduler) and p.scheduler.config.clip_sample is False
+    p.scheduler.set_timesteps(50)
+    assert p.scheduler.timesteps[0] == 981 and p.scheduler.timesteps[-1] == 1
+    try:
+        MotionEditorPipeline(unet=U(), scheduler=object())
+        raise AssertionError("scheduler without a config accepted")
+    except TypeError:
+        pass

@@ -325,6 +325,105 @@ def test_vae_decode_vs_cpu_oracle():
     assert got.shape == (2, 3, 128, 128) and e <= 5e-3, e
 
 
+def test_vae_encode_vs_cpu_oracle():
+    """SURVEY 8f rank 2, encode half (parity unpinned): two 128x128 frames -> 16x16 latents, HIP path vs oracle/ref_cpu.py::vae_encode_sample
+    with the same noise (asymmetric (0,1,0,1) padding of the stride-2 convolutions, mid attention, DiagonalGaussian sample, x 0.18215)."""
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from oracle import ref_cpu
+    sd_np = synth.synth_state_dict(synth.vae_encoder_schema(), salt="vae.")
+    x = torch.from_numpy(synth.synth_normal("vae.x", (2, 3, 128, 128), 33)).clamp(-1, 1)
+    noise = torch.from_numpy(synth.synth_normal("vae.noise", (2, 4, 16, 16), 33))
+    with torch.no_grad():
+        want = ref_cpu.vae_encode_sample({k: torch.from_numpy(v) for k, v in sd_np.items()}, x, noise) * 0.18215
+    got = AutoencoderKL(sd_np, device="cuda").encode(x.cuda()).latent_dist.sample(noise=noise.cuda(), scale=0.18215).cpu()
+    e = rel_l2(got, want)
+    record("vae_encode", e)
+    assert got.shape == (2, 4, 16, 16) and e <= 5e-3, e
+
+
+def test_harness_sequence_call_on_gpu_vs_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch):
+    """P0 (inference.py:255-326) through examples/run_edit.py on the HIP path: VAE encode -> 2 DDIM-inversion steps (normal_infer)
+    -> repeat(2) -> both editors registered -> MotionEditorPipeline.__call__ (2 steps, uncond_embeddings=None so the negative
+    embedding is prepended, skeleton = cat([0, tgt, 0, tgt])) -> VAE decode; against the same sequence composed from the oracle."""
+    import sys
+    sys.path.insert(0, str(ROOT / "examples"))
+    import run_edit
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    f, H = 8, 64
+    x = run_edit.harness_inputs(f, H, H)
+    vsd = dict(synth.synth_state_dict(synth.vae_decoder_schema(), salt="vae."))
+    vsd.update(synth.synth_state_dict(synth.vae_encoder_schema(), salt="vae."))
+    vt = {k: torch.from_numpy(v) for k, v in vsd.items()}
+    steps = inv_steps = 2
+    # ---- oracle ----
+    with torch.no_grad():
+        lat = ref_cpu.vae_encode_sample(vt, x["pixel_values"].reshape(f, 3, H, H), x["encode_noise"])
+        lat = lat.reshape(1, f, 4, H // 8, H // 8).permute(0, 2, 1, 3, 4) * 0.18215
+        d_inv = ref_cpu.DDIM()
+        d_inv.set_timesteps(inv_steps)
+        inv = ref_cpu.ddim_loop(unet_sd_torch, d_inv, lat, inv_steps, x["negative_text_embeddings"], normal_infer=True)[-1].repeat(2, 1, 1, 1, 1)
+        ddim = ref_cpu.DDIM()
+        ddim.set_timesteps(steps)
+        sp, tp = ref_cpu.SpatialEditor(x["source_masks"]), ref_cpu.TemporalEditor()
+        images = torch.cat([x["target_skeleton"]] * 2).reshape(2 * f, 3, H, H)
+        want = inv
+        for t in ddim.timesteps:
+            want = ref_cpu.denoise_step(unet_sd_torch, cn_sd_torch, ddim, want, t, x["negative_text_embeddings"], x["text_embeddings"], images, sp, tp, 7.5)
+        video = ref_cpu.decode_latents(vt, want)
+    # ---- product ----
+    pipe = MotionEditorPipeline(vae=AutoencoderKL(vsd, device="cuda"), unet=unet, controlnet=controlnet)
+    xs = {k: v.cuda() for k, v in x.items()}
+    s_inv, s_gen, inv_lat = run_edit.run(pipe, xs, steps=steps, inv_steps=inv_steps)
+    unet.spatial_editor = unet.temporal_editor = None
+    e_inv = rel_l2(inv_lat, inv)
+    got = torch.cat([s_inv, s_gen])
+    e = float((got.float().cpu() - video).abs().mean() / video.abs().mean())
+    record("harness_inversion_latents", e_inv)
+    record("harness_video_mean_abs_rel", e)
+    assert got.shape == (2, 3, f, H, H) and e_inv <= STEP_TOL and e <= 1e-2, (e_inv, e)
+
+
+def test_from_pretrained_roundtrip_on_synthetic_safetensors(tmp_path, unet_sd_np, cn_sd_np):
+    """SURVEY 8f rank 3 on the GPU: a checkpoint directory as inference.py:152-156,237-240 reads it -- an SD-1.5 style 2-D UNet
+    (`unet/diffusion_pytorch_model.safetensors`, no temporal / adapter keys), the accelerate `pytorch_model.bin` of stage 1 with the
+    temporal modules, the adapter `.pth`, a ControlNet directory -- written by this test from the synthetic weights, loaded with the
+    reference's from_pretrained signature, must reproduce the forward of the model built directly from the full state dict."""
+    from safetensors.torch import save_file
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    full = {k: torch.from_numpy(v) for k, v in unet_sd_np.items()}
+    base = {k: v for k, v in full.items() if "temp" not in k and not k.startswith("controlnet_adapter.")}
+    temporal = {k: v for k, v in full.items() if "temp" in k and not k.startswith("controlnet_adapter.")}
+    adapter = {k[len("controlnet_adapter."):]: v for k, v in full.items() if k.startswith("controlnet_adapter.")}
+    (tmp_path / "sd15" / "unet").mkdir(parents=True)
+    save_file(base, str(tmp_path / "sd15" / "unet" / "diffusion_pytorch_model.safetensors"))
+    (tmp_path / "ckpt").mkdir()
+    torch.save({**base, **temporal}, tmp_path / "ckpt" / "pytorch_model.bin")
+    torch.save(adapter, tmp_path / "adapter.pth")
+    (tmp_path / "cn").mkdir()
+    save_file({k: torch.from_numpy(v) for k, v in cn_sd_np.items()}, str(tmp_path / "cn" / "diffusion_pytorch_model.safetensors"))
+    u = UNet2DConditionModel.from_pretrained(str(tmp_path / "sd15"), subfolder="unet", resume_from_checkpoint=str(tmp_path / "ckpt"),
+                                             adapter_weight_path=str(tmp_path / "adapter.pth"), device="cuda")
+    c = synth.make_case_inputs("two", B=4, f=8, h=16, w=16)
+    kw = dict(down_block_additional_residuals=[d.cuda() for d in c["down_res"]], mid_block_additional_residual=c["mid_res"].cuda())
+    ref = UNet2DConditionModel(unet_sd_np, device="cuda")
+    got = u(c["sample"].cuda(), c["t"], c["ehs"].cuda(), **kw).sample
+    want = ref(c["sample"].cuda(), c["t"], c["ehs"].cuda(), **kw).sample
+    assert torch.equal(got, want), rel_l2(got, want)
+    cn = ControlNetModel.from_pretrained(str(tmp_path / "cn"), device="cuda")
+    lat = torch.from_numpy(synth.synth_normal("rt.lat", (2, 4, 16, 16), 33)).cuda()
+    ehs = torch.from_numpy(synth.synth_normal("rt.ehs", (2, 77, 768), 33, 0.3)).cuda()
+    img = torch.rand(2, 3, 128, 128, generator=torch.Generator().manual_seed(3)).cuda()
+    d1, m1 = cn(lat, 981, ehs, img)
+    d2, m2 = ControlNetModel(cn_sd_np, device="cuda")(lat, 981, ehs, img)
+    assert torch.equal(m1, m2) and all(torch.equal(a, b) for a, b in zip(d1, d2))
+
+
 def test_properties_at_larger_size(unet):
     """Size-independent checks on a bigger clip (B=4, f=16, 32x32 latents): (1) determinism; (2) the
     reconstruction rows do not depend on the editing rows' inputs (K/V injection is one-way);

@@ -55,3 +55,25 @@ def test_pipeline_decode_latents_uses_the_decoder(emu, vae_sd_np):
         want = ref_cpu.decode_latents(sd, lat).numpy()
     assert video.shape == (1, 3, 2, 64, 64) and video.min() >= 0.0 and video.max() <= 1.0
     assert np.abs(video - want).max() < 1e-3
+
+
+def test_vae_encode_graph_matches_oracle(monkeypatch):
+    """SURVEY 8f rank 2, encode half (inference.py:262-265): the launch graph on the emulated ABI vs oracle/ref_cpu.py::vae_encode_sample
+    (parity unpinned: diffusers' AutoencoderKL is not in the reference tree)."""
+    import emu_ops
+    from motioneditor_amd import synth
+    from motioneditor_amd.models import graph, vae
+    from oracle import ref_cpu
+    for m in (graph, vae):
+        monkeypatch.setattr(m, "ops", emu_ops)
+    sd_np = synth.synth_state_dict(synth.vae_encoder_schema(), salt="vae.")
+    x = torch.from_numpy(synth.synth_normal("vae.x", (2, 3, 32, 32), 33)).clamp(-1, 1)
+    noise = torch.from_numpy(synth.synth_normal("vae.noise", (2, 4, 4, 4), 33))
+    with torch.no_grad():
+        want = ref_cpu.vae_encode_sample({k: torch.from_numpy(v) for k, v in sd_np.items()}, x, noise) * 0.18215
+    d = vae.AutoencoderKL(sd_np, device="cpu", dtype=torch.float32).encode(x).latent_dist
+    got = d.sample(noise=noise, scale=0.18215)
+    assert got.shape == (2, 4, 4, 4)
+    assert float((got - want).abs().max() / want.abs().mean()) < 2e-4
+    mean = ref_cpu.vae_encode_moments({k: torch.from_numpy(v) for k, v in sd_np.items()}, x)[:, :4]
+    assert float((d.mode() - mean).abs().max() / mean.abs().mean()) < 2e-4
