@@ -18,7 +18,8 @@ SEG_COUNT: Dict[int, int] = {}  # seg_item.data_ptr() -> number of valid (item, 
 KEY_UNITS: Dict[int, int] = {}  # seg_item.data_ptr() -> sum over items of (1 per plain, 2 per dual segment); FLOP accounting only
 
 
-def _mk(key, rows_item, rows_mode, device):
+def _mk(key, rows_item, rows_mode, device, ref_units=None):
+    """ref_units: reference-semantics key units of the table when it differs from what the rows spell out (collapsed duplicates)."""
     hit = _cache.get((key, str(device)))
     if hit is None:
         hit = (torch.tensor(rows_item, dtype=torch.int32, device=device), torch.tensor(rows_mode, dtype=torch.int32, device=device))
@@ -26,7 +27,8 @@ def _mk(key, rows_item, rows_mode, device):
         GENERAL_DUAL[hit[1].data_ptr()] = any(m in (SEG_DUAL_CUR, SEG_DUAL_PREV) for rm in rows_mode for m in rm)
         BINARY_DUAL[hit[1].data_ptr()] = any(m == SEG_DUAL_BIN for rm in rows_mode for m in rm)
         SEG_COUNT[hit[0].data_ptr()] = sum(1 for ri in rows_item for i_ in ri if i_ >= 0)
-        KEY_UNITS[hit[0].data_ptr()] = sum((2 if m != SEG_PLAIN else 1) for ri, rm in zip(rows_item, rows_mode) for i_, m in zip(ri, rm) if i_ >= 0)
+        KEY_UNITS[hit[0].data_ptr()] = ref_units if ref_units is not None else \
+            sum((2 if m != SEG_PLAIN else 1) for ri, rm in zip(rows_item, rows_mode) for i_, m in zip(ri, rm) if i_ >= 0)
     return hit
 
 
@@ -57,8 +59,10 @@ def _gi(shard, B, f):
 def prev_cur(B: int, f: int, device, shard=None):
     """MotionFrameAttention: keys = [frame max(i-1,0) | frame i] (attention_2d.py:732-740).  f = local frames."""
     gi, f0, key = _gi(shard, B, f)
-    rows = [[gi(b, max(f0 + i - 1, 0)), gi(b, f0 + i)] for b in range(B) for i in range(f)]
-    return _mk(("prevcur", B, f) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+    # global frame 0 attends [frame 0 | frame 0]: a softmax over every key twice equals the softmax over every key once (each
+    # weight doubles in numerator and denominator), so that item gets ONE segment -- same result, half its work
+    rows = [([gi(b, f0 + i), -1] if f0 + i == 0 else [gi(b, f0 + i - 1), gi(b, f0 + i)]) for b in range(B) for i in range(f)]
+    return _mk(("prevcur", B, f) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device, ref_units=2 * B * f)
 
 
 def first_prev_chunked(B: int, f: int, chunk: int, device, shard=None):
@@ -70,8 +74,9 @@ def first_prev_chunked(B: int, f: int, chunk: int, device, shard=None):
         for i in range(f):
             g = f0 + i
             c0 = g - g % chunk
-            rows.append([gi(b, c0), gi(b, c0 + max(g % chunk - 1, 0))])
-    return _mk(("firstprev", B, f, chunk) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device)
+            # the first two frames of a chunk attend [first | first]: duplicated keys, one segment gives the same softmax
+            rows.append([gi(b, c0), -1] if g % chunk <= 1 else [gi(b, c0), gi(b, c0 + g % chunk - 1)])
+    return _mk(("firstprev", B, f, chunk) + key, rows, [[SEG_PLAIN, SEG_PLAIN]] * (B * f), device, ref_units=2 * B * f)
 
 
 def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4, shard=None):
