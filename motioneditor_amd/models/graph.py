@@ -154,10 +154,11 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
     if shard is None:
         qkv = ops.gemm(n, P.fused(names))
         return qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    q = ops.gemm(n, P.mat(names[0]))
     ext, loc = shard.kv_buffer(n.shape[0], 2 * C, B, N, n)     # the K|V GEMM writes straight into its slot of the exchanged tensor
     ops.gemm(n, P.fused(names[1:]), out=loc)
-    kv = shard.complete_kv(ext, B, N, ops.copy_rows)
+    pending = shard.start_kv(ext, B, N, ops.copy_rows)          # the exchange (RCCL stream) runs under the query projection
+    q = ops.gemm(n, P.mat(names[0]))
+    kv = shard.finish_kv(pending)
     return q, kv[:, :C], kv[:, C:]
 
 

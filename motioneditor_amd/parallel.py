@@ -69,11 +69,21 @@ class FrameShard:
         ext = torch.empty((self.world, rows, cols), dtype=like.dtype, device=like.device)
         return ext, ext[self.rank]
 
-    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
+    def start_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None):
+        """Launch the exchange that completes `ext` WITHOUT waiting for it: RCCL runs it on its own stream behind the K|V
+        projection, so the caller's next launches (the query projection) overlap the transfer; finish_kv() joins."""
         loc = ext[self.rank]
         _count("all_gather(K|V rows)", loc)
-        dist.all_gather_into_tensor(ext.reshape(-1, ext.shape[-1]), loc, group=self.group)   # in place: input = this rank's slot
+        work = dist.all_gather_into_tensor(ext.reshape(-1, ext.shape[-1]), loc, group=self.group, async_op=True)   # in place: input = this rank's slot
+        return (work, ext)
+
+    def finish_kv(self, handle) -> torch.Tensor:
+        work, ext = handle
+        work.wait()
         return ext.reshape(self.world * ext.shape[1], ext.shape[2])
+
+    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
+        return self.finish_kv(self.start_kv(ext, B, npix, copy_rows))
 
     def item(self, B: int, b: int, g: int) -> int:
         """kv item index of (batch row b, GLOBAL frame g) inside an all-gathered [world][B*f_loc items] tensor."""
@@ -139,12 +149,14 @@ class PrevFrameHalo:
         ext = torch.empty((B * npix + rows, cols), dtype=like.dtype, device=like.device)
         return ext, ext[B * npix:]
 
-    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+    def start_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows):
+        """Post the one-frame halo send / receive without waiting (the query projection overlaps it); finish_kv() joins."""
         s = self.s
         kv = ext[B * npix:]
         ops_ = []
+        keep = None
         if self.rank < self.world - 1:
-            last = torch.empty((B * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
+            last = keep = torch.empty((B * npix, kv.shape[1]), dtype=kv.dtype, device=kv.device)
             for b in range(B):
                 copy_rows(last[b * npix:(b + 1) * npix], kv[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
             _count("p2p(attn1 K|V halo)", last)
@@ -153,10 +165,17 @@ class PrevFrameHalo:
             ops_.append(dist.P2POp(dist.irecv, ext[:B * npix], s._ranks[self.rank - 1], s.group))
         else:
             copy_rows(ext[:B * npix], kv[:B * npix])      # never addressed (frame 0 has no predecessor); keep it finite
-        if ops_:
-            for r in dist.batch_isend_irecv(ops_):
-                r.wait()
+        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+        return (reqs, ext, keep)
+
+    def finish_kv(self, handle) -> torch.Tensor:
+        reqs, ext, _keep = handle
+        for r in reqs:
+            r.wait()
         return ext
+
+    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+        return self.finish_kv(self.start_kv(ext, B, npix, copy_rows))
 
     def gather_kv(self, kv: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
         ext, loc = self.kv_buffer(kv.shape[0], kv.shape[1], B, npix, kv)
