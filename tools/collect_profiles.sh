@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the judged evidence on the GPU box: usage  bash tools/collect_profiles.sh <tag>   (e.g. r01_v4)
 # Writes gpurun_out/<tag>_*; copy what should be kept into profiles/ afterwards.
-tag=${1:-r01}
+tag=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
@@ -23,5 +23,7 @@ python tools/rocpd_summary.py $(find gpurun_out/${tag}_prof -name "*.db" | head 
 ( cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap > $R/gpurun_out/${tag}_pmc_w.log 2>&1 )
 python tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*.db" | head -1) $(find gpurun_out/${tag}_pmc_w -name "*.db" | head -1) gpurun_out/${tag}_pmc_hbm.csv gpurun_out/${tag}_pmc_traffic.json 3 >> gpurun_out/${tag}_summary.txt 2>&1
 timeout 600 python tools/kbench.py gemm attn misc > gpurun_out/${tag}_kbench.txt 2>&1
+timeout 300 tools/_bin/ubench > gpurun_out/${tag}_ubench.txt 2>&1
+timeout 600 bash tools/exp_pmc_attn.sh 0 > /dev/null 2>&1; cp gpurun_out/r2c/pmc_attn.txt gpurun_out/${tag}_attn_dh40_sq_counters.txt 2>/dev/null
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
 cat gpurun_out/${tag}_summary.txt; tail -c 600 gpurun_out/${tag}_bench_c3.json

@@ -15,6 +15,23 @@ def per_kernel(db):
     return {k: (n, s) for k, n, s in cur.execute("select kernel_name, count(*), sum(value) from counters_collection group by kernel_name")}
 
 
+def short(k: str):
+    """rocprofv3 kernel name -> the name me_last_kernel() / bench.py use (first template arguments only)."""
+    import re
+    m = re.search(r"(attn2_kernel)<(\d+), (\d+), (\d+)", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>"
+    m = re.search(r"(gemm_kernel)<(\d+), (\d+)", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+    if "conv3_halo_kernel" in k:
+        return "conv3_halo_kernel"
+    m = re.search(r"(attn_kernel)<(\d+), (\d+)", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},general-dual>"
+    return None
+
+
 F, W = per_kernel(fdb), per_kernel(wdb)
 rows = []
 for k in sorted(set(F) | set(W), key=lambda k: -(F.get(k, (0, 0))[1] + W.get(k, (0, 0))[1])):
@@ -28,10 +45,10 @@ with open(out_csv, "w", newline="") as fh:
     for k, n, f_kb, w_kb in rows[:40]:
         per = (2 * f_kb + w_kb) * 1024 / n
         w.writerow([k, n, f"{f_kb:.0f}", f"{w_kb:.0f}", f"{per:.0f}", f"{(2 * f_kb + w_kb) * 1024 / steps / 1e9:.2f}"])
-        name = "gemm" if ("gemm_kernel" in k or "conv3_halo_kernel" in k) else ("attn_dh40" if "attn_kernel<40" in k else ("attn_dh80" if "attn_kernel<80" in k else None))
-        if name:
-            d = fam.setdefault(name, [0, 0.0])
-            d[0] += n
-            d[1] += (2 * f_kb + w_kb) * 1024
+        for name in (short(k), "gemm" if ("gemm_kernel" in k or "conv3_halo_kernel" in k) else None):
+            if name:
+                d = fam.setdefault(name, [0, 0.0])
+                d[0] += n
+                d[1] += (2 * f_kb + w_kb) * 1024
 json.dump({k: {"launches": v[0], "hbm_bytes_per_launch": v[1] / v[0], "gb_per_step": v[1] / steps / 1e9} for k, v in fam.items()}, open(out_json, "w"), indent=1)
 print(open(out_json).read())
