@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 2
+#define ME_ABI_VERSION 3
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -167,6 +167,9 @@ typedef struct me_tattn_args {
    * K/V is the all-gather of kv_parts equal frame shards, part-major: row of (b, global frame j, p) =
    * ((j / fpp) * batch + b) * fpp * npix + (j % fpp) * npix + p with fpp = frames / kv_parts (0 or 1 = one part) */
   int32_t q_frames, q_frame0, kv_parts;
+  /* pixel sharding (the frame<->pixel all-to-all of a frame-sharded run): q_parts > 1 = Q and O hold ALL frames in the
+   * same part-major row order as K/V (q_parts == kv_parts, q_frames == 0); npix is then this rank's pixel slice */
+  int32_t q_parts;
 } me_tattn_args;
 
 int me_tattn(const me_tattn_args* a, void* stream);
@@ -220,6 +223,11 @@ int me_axpy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, const void* A
                  int64_t rows, int32_t cols, float alpha, void* stream);
 /* copy a [rows, cols] fp16 view (skip concat, unet_2d_blocks.py "torch.cat([hidden, res], dim=1)") */
 int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream);
+/* n0 x n1 blocks of [rows, cols] fp16: block (i, j) goes from row i*xs0 + j*xs1 of X to row i*ys0 + j*ys1 of Y (strides in
+ * rows).  The (batch*frame, pixel slice) <-> (pixel slice, batch*frame) reorder either side of the frame<->pixel all-to-all
+ * of a frame-sharded run; the reference has no counterpart (its rearranges are views of one device's tensor). */
+int me_copy_blocks(void* Y, int32_t ldy, const void* X, int32_t ldx, int32_t n0, int32_t n1, int64_t rows, int32_t cols,
+                   int64_t ys0, int64_t ys1, int64_t xs0, int64_t xs1, void* stream);
 /* y = silu(x), n fp16 elements */
 int me_silu(void* Y, const void* X, int64_t n, void* stream);
 /* y = relu(x), n fp16 elements (adapter ResnetBlock.act, controlnet_adapter.py:452,504) */

@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 2
+ABI_VERSION = 3
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -59,7 +59,7 @@ class TAttnArgs(C.Structure):
         ("heads", _i32), ("dh", _i32),
         ("batch", _i32), ("frames", _i32), ("npix", _i32),
         ("kv_map", _i32 * 8), ("scale", _f32),
-        ("q_frames", _i32), ("q_frame0", _i32), ("kv_parts", _i32),
+        ("q_frames", _i32), ("q_frame0", _i32), ("kv_parts", _i32), ("q_parts", _i32),
     ]
 
 
@@ -96,6 +96,7 @@ SYMBOLS = {
     "me_softmax_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
+    "me_copy_blocks": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _i64, _i64, _i64, _i64, _vp]),
     "me_silu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "me_relu": (C.c_int, [_vp, _vp, _i64, _vp]),
     "me_timestep_embed": (C.c_int, [_vp, _i32, _i32, _f32, _vp]),

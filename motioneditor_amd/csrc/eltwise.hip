@@ -82,6 +82,19 @@ __global__ __launch_bounds__(256) void copy_rows_kernel(f16* Y, int ldy, const f
   }
 }
 
+__global__ __launch_bounds__(256) void copy_blocks_kernel(f16* Y, int ldy, const f16* X, int ldx, int n1, long rows, int cols, long total, long ys0, long ys1,
+                                                          long xs0, long xs1) {
+  const int vpr = cols / 8;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    long r = idx / vpr;
+    const int c = (int)(idx - r * vpr) * 8;
+    const long blk = r / rows;
+    r -= blk * rows;
+    const long i = blk / n1, j = blk - i * n1;
+    *reinterpret_cast<uint4*>(Y + (i * ys0 + j * ys1 + r) * ldy + c) = ldg128(X + (i * xs0 + j * xs1 + r) * ldx + c);
+  }
+}
+
 template <int OP>  // 0 silu, 1 relu
 __global__ __launch_bounds__(256) void unary_kernel(f16* Y, const f16* X, long n) {
   for (long idx = ((long)blockIdx.x * 256 + threadIdx.x) * 8; idx < n; idx += (long)gridDim.x * 256 * 8) {
@@ -223,6 +236,17 @@ extern "C" int me_copy_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, in
   hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(rows * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
                      reinterpret_cast<const f16*>(X), ldx, (long)rows, cols);
   ME_CHECK_LAUNCH("me_copy_rows")
+}
+
+extern "C" int me_copy_blocks(void* Y, int32_t ldy, const void* X, int32_t ldx, int32_t n0, int32_t n1, int64_t rows, int32_t cols, int64_t ys0, int64_t ys1,
+                              int64_t xs0, int64_t xs1, void* stream) {
+  if (!Y || !X || n0 <= 0 || n1 <= 0 || rows <= 0 || cols <= 0 || cols % 8 || ldy % 8 || ldx % 8 || ys0 < 0 || ys1 < 0 || xs0 < 0 || xs1 < 0 ||
+      (((uintptr_t)Y | (uintptr_t)X) & 15)) { me_set_error("me_copy_blocks: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
+  const long total = (long)n0 * n1 * rows * (cols / 8);
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3(grid_for(total)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<f16*>(Y), ldy,
+                     reinterpret_cast<const f16*>(X), ldx, n1, (long)rows, cols, total, (long)ys0, (long)ys1, (long)xs0, (long)xs1);
+  ME_CHECK_LAUNCH("me_copy_blocks")
 }
 
 extern "C" int me_silu(void* Y, const void* X, int64_t n, void* stream) {

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(512) void tattn_kernel(const me_tattn_args a) {
   const int hl = tid / QF, il = tid - hl * QF;
   const int i = q0 + il;                                   // global frame of this query
   const int lcol = hl * a.dh;
-  const long qrow = ((long)b * QF + il) * a.npix + p;
+  // query/output row: (b, local frame, pixel), or part-major like K/V after the frame<->pixel all-to-all (q_parts > 1)
+  const long qrow = a.q_parts > 1 ? ((long)(i / fpp) * a.batch + b) * fpp * a.npix + (long)(i % fpp) * a.npix + p : ((long)b * QF + il) * a.npix + p;
   const int nch = a.dh / 8;
 
   float s[F];
@@ -141,7 +142,7 @@ extern "C" int me_tattn(const me_tattn_args* a, void* stream) {
   if (a->ldq % 8 || a->ldk % 8 || a->ldv % 8 || a->ldo % 8) { me_set_error("me_tattn: row strides must be multiples of 8"); return ME_EINVAL; }
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) & 15) { me_set_error("me_tattn: misaligned pointer"); return ME_EINVAL; }
   if (a->q_frames < 0 || a->q_frame0 < 0 || (a->q_frames > 0 && a->q_frame0 + a->q_frames > a->frames) ||
-      (a->kv_parts > 1 && a->frames % a->kv_parts)) { me_set_error("me_tattn: bad frame-shard geometry"); return ME_EINVAL; }
+      (a->kv_parts > 1 && a->frames % a->kv_parts) || (a->q_parts > 1 && (a->q_parts != a->kv_parts || a->q_frames > 0))) { me_set_error("me_tattn: bad frame-shard geometry"); return ME_EINVAL; }
   for (int b = 0; b < a->batch; ++b)
     if (a->kv_map[b] < 0 || a->kv_map[b] >= a->batch) { me_set_error("me_tattn: kv_map out of range"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -77,8 +77,12 @@ class TemporalCall:
     N: int
     dh: int
     shard: object = None   # parallel.FrameShard: q holds the local frames, k/v all frames (all-gathered, part-major)
+    parts: int = 0         # > 1: after the frame<->pixel all-to-all -- q, k, v hold ALL f frames of N pixels, part-major
 
     def run(self, kv_map: Optional[Sequence[int]] = None) -> torch.Tensor:
+        if self.parts > 1:
+            return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=self.f, npix=self.N, kv_map=kv_map,
+                                          kv_parts=self.parts, q_parts=self.parts)
         if self.shard is None:
             return ops.temporal_attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, batch=self.B, frames=self.f, npix=self.N, kv_map=kv_map)
         sh = self.shard
@@ -162,6 +166,21 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
     return q, kv[:, :C], kv[:, C:]
 
 
+def _temporal_attn(P: Packed, p: str, n: torch.Tensor, C: int, B: int, f: int, N: int, dh: int, shard, editor=None, place: str = "") -> torch.Tensor:
+    """Causal attention over frames of the projections of `n` (rows (b, local frame, pixel)); returns the attention output
+    in the same row order.  Frame-sharded: the fused q|k|v rows go through the frame<->pixel all-to-all, so every rank
+    attends over all frames of its pixel slice (parallel.FrameShard.to_pixel_shards), or K|V is all-gathered."""
+    def go(tc):
+        return editor(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if editor is not None else tc.run()
+    if shard is not None and shard.pixel_sharded(N):
+        qkv = ops.gemm(n, P.fused([p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]))
+        r = shard.to_pixel_shards(qkv, B * f, N, ops.copy_blocks)
+        a = go(TemporalCall(r[:, :C], r[:, C:2 * C], r[:, 2 * C:], B, shard.f_total, N // shard.world, dh, None, shard.world))
+        return shard.to_frame_shards(a, B * f, N, ops.copy_blocks)
+    q, k, v = _qkv(P, p, n, C, shard)
+    return go(TemporalCall(q, k, v, B, f, N, dh, shard))
+
+
 def _tconv(P: Packed, name: str, h_ext: torch.Tensor, x: "Act", chunk: int, shard, **epi) -> torch.Tensor:
     """TemporalConv k=3 over frames.  Sharded: h_ext has 2*B*N spare rows for the neighbours' boundary frames."""
     rows = x.B * x.f * x.N
@@ -207,9 +226,7 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
     t = feed_forward(P, p + ".ff", _ln(P, p + ".norm3", t), t)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
     if has_temp:
-        q, k, v = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, shard)
-        tc = TemporalCall(q, k, v, x.B, x.f, x.N, dh, shard)
-        a = temporal(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if temporal is not None else tc.run()
+        a = _temporal_attn(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, x.B, x.f, x.N, dh, shard, temporal, place)
         t = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     return x.like(t)
 
@@ -288,8 +305,7 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int
     a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a)
     a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
     # causal temporal attention over the TRUE frame count
-    q_, k_, v_ = _qkv(P, p + ".attn_self_temp", _ln(P, p + ".norm_self_temp", a), C, shard)
-    at = TemporalCall(q_, k_, v_, nb, x.f, x.N, dh, shard).run()
+    at = _temporal_attn(P, p + ".attn_self_temp", _ln(P, p + ".norm_self_temp", a), C, nb, x.f, x.N, dh, shard)
     return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc)
 
 

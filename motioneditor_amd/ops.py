@@ -193,9 +193,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
 
 def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, dh: int, batch: int, frames: int, npix: int,
                        kv_map: Optional[Sequence[int]] = None, scale: Optional[float] = None, q_frames: int = 0, q_frame0: int = 0,
-                       kv_parts: int = 1) -> torch.Tensor:
+                       kv_parts: int = 1, q_parts: int = 1) -> torch.Tensor:
     """frames = K/V frames.  Frame-sharded: q holds q_frames local frames from global frame q_frame0; k, v are the
-    all-gather (part-major) of kv_parts equal frame shards."""
+    all-gather (part-major) of kv_parts equal frame shards.  Pixel-sharded (after the frame<->pixel all-to-all): q, k, v and
+    the output all hold every frame of this rank's npix pixels, part-major (q_parts == kv_parts)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk2d(t, "temporal_attention." + n)
     out = empty(batch * (q_frames or frames) * npix, heads * dh, q)
@@ -207,7 +208,7 @@ def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, hea
     for i in range(8):
         a.kv_map[i] = km[i] if i < len(km) else 0
     a.scale = dh ** -0.5 if scale is None else scale
-    a.q_frames, a.q_frame0, a.kv_parts = q_frames, q_frame0, kv_parts
+    a.q_frames, a.q_frame0, a.kv_parts, a.q_parts = q_frames, q_frame0, kv_parts, q_parts
     e0 = _pb()
     capi.check(capi.lib().me_tattn(C.byref(a), _stream()), "me_tattn")
     _pe(e0, "tattn", 4.0 * batch * npix * heads * frames * frames * dh, 2.0 * 4 * batch * frames * npix * heads * dh)
@@ -284,6 +285,17 @@ def copy_rows(y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     _chk2d(y, "copy_rows.y")
     _chk2d(x, "copy_rows.x")
     capi.check(capi.lib().me_copy_rows(y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], _stream()), "me_copy_rows")
+    return y
+
+
+def copy_blocks(y: torch.Tensor, x: torch.Tensor, n0: int, n1: int, rows: int, *, ys0: int, ys1: int, xs0: int, xs1: int) -> torch.Tensor:
+    """n0 x n1 blocks of [rows, cols]: block (i, j) from row i*xs0 + j*xs1 of x to row i*ys0 + j*ys1 of y."""
+    _chk2d(y, "copy_blocks.y")
+    _chk2d(x, "copy_blocks.x")
+    if (n0 - 1) * xs0 + (n1 - 1) * xs1 + rows > x.shape[0] or (n0 - 1) * ys0 + (n1 - 1) * ys1 + rows > y.shape[0] or x.shape[1] > y.shape[1]:
+        raise ValueError("copy_blocks: block grid exceeds a tensor")
+    capi.check(capi.lib().me_copy_blocks(y.data_ptr(), y.stride(0), x.data_ptr(), x.stride(0), n0, n1, rows, x.shape[1], ys0, ys1, xs0, xs1, _stream()),
+               "me_copy_blocks")
     return y
 
 

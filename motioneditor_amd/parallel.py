@@ -4,9 +4,12 @@ reference become these exchanges (torch.distributed; backend "nccl" = RCCL over 
 
   * spatial attn1 (keys of the previous frame only, attention_2d.py:732-740 and the edited variant): a ONE-frame halo
     of the layer's K|V rows from the previous rank (point-to-point; `PrevFrameHalo`), 1 / f_loc of the all-gather;
-  * adapter sparse-causal attention (first / previous frame of an 8-frame chunk) and temporal attention (all earlier
-    frames): ONE all-gather of the layer's K|V rows; the attention kernels address the gathered tensor part-major
-    through their key-segment tables / kv_parts argument;
+  * adapter sparse-causal attention (first / previous frame of an 8-frame chunk): ONE all-gather of the layer's K|V rows; the
+    attention kernel addresses the gathered tensor part-major through its key-segment table;
+  * temporal attention (every pixel attends over all earlier frames; attention_2d.py:534-545): a frame<->pixel ALL-TO-ALL of the
+    fused q|k|v rows -- each rank then holds all frames of N/R pixels, runs me_tattn on them (q_parts = kv_parts = R) and a second
+    all-to-all returns the output rows to their frame owners: (R-1)/R * (3C + C) columns per row cross the links instead of
+    (R-1) * 2C for the all-gather (which stays as `temporal="gather"`, used when R does not divide the pixel count);
   * TemporalConv k=3: one-frame halos from both neighbours (point-to-point);
   * ResnetBlock2D / conv_norm_out GroupNorm (statistics span all frames): all-reduce of (sum, sum of squares).
 ControlNet, cross-attention, feed-forward, spatial convolutions, per-frame GroupNorm, CFG and DDIM are rank-local.
@@ -22,10 +25,10 @@ import torch.distributed as dist
 STATS = {}
 
 
-def _count(kind: str, t: torch.Tensor) -> None:
+def _count(kind: str, t: torch.Tensor, frac: float = 1.0) -> None:
     c = STATS.setdefault(kind, [0, 0])
     c[0] += 1
-    c[1] += t.numel() * t.element_size()
+    c[1] += int(t.numel() * t.element_size() * frac)
 
 
 def reset_stats() -> None:
@@ -39,7 +42,10 @@ def stats_summary(steps: int = 1) -> dict:
 
 
 class FrameShard:
-    def __init__(self, f_total: int, group=None):
+    def __init__(self, f_total: int, group=None, temporal: str = "a2a"):
+        if temporal not in ("a2a", "gather"):
+            raise ValueError("temporal must be 'a2a' or 'gather'")
+        self.temporal = temporal
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -84,6 +90,31 @@ class FrameShard:
 
     def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
         return self.finish_kv(self.start_kv(ext, B, npix, copy_rows))
+
+    # ---- frame <-> pixel all-to-all for temporal attention -----------------------------------------------
+    def pixel_sharded(self, npix: int) -> bool:
+        return self.temporal == "a2a" and self.world > 1 and npix % self.world == 0
+
+    def to_pixel_shards(self, x: torch.Tensor, BF: int, npix: int, copy_blocks) -> torch.Tensor:
+        """x: this rank's rows (b, local frame, pixel) [BF*npix, W].  Returns [R*BF*Ns, W], part-major rows
+        (source rank, b, local frame, pixel of THIS rank's slice), Ns = npix / R."""
+        R, Ns = self.world, npix // self.world
+        send = torch.empty((R * BF * Ns, x.shape[1]), dtype=x.dtype, device=x.device)
+        copy_blocks(send, x, R, BF, Ns, ys0=BF * Ns, ys1=Ns, xs0=Ns, xs1=npix)      # (bf, j, pl) -> (j, bf, pl)
+        recv = torch.empty_like(send)
+        _count("all_to_all(temporal q|k|v)", send, (R - 1) / R)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv
+
+    def to_frame_shards(self, o: torch.Tensor, BF: int, npix: int, copy_blocks) -> torch.Tensor:
+        """Inverse of to_pixel_shards for the attention output [R*BF*Ns, C] -> rows (b, local frame, pixel) [BF*npix, C]."""
+        R, Ns = self.world, npix // self.world
+        recv = torch.empty_like(o)
+        _count("all_to_all(temporal out)", o, (R - 1) / R)
+        dist.all_to_all_single(recv, o.contiguous(), group=self.group)
+        out = torch.empty((BF * npix, o.shape[1]), dtype=o.dtype, device=o.device)
+        copy_blocks(out, recv, R, BF, Ns, ys0=Ns, ys1=npix, xs0=BF * Ns, xs1=Ns)       # (j, bf, pl) -> (bf, j, pl)
+        return out
 
     def item(self, B: int, b: int, g: int) -> int:
         """kv item index of (batch row b, GLOBAL frame g) inside an all-gathered [world][B*f_loc items] tensor."""

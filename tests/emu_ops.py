@@ -152,7 +152,7 @@ def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=N
     return res
 
 
-def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1):
+def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1, q_parts=1):
     scale = dh ** -0.5 if scale is None else scale
     C = heads * dh
     km = list(kv_map) if kv_map is not None else list(range(batch))
@@ -163,12 +163,15 @@ def temporal_attention(q, k, v, *, heads, dh, batch, frames, npix, kv_map=None, 
         t = t.float()[:, :C].reshape(max(kv_parts, 1), batch, fpp, npix, heads, dh).permute(1, 0, 2, 3, 4, 5).reshape(batch, frames, npix, heads, dh)
         return t.permute(0, 2, 3, 1, 4)
 
-    qq = q.float()[:, :C].reshape(batch, qf, npix, heads, dh).permute(0, 2, 3, 1, 4)
+    qq = kv_shp(q) if q_parts > 1 else q.float()[:, :C].reshape(batch, qf, npix, heads, dh).permute(0, 2, 3, 1, 4)
     kk, vv = kv_shp(k)[km], kv_shp(v)[km]
     s = torch.einsum("bphid,bphjd->bphij", qq, kk) * scale
     gi = (q_frame0 if q_frames else 0) + torch.arange(qf)
     s = s + (torch.arange(frames)[None, :] > gi[:, None]).float() * -10000.0
     o = torch.einsum("bphij,bphjd->bphid", s.softmax(-1), vv)
+    if q_parts > 1:   # part-major output rows (part b fl p)
+        o = o.permute(0, 3, 1, 2, 4).reshape(batch, q_parts, fpp, npix, C).permute(1, 0, 2, 3, 4)
+        return o.reshape(batch * frames * npix, C).to(q.dtype)
     return o.permute(0, 3, 1, 2, 4).reshape(batch * qf * npix, C).to(q.dtype)
 
 
@@ -202,6 +205,13 @@ def axpy_rows(y, x, a_, alpha=1.0):
 
 def copy_rows(y, x):
     y.copy_(x)
+    return y
+
+
+def copy_blocks(y, x, n0, n1, rows, *, ys0, ys1, xs0, xs1):
+    for i in range(n0):
+        for j in range(n1):
+            y[i * ys0 + j * ys1:i * ys0 + j * ys1 + rows, :x.shape[1]] = x[i * xs0 + j * xs1:i * xs0 + j * xs1 + rows]
     return y
 
 

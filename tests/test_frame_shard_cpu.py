@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, f, out_path, hybrid=False):
+def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -60,14 +60,18 @@ def _worker(rank, world, port, f, out_path, hybrid=False):
             if rank % 2 == k:
                 shard_group = g
     parallel.reset_stats()
-    shard = parallel.FrameShard(f, shard_group)
+    shard = parallel.FrameShard(f, shard_group, temporal=temporal)
     lo, hi = shard.frame0, shard.frame0 + shard.f_loc
     ted.cur_step = sed.cur_step = step
     got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_group)
     assert (sed.cur_step, ted.cur_step, sed.cur_att_layer, ted.cur_att_layer) == (step + 1, step + 1, 0, 0)
     st = parallel.stats_summary()
-    # exchange budget of one step: 16 attn1 halos, 28 + 12 K|V all-gathers, 45 GroupNorm all-reduces
-    assert st["all_gather(K|V rows)"]["calls_per_step"] == 40 and st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
+    # exchange budget of one step: 16 attn1 halos, 45 GroupNorm all-reduces, 12 K|V all-gathers (adapter
+    # sparse-causal attention) and 28 temporal attentions: frame<->pixel all-to-all pairs, or K|V all-gathers where the
+    # pixel count of the level does not divide over the shards (the 1x1 level of these 8x8 latents) / under temporal="gather"
+    a2a = st.get("all_to_all(temporal q|k|v)", {"calls_per_step": 0})["calls_per_step"]
+    assert a2a == st.get("all_to_all(temporal out)", {"calls_per_step": 0})["calls_per_step"] == (24 if temporal == "a2a" else 0), st
+    assert st["all_gather(K|V rows)"]["calls_per_step"] + a2a == 40 and st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
     parts = [torch.empty_like(got) for _ in range(world)]
     dist.all_gather(parts, got)
     if hybrid:   # both members of a CFG pair hold the same frames and must agree exactly
@@ -83,11 +87,11 @@ def _worker(rank, world, port, f, out_path, hybrid=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("f", [16, 24])
-def test_frame_sharded_step_equals_single_process(tmp_path, f):
+@pytest.mark.parametrize("f,temporal", [(16, "a2a"), (24, "a2a"), (16, "gather")])
+def test_frame_sharded_step_equals_single_process(tmp_path, f, temporal):
     out = tmp_path / "r.pt"
-    port = 29700 + (os.getpid() % 2000) + f
-    mp.spawn(_worker, args=(2, port, f, str(out)), nprocs=2, join=True)
+    port = 29700 + (os.getpid() % 2000) + f + (3 if temporal == "gather" else 0)
+    mp.spawn(_worker, args=(2, port, f, str(out), False, temporal), nprocs=2, join=True)
     err = torch.load(out)["err"]
     assert err < 1e-4, err
 

@@ -395,6 +395,36 @@ def test_temporal_attention_sharded_queries_part_major_kv(ops, F, parts, qf, q0,
     check(got, emu.temporal_attention(q, kv[:, :C], kv[:, C:], **args), f"tattn sharded F={F} parts={parts}")
 
 
+@pytest.mark.parametrize("F,parts,dh,npix", [(16, 2, 40, 5), (24, 4, 80, 3), (24, 8, 160, 2)])
+def test_temporal_attention_pixel_sharded_part_major_q_and_kv(ops, F, parts, dh, npix):
+    """After the frame<->pixel all-to-all q, k, v and the output are all part-major (q_parts = kv_parts); the result must be
+    the plain temporal attention of the same rows put back in (b, frame, pixel) order."""
+    B, C, fpp = 4, 8 * dh, F // parts
+    qkv = rnd(parts * B * fpp * npix, 3 * C, seed=3)
+    args = dict(heads=8, dh=dh, batch=B, frames=F, npix=npix, kv_map=[0, 0, 2, 2])
+    got = ops.temporal_attention(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], kv_parts=parts, q_parts=parts, **args)
+    check(got, emu.temporal_attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], kv_parts=parts, q_parts=parts, **args), f"tattn a2a F={F} parts={parts}")
+    # same numbers as the unsharded kernel on the rows in (b, frame, pixel) order
+    plain = qkv.reshape(parts, B, fpp, npix, 3 * C).permute(1, 0, 2, 3, 4).reshape(B * F * npix, 3 * C).contiguous()
+    ref = ops.temporal_attention(cu(plain)[:, :C], cu(plain)[:, C:2 * C], cu(plain)[:, 2 * C:], **args)
+    ref = ref.reshape(B, parts, fpp, npix, C).permute(1, 0, 2, 3, 4).reshape(-1, C)
+    assert torch.equal(got, ref)
+
+
+def test_copy_blocks_is_the_frame_pixel_reorder(ops):
+    R, BF, Ns, W = 4, 6, 16, 48
+    x = rnd(BF * R * Ns, W + 8, seed=4)
+    y = torch.zeros(R * BF * Ns, W, dtype=torch.float16, device="cuda")
+    ops.copy_blocks(y, cu(x)[:, :W], R, BF, Ns, ys0=BF * Ns, ys1=Ns, xs0=Ns, xs1=R * Ns)
+    want = x[:, :W].reshape(BF, R, Ns, W).permute(1, 0, 2, 3).reshape(-1, W)
+    assert torch.equal(y.cpu(), want)
+    back = torch.zeros(BF * R * Ns, W, dtype=torch.float16, device="cuda")
+    ops.copy_blocks(back, y, R, BF, Ns, ys0=Ns, ys1=R * Ns, xs0=BF * Ns, xs1=Ns)
+    assert torch.equal(back.cpu(), x[:, :W])
+    with pytest.raises(ValueError):
+        ops.copy_blocks(back, y, R + 1, BF, Ns, ys0=Ns, ys1=R * Ns, xs0=BF * Ns, xs1=Ns)
+
+
 @pytest.mark.parametrize("C,f_loc,f_tot,frame0,chunk,npix,nb", [(320, 8, 24, 8, 24, 4, 2), (320, 12, 24, 12, 8, 4, 1), (640, 6, 24, 0, 8, 2, 2), (320, 6, 24, 18, 24, 3, 4)])
 def test_gemm_tconv_sharded_with_halos(ops, C, f_loc, f_tot, frame0, chunk, npix, nb):
     rows = nb * f_loc * npix
