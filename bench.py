@@ -13,8 +13,8 @@ weights of the SD-1.5 / ControlNet-openpose / adapter architectures (no checkpoi
 
 Multi-GPU: ONE clip, strong scaling (the metric is "24f x 512^2 at 1/2/4/8 MI355X"), one process per GPU, RCCL:
   --parallel auto (default)  N = 2: cfg (the two classifier-free-guidance halves; one all-gather of the noise prediction per
-                             step); N = 4, 8: cfg-frames = CFG pair x frame shards of N/2 ranks (K|V halo /
-                             all-gather, TemporalConv halos, GroupNorm-statistic all-reduce, each at batch 2); odd N: frames
+                             step); N = 4, 8: cfg-frames = CFG pair x frame shards of N/2 ranks (K|V halos,
+                             frame<->pixel all-to-all, TemporalConv halos, GroupNorm-statistic all-reduce, each at batch 2); odd N: frames
   --parallel frames          the frame axis over all N ranks (BASELINE configs[3]/[4] as written)
   --parallel cfg | replicas  CFG pairs x N/2 clips, or one independent clip per GPU (weak scaling, no data-path collective)
 value = clips * steps / max-over-ranks time.  `comm` in the JSON = data-path exchanges per step of rank 0.
@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--parallel", choices=["auto", "cfg", "replicas", "frames", "cfg-frames"], default="auto")
+    ap.add_argument("--shard-exchange", choices=["lean", "gather"], default="lean",
+                    help="frame sharding A/B: 'lean' = frame<->pixel all-to-all for temporal attention + two-frame halos for the adapter (default); "
+                         "'gather' = the K|V all-gathers BASELINE configs[3] names")
     ap.add_argument("--shapes", action="store_true", help="print the GEMM shapes with the largest time share to stderr")
     ap.add_argument("--editors", choices=["active", "inactive"], default="active",
                     help="secondary measurement: 'inactive' times the un-edited step (steps 0-3 of a 50-step run); the headline metric is 'active'")
@@ -279,7 +282,8 @@ def main():
     shard = None
     if n_shards > 1:
         from motioneditor_amd import parallel
-        shard = parallel.FrameShard(f, shard_group)               # f / n_shards frames per rank
+        lean = args.shard_exchange == "lean"
+        shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather")   # f / n_shards frames per rank
         assert shard.rank == shard_i
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (cfg), or for all ranks
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"], emu_dtype)
@@ -328,6 +332,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         lat = run_step(i0 + args.warmup + k, lat)
+    host_dt = time.perf_counter() - t0      # the host's share: time to ENQUEUE the steps (ctypes launches, torch allocator, table look-ups)
     sync()
     if dist_on:
         dist.barrier()
@@ -380,10 +385,11 @@ def main():
                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
                           "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
                           "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
-                          "hip_graph_replay": bool(use_graph), "parallel_mode": mode, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; the ControlNet restatement (diffusers, not in the reference tree) is unpinned"},
                "step_tflop_reference_semantics": round(tf_ref, 2), "step_tflop_is_baseline_md_figure": tf_exact,
                "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1)}
+        out["host_enqueue_ms_per_step"] = round(host_dt / args.steps * 1e3, 2)   # < ms_per_step: the GPU, not the Python launch loop, is the limit
         if comm is not None:
             out["comm"] = comm
         if prof:

@@ -167,15 +167,17 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
 
 
 def _temporal_attn(P: Packed, p: str, n: torch.Tensor, C: int, B: int, f: int, N: int, dh: int, shard, editor=None, place: str = "") -> torch.Tensor:
-    """Causal attention over frames of the projections of `n` (rows (b, local frame, pixel)); returns the attention output
-    in the same row order.  Frame-sharded: the fused q|k|v rows go through the frame<->pixel all-to-all, so every rank
-    attends over all frames of its pixel slice (parallel.FrameShard.to_pixel_shards), or K|V is all-gathered."""
+    """Causal attention over frames of the projections of `n` (the normed stream, rows (b, local frame, pixel)); returns the
+    attention output in the same row order.  Frame-sharded: the rows of `n` go through the frame<->pixel all-to-all BEFORE
+    the q|k|v projection (a row-wise GEMM commutes with the row exchange, so C columns travel instead of 3C), every rank
+    projects and attends over all frames of its pixel slice, and a second all-to-all returns the output rows
+    (parallel.FrameShard.to_pixel_shards); or K|V is all-gathered (shard.temporal == "gather")."""
     def go(tc):
         return editor(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if editor is not None else tc.run()
     if shard is not None and shard.pixel_sharded(N):
-        qkv = ops.gemm(n, P.fused([p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]))
-        r = shard.to_pixel_shards(qkv, B * f, N, ops.copy_blocks)
-        a = go(TemporalCall(r[:, :C], r[:, C:2 * C], r[:, 2 * C:], B, shard.f_total, N // shard.world, dh, None, shard.world))
+        r = shard.to_pixel_shards(n, B * f, N, ops.copy_blocks)
+        qkv = ops.gemm(r, P.fused([p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]))
+        a = go(TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, shard.f_total, N // shard.world, dh, None, shard.world))
         return shard.to_frame_shards(a, B * f, N, ops.copy_blocks)
     q, k, v = _qkv(P, p, n, C, shard)
     return go(TemporalCall(q, k, v, B, f, N, dh, shard))
@@ -290,8 +292,9 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int
     hc = _tconv(P, p + ".block1", tx, x, ADAPTER_CHUNK, shard, act=1)
     hc = ops.gemm(hc, P.mat(p + ".block2.weight"), bias=P.vec(p + ".block2.bias"), res=t)
     # sparse-causal self attention inside chunks of 8 frames
-    q_, k_, v_ = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, shard)
-    a = AttnCall(q_, k_, v_, x.B, x.f, x.N, dh, x.N, False, shard).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev, shard))
+    sh2 = shard.chunk_view(ADAPTER_CHUNK) if (shard is not None and shard.adapter == "halo") else shard   # two halo frames, not the all-gather
+    q_, k_, v_ = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, sh2, x.B, x.N)
+    a = AttnCall(q_, k_, v_, x.B, x.f, x.N, dh, x.N, False, sh2).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev, sh2))
     a = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
     # pose x UNet-feature cross attention, per frame

@@ -4,12 +4,13 @@ reference become these exchanges (torch.distributed; backend "nccl" = RCCL over 
 
   * spatial attn1 (keys of the previous frame only, attention_2d.py:732-740 and the edited variant): a ONE-frame halo
     of the layer's K|V rows from the previous rank (point-to-point; `PrevFrameHalo`), 1 / f_loc of the all-gather;
-  * adapter sparse-causal attention (first / previous frame of an 8-frame chunk): ONE all-gather of the layer's K|V rows; the
-    attention kernel addresses the gathered tensor part-major through its key-segment table;
+  * adapter sparse-causal attention (first / previous frame of an 8-frame chunk): at most TWO remote frames of the layer's
+    K|V rows, point-to-point (`ChunkHalo`; the all-gather `FrameShard.start_kv` remains for `adapter="gather"`);
   * temporal attention (every pixel attends over all earlier frames; attention_2d.py:534-545): a frame<->pixel ALL-TO-ALL of the
-    fused q|k|v rows -- each rank then holds all frames of N/R pixels, runs me_tattn on them (q_parts = kv_parts = R) and a second
-    all-to-all returns the output rows to their frame owners: (R-1)/R * (3C + C) columns per row cross the links instead of
-    (R-1) * 2C for the all-gather (which stays as `temporal="gather"`, used when R does not divide the pixel count);
+    normed input rows -- each rank then holds all frames of N/R pixels, projects q|k|v there (a row-wise GEMM commutes with the
+    row exchange), runs me_tattn on them (q_parts = kv_parts = R) and a second all-to-all returns the output rows to their
+    frame owners: (R-1)/R * 2C columns per row cross the links instead of (R-1) * 2C for the all-gather (which stays as
+    `temporal="gather"`, used when R does not divide the pixel count);
   * TemporalConv k=3: one-frame halos from both neighbours (point-to-point);
   * ResnetBlock2D / conv_norm_out GroupNorm (statistics span all frames): all-reduce of (sum, sum of squares).
 ControlNet, cross-attention, feed-forward, spatial convolutions, per-frame GroupNorm, CFG and DDIM are rank-local.
@@ -42,10 +43,10 @@ def stats_summary(steps: int = 1) -> dict:
 
 
 class FrameShard:
-    def __init__(self, f_total: int, group=None, temporal: str = "a2a"):
-        if temporal not in ("a2a", "gather"):
-            raise ValueError("temporal must be 'a2a' or 'gather'")
-        self.temporal = temporal
+    def __init__(self, f_total: int, group=None, temporal: str = "a2a", adapter: str = "halo"):
+        if temporal not in ("a2a", "gather") or adapter not in ("halo", "gather"):
+            raise ValueError("temporal must be 'a2a' or 'gather', adapter 'halo' or 'gather'")
+        self.temporal, self.adapter = temporal, adapter
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
@@ -102,7 +103,7 @@ class FrameShard:
         send = torch.empty((R * BF * Ns, x.shape[1]), dtype=x.dtype, device=x.device)
         copy_blocks(send, x, R, BF, Ns, ys0=BF * Ns, ys1=Ns, xs0=Ns, xs1=npix)      # (bf, j, pl) -> (j, bf, pl)
         recv = torch.empty_like(send)
-        _count("all_to_all(temporal q|k|v)", send, (R - 1) / R)
+        _count("all_to_all(temporal in)", send, (R - 1) / R)
         dist.all_to_all_single(recv, send, group=self.group)
         return recv
 
@@ -128,6 +129,11 @@ class FrameShard:
     def prev_frame_view(self) -> "PrevFrameHalo":
         """The view attn1 uses: only the previous rank's LAST frame is fetched."""
         return PrevFrameHalo(self)
+
+    def chunk_view(self, chunk: int) -> "ChunkHalo":
+        """The view the adapter's sparse-causal attention uses: the first frame of the chunk this rank's range starts in and
+        the frame before the range -- at most two remote frames."""
+        return ChunkHalo(self, chunk)
 
     # ---- one-frame halos for the temporal convolutions --------------------------------------------------
     def exchange_halos(self, x_ext: torch.Tensor, B: int, npix: int, copy_rows) -> tuple:
@@ -212,3 +218,86 @@ class PrevFrameHalo:
         ext, loc = self.kv_buffer(kv.shape[0], kv.shape[1], B, npix, kv)
         copy_rows(loc, kv)
         return self.complete_kv(ext, B, npix, copy_rows)
+
+
+class ChunkHalo:
+    """K|V of this rank's frames preceded by TWO halo blocks: rows = [B items: first frame of the chunk the rank's range starts in |
+    B items: the frame before the range | B * f_loc local items].  The adapter's sparse-causal attention
+    (controlnet_adapter.py:352-361: keys = [first frame of the 8-frame chunk | previous frame in the chunk]) reads nothing else,
+    so at most two remote frames replace the all-gather of every rank's K|V.  The chunk's first frame may live several ranks
+    back (f_loc < chunk): its owner sends it point-to-point to every rank whose range starts inside that chunk."""
+
+    layout = "chunkhalo"
+
+    def __init__(self, shard: FrameShard, chunk: int):
+        self.s, self.chunk = shard, chunk
+        self.world, self.rank, self.f_loc, self.f_total, self.frame0 = shard.world, shard.rank, shard.f_loc, shard.f_total, shard.frame0
+        self.first, self.prev = self.needs(self.rank)
+
+    def needs(self, r: int):
+        """(global frame of the remote chunk-first frame or None, global frame of the remote previous frame or None) of rank r.
+        A range that starts ON a chunk boundary needs neither; one that starts on the chunk's second frame needs the first only
+        (its [first | previous] keys coincide, segments.first_prev_chunked)."""
+        f0 = r * self.f_loc
+        m = f0 % self.chunk
+        return (f0 - m if m >= 1 else None, f0 - 1 if m >= 2 else None)
+
+    def item(self, B: int, b: int, g: int) -> int:
+        if self.frame0 <= g < self.frame0 + self.f_loc:
+            return 2 * B + b * self.f_loc + (g - self.frame0)
+        if g == self.first:
+            return b
+        if g == self.prev:
+            return B + b
+        raise IndexError(f"frame {g} is neither local to rank {self.rank} nor one of its two halo frames")
+
+    def kv_buffer(self, rows: int, cols: int, B: int, npix: int, like: torch.Tensor):
+        ext = torch.empty((2 * B * npix + rows, cols), dtype=like.dtype, device=like.device)
+        return ext, ext[2 * B * npix:]
+
+    def start_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows):
+        s, hb, fl = self.s, B * npix, self.f_loc
+        kv = ext[2 * hb:]
+
+        def frame_rows(dst, fl_idx):   # the rows of local frame fl_idx of every batch row -> dst [B*npix, cols]
+            for b in range(B):
+                copy_rows(dst[b * npix:(b + 1) * npix], kv[(b * fl + fl_idx) * npix:(b * fl + fl_idx + 1) * npix])
+
+        ops_, keep = [], []
+        for r in range(self.world):          # what this rank owes the others (every rank derives the same schedule)
+            if r == self.rank:
+                continue
+            first, prev = self.needs(r)
+            mine = [g for g in (first, prev) if g is not None and g // fl == self.rank]
+            if not mine:
+                continue
+            buf = torch.empty((len(mine) * hb, kv.shape[1]), dtype=kv.dtype, device=kv.device)
+            for i, g in enumerate(mine):
+                frame_rows(buf[i * hb:(i + 1) * hb], g - self.frame0)
+            keep.append(buf)
+            _count("p2p(adapter K|V halo)", buf)
+            ops_.append(dist.P2POp(dist.isend, buf, s._ranks[r], s.group))
+        of = self.first // fl if self.first is not None else None
+        op = self.prev // fl if self.prev is not None else None
+        if of is not None and of == op:      # both frames from the same rank: one message [first | prev]
+            ops_.append(dist.P2POp(dist.irecv, ext[:2 * hb], s._ranks[of], s.group))
+        else:
+            if of is not None:
+                ops_.append(dist.P2POp(dist.irecv, ext[:hb], s._ranks[of], s.group))
+            if op is not None:
+                ops_.append(dist.P2POp(dist.irecv, ext[hb:2 * hb], s._ranks[op], s.group))
+        if of is None:
+            copy_rows(ext[:hb], kv[:hb])          # never addressed; keep it finite
+        if op is None:
+            copy_rows(ext[hb:2 * hb], kv[:hb])
+        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
+        return (reqs, ext, keep)
+
+    def finish_kv(self, handle) -> torch.Tensor:
+        reqs, ext, _keep = handle
+        for r in reqs:
+            r.wait()
+        return ext
+
+    def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
+        return self.finish_kv(self.start_kv(ext, B, npix, copy_rows))

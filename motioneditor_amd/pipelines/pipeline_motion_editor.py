@@ -86,10 +86,21 @@ class MotionEditorPipeline:
             raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
         return (latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma).contiguous()
 
-    # ---- reference :418-459 (tensor branch only: the harness passes a tensor skeleton) ----
+    # ---- reference :418-459: a tensor, a PIL image, or a list of either ----
     def prepare_image(self, image, width, height, batch_size, num_images_per_prompt, device, dtype, do_classifier_free_guidance):
         if not isinstance(image, torch.Tensor):
-            raise NotImplementedError("PIL inputs are data-prep (out of scope); pass a float tensor in [0,1]")
+            import numpy as np
+            import PIL.Image
+            if isinstance(image, PIL.Image.Image):
+                image = [image]
+            if isinstance(image[0], PIL.Image.Image):     # RGB, Lanczos resize to (width, height), [0, 1], NCHW (:423-440)
+                lanczos = PIL.Image.Resampling.LANCZOS if hasattr(PIL.Image, "Resampling") else PIL.Image.LANCZOS
+                arr = np.stack([np.asarray(im.convert("RGB").resize((width, height), resample=lanczos)) for im in image])
+                image = torch.from_numpy((arr.astype(np.float32) / 255.0).transpose(0, 3, 1, 2).copy())
+            elif isinstance(image[0], torch.Tensor):
+                image = torch.cat(list(image), dim=0)
+            else:
+                raise TypeError(f"prepare_image: unsupported image type {type(image[0])}")
         repeat_by = batch_size if image.shape[0] == 1 else num_images_per_prompt
         image = image.repeat_interleave(repeat_by, dim=0).to(device=device, dtype=dtype)
         if do_classifier_free_guidance:

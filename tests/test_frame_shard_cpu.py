@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a"):
+def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a", adapter="halo"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -60,7 +60,7 @@ def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a"):
             if rank % 2 == k:
                 shard_group = g
     parallel.reset_stats()
-    shard = parallel.FrameShard(f, shard_group, temporal=temporal)
+    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter)
     lo, hi = shard.frame0, shard.frame0 + shard.f_loc
     ted.cur_step = sed.cur_step = step
     got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_group)
@@ -69,9 +69,13 @@ def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a"):
     # exchange budget of one step: 16 attn1 halos, 45 GroupNorm all-reduces, 12 K|V all-gathers (adapter
     # sparse-causal attention) and 28 temporal attentions: frame<->pixel all-to-all pairs, or K|V all-gathers where the
     # pixel count of the level does not divide over the shards (the 1x1 level of these 8x8 latents) / under temporal="gather"
-    a2a = st.get("all_to_all(temporal q|k|v)", {"calls_per_step": 0})["calls_per_step"]
+    a2a = st.get("all_to_all(temporal in)", {"calls_per_step": 0})["calls_per_step"]
     assert a2a == st.get("all_to_all(temporal out)", {"calls_per_step": 0})["calls_per_step"] == (24 if temporal == "a2a" else 0), st
-    assert st["all_gather(K|V rows)"]["calls_per_step"] + a2a == 40 and st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
+    halo = 12 if adapter == "halo" else 0   # the adapter's 12 sparse-causal attentions fetch <= 2 halo frames instead of the all-gather
+    assert st["all_gather(K|V rows)"]["calls_per_step"] + a2a + halo == 40 and st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
+    if adapter == "halo":
+        sends = sum(1 for r in range(shard.world) if r != shard.rank and any(g is not None and g // shard.f_loc == shard.rank for g in shard.chunk_view(8).needs(r)))
+        assert st.get("p2p(adapter K|V halo)", {"calls_per_step": 0})["calls_per_step"] == 12 * sends, st
     parts = [torch.empty_like(got) for _ in range(world)]
     dist.all_gather(parts, got)
     if hybrid:   # both members of a CFG pair hold the same frames and must agree exactly
@@ -87,11 +91,11 @@ def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("f,temporal", [(16, "a2a"), (24, "a2a"), (16, "gather")])
+@pytest.mark.parametrize("f,temporal", [(16, "a2a"), (24, "a2a"), (24, "gather")])
 def test_frame_sharded_step_equals_single_process(tmp_path, f, temporal):
     out = tmp_path / "r.pt"
     port = 29700 + (os.getpid() % 2000) + f + (3 if temporal == "gather" else 0)
-    mp.spawn(_worker, args=(2, port, f, str(out), False, temporal), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, f, str(out), False, temporal, "halo" if temporal == "a2a" else "gather"), nprocs=2, join=True)
     err = torch.load(out)["err"]
     assert err < 1e-4, err
 
@@ -144,3 +148,45 @@ def test_prev_frame_halo_view_indexing_and_segment_tables():
     a, _ = segments.prev_cur(B, f_loc, torch.device("cpu"), g)
     h, _ = segments.prev_cur(B, f_loc, torch.device("cpu"), PrevFrameHalo(SimpleNamespace(world=3, rank=1, f_loc=f_loc, f_total=12, frame0=f_loc, group=None, _ranks=[0, 1, 2])))
     assert a.tolist() != h.tolist()
+
+
+def _chunk_halo_worker(rank, world, port, f, chunk):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_ops
+    from motioneditor_amd import parallel, segments
+    B, npix, cols = 2, 3, 8
+    sh = parallel.FrameShard(f, None).chunk_view(chunk)
+
+    def rows_of(b, g):   # the value pattern of K|V rows (b, global frame g)
+        return (torch.arange(npix * cols, dtype=torch.float32).reshape(npix, cols) + 1000 * g + 100000 * b).to(torch.float16)
+
+    ext, loc = sh.kv_buffer(B * sh.f_loc * npix, cols, B, npix, torch.zeros(1, dtype=torch.float16))
+    for b in range(B):
+        for i in range(sh.f_loc):
+            loc[(b * sh.f_loc + i) * npix:(b * sh.f_loc + i + 1) * npix] = rows_of(b, sh.frame0 + i)
+    kv = sh.complete_kv(ext, B, npix, emu_ops.copy_rows)
+    item, mode = segments.first_prev_chunked(B, sh.f_loc, chunk, torch.device("cpu"), sh)
+    item = item.reshape(B * sh.f_loc, -1)
+    for b in range(B):
+        for i in range(sh.f_loc):
+            g = sh.frame0 + i
+            c0 = g - g % chunk
+            want = [c0] if g % chunk <= 1 else [c0, g - 1]
+            got = [int(v) for v in item[b * sh.f_loc + i] if v >= 0]
+            assert len(got) == len(want), (rank, g, got, want)
+            for it, gw in zip(got, want):
+                assert torch.equal(kv[it * npix:(it + 1) * npix], rows_of(b, gw)), (rank, b, g, gw)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,f,chunk", [(8, 24, 8), (4, 24, 8), (8, 16, 8), (3, 24, 8)])
+def test_chunk_halo_fetches_first_and_previous_frames_from_any_rank(world, f, chunk):
+    """f_loc = 3 puts the chunk's first frame up to two ranks back and the previous frame on the neighbour: every key item the
+    adapter's [first | previous] table names must hold that frame's rows after the point-to-point exchange."""
+    port = 29700 + (os.getpid() % 2000) + 100 + world + f
+    mp.spawn(_chunk_halo_worker, args=(world, port, f, chunk), nprocs=world, join=True)

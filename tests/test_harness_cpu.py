@@ -63,3 +63,25 @@ def test_foreign_scheduler_config_is_adopted_and_bad_ones_rejected():
         raise AssertionError("scheduler without a config accepted")
     except TypeError:
         pass
+
+
+def test_prepare_image_accepts_pil_and_tensor_lists_like_the_reference():
+    """pipeline_motion_editor.py:418-459: PIL -> RGB -> Lanczos resize -> [0,1] NCHW; lists of tensors are concatenated;
+    one image is repeated over the batch; classifier-free guidance doubles the batch."""
+    import numpy as np
+    import PIL.Image
+    from motioneditor_amd.pipelines.pipeline_motion_editor import MotionEditorPipeline
+    pipe = MotionEditorPipeline.__new__(MotionEditorPipeline)
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (24, 20, 3), dtype=np.uint8)
+    ims = [PIL.Image.fromarray(a), PIL.Image.fromarray(a[::-1].copy()).convert("L")]
+    out = pipe.prepare_image(ims, 16, 8, 2, 1, "cpu", torch.float32, True)
+    assert out.shape == (4, 3, 8, 16) and out.dtype == torch.float32 and 0.0 <= float(out.min()) and float(out.max()) <= 1.0
+    want0 = np.asarray(ims[0].convert("RGB").resize((16, 8), resample=PIL.Image.Resampling.LANCZOS)).astype(np.float32) / 255.0
+    assert torch.equal(out[0], torch.from_numpy(want0.transpose(2, 0, 1))) and torch.equal(out[:2], out[2:])
+    assert torch.equal(out[1, 0], out[1, 1]) and torch.equal(out[1, 1], out[1, 2])       # the "L" image became grey RGB
+    one = pipe.prepare_image(ims[0], 16, 8, 3, 1, "cpu", torch.float16, False)
+    assert one.shape == (3, 3, 8, 16) and one.dtype == torch.float16 and torch.equal(one[0], one[2])
+    ts = [torch.rand(1, 3, 8, 16), torch.rand(1, 3, 8, 16)]
+    cat = pipe.prepare_image(ts, 16, 8, 2, 1, "cpu", torch.float32, False)
+    assert torch.equal(cat, torch.cat(ts))
