@@ -18,7 +18,15 @@ from .capi import AttnArgs, ConvSmallArgs, GemmArgs, GroupNormArgs, LayerNormArg
 F16 = torch.float16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream() -> int:
+    """hipStream_t of torch's current stream.  The raw accessors cost ~0.3 us; torch.cuda.current_stream() builds a Stream
+    object per call (~8 us, a third of the host's enqueue time of a step at ~1100 launches)."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
