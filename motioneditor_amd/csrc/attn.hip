@@ -454,13 +454,16 @@ __device__ __forceinline__ void dma16_masked(unsigned lds_dst, const char* base,
       : "memory");
 }
 
-template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB>
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD>
 __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args a) {
+  static_assert(!FOLD || DH % 32 != 0, "FOLD needs a spare k-slot in the last QK^T step");
   constexpr int NTHR = 64 * NW;
   constexpr int D32 = (DH + 31) / 32;
   constexpr int DT = (DH + 15) / 16;
   constexpr int CKR = DH / 8;                         // real 16-byte chunks per K / V row
-  constexpr int CK = (CKR & 1) ? CKR : CKR + 1;       // K row pitch in chunks (odd: 16 rows x one chunk column hit distinct 16-byte slots)
+  // K row pitch in chunks (odd: 16 rows x one chunk column hit distinct 16-byte slots); FOLD adds the ones chunk CKR
+  constexpr int CK = FOLD ? ((CKR + 1) | 1) : ((CKR & 1) ? CKR : CKR + 1);
+  constexpr int GS = CKR - (D32 - 1) * 4;             // FOLD: lane group whose last-step Q fragment starts at k-slot DH
   constexpr bool ONES = DT * 16 > DH;                 // spare V^T rows: row DH = all ones -> the PV MFMA also produces the softmax denominator
   constexpr int CV = DH == 40 ? 6 : (DH == 80 ? 10 : 22);   // V row pitch in chunks (8 consecutive rows x 32 B on distinct banks)
   constexpr int KPB = CK * 16, VPB = CV * 16;         // pitches in bytes
@@ -498,22 +501,35 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     for (int i = tid; i < NBUF * NSUB * KT; i += NTHR)
       *reinterpret_cast<f16*>(smem + (i / KT) * SUB + KBYTES + (i % KT) * VPB + DH * 2) = (f16)1.f;
   }
+  if constexpr (FOLD) {   // K column DH = 1: the Q fragment's k-slot DH then carries -(reference offset) into every logit
+    for (int i = tid; i < NBUF * NSUB * KT; i += NTHR)
+      *reinterpret_cast<f16*>(smem + (i / KT) * SUB + (i % KT) * KPB + DH * 2) = (f16)1.f;
+  }
+  const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
-  // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8], zero beyond dh
+  // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8], zero beyond dh.
+  // scaled: pre-multiplied by c, so the MFMA result is the logit in log2 units and needs no VALU pass before exp2.
   f16x8 fq[QT][D32];
   int qrow[QT];
+  auto load_q = [&](auto scaled_c) {
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
-    qrow[qt] = q < a.nq ? item * a.nq + q : -1;
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
+      qrow[qt] = q < a.nq ? item * a.nq + q : -1;
 #pragma unroll
-    for (int ks = 0; ks < D32; ++ks) {
-      const int d = ks * 32 + g * 8;
-      U128 u;
-      u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
-      fq[qt][ks] = u.h;
+      for (int ks = 0; ks < D32; ++ks) {
+        const int d = ks * 32 + g * 8;
+        U128 u;
+        u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
+        if constexpr (decltype(scaled_c)::value) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) u.e[e] = (f16)((float)u.e[e] * c);
+        }
+        fq[qt][ks] = u.h;
+      }
     }
-  }
+  };
+  load_q(std::integral_constant<bool, FOLD>{});
 
   const int ntk = (a.nk + KT - 1) / KT;          // 64-key sub-tiles per segment
   const int nst = (ntk + NSUB - 1) / NSUB;        // stages per segment
@@ -533,7 +549,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     }
   }
   const int T = nvalid * nst;                     // stages in total
-  const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
   // DMA slots: instruction q = wave + NW i covers image bytes [q * 1024, +1024) of a sub-tile (K rows first, then V rows);
   // lane -> chunk q * 64 + lane of that operand.  off[i] = byte offset of the lane's source chunk from the sub-tile's base
@@ -595,151 +610,257 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 
   f32x4 o[QT][DT];
   float mrun[QT], lrun[QT];
+  auto reset_acc = [&]() {
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    mrun[qt] = NEG_BIG;
-    lrun[qt] = 0.f;
+    for (int qt = 0; qt < QT; ++qt) {
+      mrun[qt] = NEG_BIG;
+      lrun[qt] = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
+      for (int dt = 0; dt < DT; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto prime = [&]() {   // load cursor to the first stage, fetch it, wait for it
+    seg_l = st_l = 0;
+    if (T > 0) {
+      seg_base();
+      dma_stage(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  reset_acc();
   __syncthreads();   // LDS image initialised before the first DMA lands
-  if (T > 0) {
-    seg_base();
-    dma_stage(0);
+  prime();
+
+  // FOLD (phase A, the speculative fast path): the reference offset m~ of a query (mrun) rides in k-slot DH of its Q fragment,
+  // against the ones column of K: the QK^T MFMA then delivers  s * c - m~  directly and P = 2^(that), no VALU pass between.
+  // m~ = ceil(row maximum over the FIRST 64-key tile), an integer (exact in fp16), and stays fixed: a softmax is exact for
+  // any offset as long as P stays inside fp16's range.  Keys lighter than the first tile's maximum underflow exactly as
+  // they do under a running maximum; a key more than 2^15 x HEAVIER would overflow, so every P's fp16 bit pattern is
+  // folded into a running per-lane maximum (`trip`, one v_pk_max_u16 per P register) and checked ONCE, after the sweep: if
+  // any lane of the block saw P >= 2^15, the block discards phase A and recomputes with the classic online softmax
+  // (phase B, below).  Conversions round towards zero, so such a P saturates at 65504 -- finite -- and phase A can
+  // neither produce inf / NaN nor fault while it runs to its end.
+  auto set_ref = [&](int qt, float m) {
+    const f16 hm = (f16)(-fminf(fmaxf(m, -2000.f), 2000.f));
+    if (g == GS) fq[qt][D32 - 1][0] = hm;
+    mrun[qt] = -(float)hm;
+  };
+  if constexpr (FOLD) {
+    if (T > 0) {   // initial offset = ceil(row maximum over the first 64-key tile): one extra QK^T per block, no P, no PV
+      const char* sK = smem;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 s0[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < D32; ++ks)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            s0[t] = mfma16(*reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KPB + (ks * 4 + g) * 16), fq[qt][ks], s0[t]);
+        float mr = NEG_BIG;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, (g * 4 + t * 16 + r < a.nk) ? s0[t][r] : NEG_BIG);
+        mr = xor32_max(xor16_max(mr));
+        set_ref(qt, ceilf(mr));
+      }
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
 
   using BT = std::integral_constant<bool, true>;
   using BF = std::integral_constant<bool, false>;
-  auto tile = [&](auto full_c, const char* st, int kt) {
+  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+  u16x2 trip = {0, 0};
+  auto tile = [&](auto full_c, auto fold_c, const char* st, int kt) {
     constexpr bool FULL = decltype(full_c)::value;
+    constexpr bool FOLDT = decltype(fold_c)::value;
     const char* sK = st;
     const char* sV = st + KBYTES;
     const int kbase = kt * KT + g * 4;  // + t*16 + r
 
     // ---- S^T = K Q^T ----
     f32x4 s[QT][4];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < D32; ++ks) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KPB + (ks * 4 + g) * 16);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
-      }
-    }
-
-    // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
     f16x8 pf[QT][2];
+    auto qk = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D32; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f16x8 fk = *reinterpret_cast<const f16x8*>(sK + (t * 16 + l15) * KPB + (ks * 4 + g) * 16);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
+        }
+      }
       if constexpr (!FULL) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kbase + t * 16 + r >= a.nk) s[qt][t][r] = NEG_BIG;   // raw logit; c < 1 keeps NEG_BIG * c finite
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kbase + t * 16 + r >= a.nk) s[qt][t][r] = NEG_BIG;   // raw logit; c < 1 keeps NEG_BIG * c finite
       }
-      float mr = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
-      mr = fmaxf(fmaxf(mr, s[qt][0][3]), s[qt][1][0]);
-      mr = fmaxf(fmaxf(mr, s[qt][1][1]), s[qt][1][2]);
-      mr = fmaxf(fmaxf(mr, s[qt][1][3]), s[qt][2][0]);
-      mr = fmaxf(fmaxf(mr, s[qt][2][1]), s[qt][2][2]);
-      mr = fmaxf(fmaxf(mr, s[qt][2][3]), s[qt][3][0]);
-      mr = fmaxf(fmaxf(mr, s[qt][3][1]), s[qt][3][2]);
-      mr = fmaxf(mr, s[qt][3][3]);
-      mr = xor32_max(xor16_max(mr));
-      const float mnew = fmaxf(mrun[qt], mr * c);
-      const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
-      mrun[qt] = mnew;
-      float p[4][4];
-      float psum = 0.f;
-      const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew};
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          const f32x2 sv = {s[qt][t][2 * h2], s[qt][t][2 * h2 + 1]};
-          const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
-          p[t][2 * h2] = __builtin_amdgcn_exp2f(x[0]);
-          p[t][2 * h2 + 1] = __builtin_amdgcn_exp2f(x[1]);
-          if constexpr (!ONES) psum += p[t][2 * h2] + p[t][2 * h2 + 1];
-        }
-      if constexpr (!ONES) lrun[qt] = lrun[qt] * alpha + psum;
-      // rescale only when some query of the wave saw its running max move (exact: alpha == 1 otherwise)
-      if (__builtin_amdgcn_readfirstlane(__any(alpha != 1.0f))) {
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+    };
+    auto pv = [&]() {
+      // ---- O^T += V^T P^T: operand A k-slot (g, j) = key kk*32 + (j>>2)*16 + g*4 + (j&3), as P^T above ----
+      const unsigned vlane = (unsigned)(size_t)(sV + (g * 4 + (l15 >> 2)) * VPB + (l15 & 3) * 8);
+      {
+        // transposed reads one d-block ahead of the MFMAs that consume them
+        uint2 rv[2][4];   // [parity of dt][kk*2 + j]
+        auto issue = [&](auto dt_c) {
+          constexpr int dt = decltype(dt_c)::value;
+          rv[dt & 1][0] = lds_tr16<(0) * VPB + dt * 32>(vlane);
+          rv[dt & 1][1] = lds_tr16<(16) * VPB + dt * 32>(vlane);
+          rv[dt & 1][2] = lds_tr16<(32) * VPB + dt * 32>(vlane);
+          rv[dt & 1][3] = lds_tr16<(48) * VPB + dt * 32>(vlane);
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for(std::make_integer_sequence<int, DT>{}, [&](auto dt_c) {
+          constexpr int dt = decltype(dt_c)::value;
+          if constexpr (dt + 1 < DT) {
+            issue(std::integral_constant<int, dt + 1>{});
+            lds_wait<4>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+          } else {
+            lds_wait<0>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+          }
+  #pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            union { uint2 u[2]; f16x8 v; } fv;
+            fv.u[0] = rv[dt & 1][kk * 2];
+            fv.u[1] = rv[dt & 1][kk * 2 + 1];
+  #pragma unroll
+            for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.v, pf[qt][kk], o[qt][dt]);
+          }
+        });
       }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        union { f16x2 h[4]; f16x8 v; } f;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-          f.h[h2] = __builtin_convertvector((f32x2){p[2 * kk][2 * h2], p[2 * kk][2 * h2 + 1]}, f16x2);
-          f.h[2 + h2] = __builtin_convertvector((f32x2){p[2 * kk + 1][2 * h2], p[2 * kk + 1][2 * h2 + 1]}, f16x2);
-        }
-        pf[qt][kk] = f.v;
-      }
-    }
+    };
 
-    // ---- O^T += V^T P^T: operand A k-slot (g, j) = key kk*32 + (j>>2)*16 + g*4 + (j&3), as P^T above ----
-    const unsigned vlane = (unsigned)(size_t)(sV + (g * 4 + (l15 >> 2)) * VPB + (l15 & 3) * 8);
-    {
-      // transposed reads one d-block ahead of the MFMAs that consume them
-      uint2 rv[2][4];   // [parity of dt][kk*2 + j]
-      auto issue = [&](auto dt_c) {
-        constexpr int dt = decltype(dt_c)::value;
-        rv[dt & 1][0] = lds_tr16<(0) * VPB + dt * 32>(vlane);
-        rv[dt & 1][1] = lds_tr16<(16) * VPB + dt * 32>(vlane);
-        rv[dt & 1][2] = lds_tr16<(32) * VPB + dt * 32>(vlane);
-        rv[dt & 1][3] = lds_tr16<(48) * VPB + dt * 32>(vlane);
-      };
-      issue(std::integral_constant<int, 0>{});
-      static_for(std::make_integer_sequence<int, DT>{}, [&](auto dt_c) {
-        constexpr int dt = decltype(dt_c)::value;
-        if constexpr (dt + 1 < DT) {
-          issue(std::integral_constant<int, dt + 1>{});
-          lds_wait<4>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
-        } else {
-          lds_wait<0>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
-        }
+    if constexpr (FOLDT) {
+      // P = 2^(MFMA result), rounded TOWARDS ZERO to fp16 (the denominator is the sum of the same rounded values, so the
+      // bias cancels); P >= 0, so the unsigned order of the bit patterns is the value order.
+      union PW { f16x8 v; u16x2 w[4]; };
+      qk();
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float psum = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          union { uint2 u[2]; f16x8 v; } fv;
-          fv.u[0] = rv[dt & 1][kk * 2];
-          fv.u[1] = rv[dt & 1][kk * 2 + 1];
+          union { f16x2 h[4]; f16x8 v; } f;
 #pragma unroll
-          for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.v, pf[qt][kk], o[qt][dt]);
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const float p0 = __builtin_amdgcn_exp2f(s[qt][2 * kk][2 * h2]), p1 = __builtin_amdgcn_exp2f(s[qt][2 * kk][2 * h2 + 1]);
+            const float p2 = __builtin_amdgcn_exp2f(s[qt][2 * kk + 1][2 * h2]), p3 = __builtin_amdgcn_exp2f(s[qt][2 * kk + 1][2 * h2 + 1]);
+            f.h[h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+            f.h[2 + h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(p2, p3));
+            if constexpr (!ONES) psum += (p0 + p1) + (p2 + p3);
+          }
+          pf[qt][kk] = f.v;
+          PW pw;
+          pw.v = f.v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) trip = __builtin_elementwise_max(trip, pw.w[i]);
         }
-      });
+        if constexpr (!ONES) lrun[qt] += psum;
+      }
+      pv();
+    } else {
+      qk();
+      // ---- online softmax (per query = per lane column), P^T packed to fp16 MFMA B fragments ----
+  #pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        float mr = fmaxf(fmaxf(s[qt][0][0], s[qt][0][1]), s[qt][0][2]);
+        mr = fmaxf(fmaxf(mr, s[qt][0][3]), s[qt][1][0]);
+        mr = fmaxf(fmaxf(mr, s[qt][1][1]), s[qt][1][2]);
+        mr = fmaxf(fmaxf(mr, s[qt][1][3]), s[qt][2][0]);
+        mr = fmaxf(fmaxf(mr, s[qt][2][1]), s[qt][2][2]);
+        mr = fmaxf(fmaxf(mr, s[qt][2][3]), s[qt][3][0]);
+        mr = fmaxf(fmaxf(mr, s[qt][3][1]), s[qt][3][2]);
+        mr = fmaxf(mr, s[qt][3][3]);
+        mr = xor32_max(xor16_max(mr));
+        const float mnew = fmaxf(mrun[qt], mr * c);
+        const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        float p[4][4];
+        float psum = 0.f;
+        const f32x2 c2 = {c, c}, nm2 = {-mnew, -mnew};
+  #pragma unroll
+        for (int t = 0; t < 4; ++t)
+  #pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 sv = {s[qt][t][2 * h2], s[qt][t][2 * h2 + 1]};
+            const f32x2 x = __builtin_elementwise_fma(sv, c2, nm2);
+            p[t][2 * h2] = __builtin_amdgcn_exp2f(x[0]);
+            p[t][2 * h2 + 1] = __builtin_amdgcn_exp2f(x[1]);
+            if constexpr (!ONES) psum += p[t][2 * h2] + p[t][2 * h2 + 1];
+          }
+        if constexpr (!ONES) lrun[qt] = lrun[qt] * alpha + psum;
+        // rescale only when some query of the wave saw its running max move (exact: alpha == 1 otherwise)
+        if (__builtin_amdgcn_readfirstlane(__any(alpha != 1.0f))) {
+  #pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= alpha;
+        }
+  #pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          union { f16x2 h[4]; f16x8 v; } f;
+  #pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            f.h[h2] = __builtin_convertvector((f32x2){p[2 * kk][2 * h2], p[2 * kk][2 * h2 + 1]}, f16x2);
+            f.h[2 + h2] = __builtin_convertvector((f32x2){p[2 * kk + 1][2 * h2], p[2 * kk + 1][2 * h2 + 1]}, f16x2);
+          }
+          pf[qt][kk] = f.v;
+        }
+      }
+
+      pv();
     }
+    __builtin_amdgcn_sched_barrier(0);   // keep the next tile's K fragment reads below this tile's PV: 8 x 4 registers the kernel does not have
   };
 
   const int nfull = a.nk / KT;
-  int st_c = 0;   // compute cursor: stage inside the segment
-  for (int si = 0; si < T; ++si) {
-    if (NBUF > 1 && si + 1 < T) dma_stage(si + 1);
-    const char* st = smem + (si & (NBUF - 1)) * STAGE;
+  auto sweep = [&](auto fold_c) {
+    int st_c = 0;   // compute cursor: stage inside the segment
+    for (int si = 0; si < T; ++si) {
+      if (NBUF > 1 && si + 1 < T) dma_stage(si + 1);
+      const char* st = smem + (si & (NBUF - 1)) * STAGE;
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-      const int kt = st_c * NSUB + j;
-      if (kt < nfull) tile(BT{}, st + j * SUB, kt);
-      else if (kt < ntk) tile(BF{}, st + j * SUB, kt);
+      for (int j = 0; j < NSUB; ++j) {
+        const int kt = st_c * NSUB + j;
+        if (kt < nfull) tile(BT{}, fold_c, st + j * SUB, kt);
+        else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
+      }
+      if (++st_c == nst) st_c = 0;
+      if (NBUF == 1 && si + 1 < T) {
+        __syncthreads();   // single buffer: every wave is done reading it
+        dma_stage(si + 1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
+      __syncthreads();                                    // ... and so have everyone else's; this stage is free
     }
-    if (++st_c == nst) st_c = 0;
-    if (NBUF == 1 && si + 1 < T) {
-      __syncthreads();   // single buffer: every wave is done reading it
-      dma_stage(si + 1);
+  };
+  if constexpr (FOLD) {
+    sweep(BT{});
+    // one check per block: did any P reach 2^15 (0x7800)?  Then phase A's result is discarded: phase B = the classic
+    // running-maximum sweep over the same keys with the unscaled Q.  (K's ones column then meets a zero k-slot.)
+    __shared__ int trip_flag;
+    if (tid == 0) trip_flag = 0;
+    __syncthreads();
+    if ((trip[0] > trip[1] ? trip[0] : trip[1]) >= 0x7800) trip_flag = 1;
+    __syncthreads();
+    if (trip_flag) {
+      load_q(BF{});
+      reset_acc();
+      prime();
+      sweep(BF{});
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
-    __syncthreads();                                    // ... and so have everyone else's; this stage is free
+  } else {
+    sweep(BF{});
   }
 
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] ----
@@ -805,12 +926,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ V, 
   }
 }
 
-template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB>
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD = (DH % 32 != 0)>
 int launch_attn2(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 16 * QT * NW;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
-  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
+  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d>", DH, QT, NW);
@@ -860,9 +981,19 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
                          reinterpret_cast<const f16*>(a->V), a->ldv, a->nk, C, reinterpret_cast<float*>(a->vsum));
     }
     // 8 waves x 32 queries when the launch has whole 256-query blocks (halves the K/V fill per query), else 4 waves
+    static const bool fold_on = !(getenv("ME_ATTN_FOLD") && atoi(getenv("ME_ATTN_FOLD")) == 0);
+    const bool fold = fold_on && a->nk >= 256;
     switch (a->dh) {
-      case 40: rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1>(a, st); break;
-      case 80: rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1>(a, st); break;
+      // fold (speculative fixed-offset softmax with the classic sweep as in-kernel fallback) pays from a few tiles per query on:
+      // its start-up is one extra QK^T tile.  The 77-key text cross-attention stays classic.  ME_ATTN_FOLD=0: A/B switch.
+      case 40:
+        if (fold) rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, true>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, true>(a, st);
+        else rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, false>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, false>(a, st);
+        break;
+      case 80:
+        if (fold) rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, true>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, true>(a, st);
+        else rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, false>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, false>(a, st);
+        break;
       case 160: rc = launch_attn2<160, 1, 4, 2, 1, 1>(a, st); break;
       default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
     }

@@ -261,6 +261,42 @@ def test_attention_production_size(ops, dh, N, kind):
     check(got.cpu()[rows], want, f"attn production size dh={dh} N={N} {kind}", mx=2e-3 * peak)
 
 
+@pytest.mark.parametrize("dh,nq,nk,where", [(40, 512, 1024, "late"), (40, 512, 1024, "some"), (40, 96, 640, "late"), (80, 256, 512, "late"), (80, 64, 512, "some"),
+                                            (40, 512, 1024, "edge")])
+def test_attention_fixed_offset_overflow_falls_back_to_running_max(ops, dh, nq, nk, where):
+    """The fast path of attn2 fixes every query's softmax offset from the FIRST 64-key tile and checks once per block that no
+    P reached 2^15; blocks that did are recomputed in-kernel with the classic running maximum.  'late': every query meets keys
+    ~ e^35 heavier than its first tile (all blocks fall back); 'some': only the queries of one 16-row group do (a single block
+    falls back, the others keep the fast result); 'edge': the heavy key sits 14.5 binades up -- just inside fp16's range, no
+    fallback, P up to 2^14.5 next to P ~ 1."""
+    from motioneditor_amd import segments
+    C, n_items = 8 * dh, 2
+    g = torch.Generator().manual_seed(21)
+    q = torch.randn(n_items * nq, C, generator=g) * 0.5
+    k = torch.randn(n_items * nk, C, generator=g) * 0.5
+    v = torch.randn(n_items * nk, C, generator=g)
+    scale = dh ** -0.5
+    hot = nk - 70                                       # a key of the last-but-one tile
+    for it in range(n_items):
+        rows = range(nq) if where != "some" else range(32, 48)
+        for h in range(8):
+            qs = q[it * nq:(it + 1) * nq, h * dh:(h + 1) * dh]
+            # make key `hot` parallel to the mean query direction of the chosen rows: logit = |q| |k| cos ~ target nats
+            d = qs[list(rows)].mean(0)
+            d = d / d.norm()
+            target = 10.0 if where == "edge" else 35.0   # nats above the typical logit (|.| < 2)
+            qs[list(rows)] += d * 3.0                   # give those queries a common component of length 3
+            k[it * nk + hot, h * dh:(h + 1) * dh] = d * (target / (3.0 * scale))
+    q, k, v = q.half(), k.half(), v.half()
+    si, sm = segments.self_items(n_items, "cpu")
+    args = dict(heads=8, dh=dh, n_items=n_items, nq=nq, nk=nk, seg_item=si, seg_mode=sm)
+    got = ops.attention(cu(q), cu(k), cu(v), **{**args, "seg_item": cu(si), "seg_mode": cu(sm)})
+    want = emu.attention(q, k, v, **args)
+    assert torch.isfinite(got).all()
+    check(got, want, f"attn fixed-offset fallback dh={dh} nq={nq} {where}", rel=2e-3, mx=2e-2)
+    assert torch.equal(got, ops.attention(cu(q), cu(k), cu(v), **{**args, "seg_item": cu(si), "seg_mode": cu(sm)}))   # run to run
+
+
 def test_attention_large_logits_online_softmax_rescale(ops):
     """Force the running max to jump late (a spiked key in the LAST tile) so the rescale path matters."""
     dh, nq, nk, C = 40, 64, 300, 320
