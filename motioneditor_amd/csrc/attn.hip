@@ -527,6 +527,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
         }
         fq[qt][ks] = u.h;
       }
+      if constexpr (FOLD) {
+        if (g == GS) fq[qt][D32 - 1][1] = (f16)-1.f;   // against the pad marks of K column DH+1
+      }
     }
   };
   load_q(std::integral_constant<bool, FOLD>{});
@@ -583,6 +586,18 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   };
   auto dma_stage = [&](int si) {   // fetch the load cursor's stage into buffer si % NBUF, advance the cursor
     const unsigned st = smem_base + (si & (NBUF - 1)) * STAGE;
+    if constexpr (FOLD) {
+      // pad marks: K column DH+1 (next to the ones column, never touched by the DMA) is 60000 for the rows of this stage that lie
+      // past nk and 0 elsewhere; the Q fragments carry -1 in that k-slot, so those logits come out of the MFMA at -60000 and
+      // their P is exactly 0 -- the tail tile needs no masking code (and the kernel no second tile variant).
+      if (a.nk % KT != 0 && wave == NW - 1) {
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+          const int kt = st_l * NSUB + j;
+          *reinterpret_cast<f16*>(smem + (si & (NBUF - 1)) * STAGE + j * SUB + lane * KPB + DH * 2 + 2) = (kt * KT + lane >= a.nk) ? (f16)60000.f : (f16)0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NSUB; ++j) {
       const int kt = st_l * NSUB + j;
@@ -663,7 +678,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, (g * 4 + t * 16 + r < a.nk) ? s0[t][r] : NEG_BIG);
+          for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s0[t][r]);   // keys past nk: pad marks put them at -60000
         mr = xor32_max(xor16_max(mr));
         set_ref(qt, ceilf(mr));
       }
@@ -832,8 +847,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 #pragma unroll
       for (int j = 0; j < NSUB; ++j) {
         const int kt = st_c * NSUB + j;
-        if (kt < nfull) tile(BT{}, fold_c, st + j * SUB, kt);
-        else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
+        if constexpr (FOLD) {   // keys past nk are masked through the K image (pad marks, see dma_stage): one tile variant only
+          if (kt < ntk) tile(BT{}, fold_c, st + j * SUB, kt);
+        } else {
+          if (kt < nfull) tile(BT{}, fold_c, st + j * SUB, kt);
+          else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
+        }
       }
       if (++st_c == nst) st_c = 0;
       if (NBUF == 1 && si + 1 < T) {
