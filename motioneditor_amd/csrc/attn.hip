@@ -651,10 +651,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   // against the ones column of K: the QK^T MFMA then delivers  s * c - m~  directly and P = 2^(that), no VALU pass between.
   // m~ = ceil(row maximum over the FIRST 64-key tile), an integer (exact in fp16), and stays fixed: a softmax is exact for
   // any offset as long as P stays inside fp16's range.  Keys lighter than the first tile's maximum underflow exactly as
-  // they do under a running maximum; a key more than 2^15 x HEAVIER would overflow, so every P's fp16 bit pattern is
-  // folded into a running per-lane maximum (`trip`, one v_pk_max_u16 per P register) and checked ONCE, after the sweep: if
-  // any lane of the block saw P >= 2^15, the block discards phase A and recomputes with the classic online softmax
-  // (phase B, below).  Conversions round towards zero, so such a P saturates at 65504 -- finite -- and phase A can
+  // they do under a running maximum; a key more than 2^16 x HEAVIER would overflow fp16, which is checked ONCE, after the
+  // sweep, on the denominators (below): if any query of the block may have seen a saturated P, the block discards phase A
+  // and recomputes with the classic online softmax (phase B).  Conversions round towards zero, so such a P saturates at 65504 -- finite -- and phase A can
   // neither produce inf / NaN nor fault while it runs to its end.
   auto set_ref = [&](int qt, float m) {
     const f16 hm = (f16)(-fminf(fmaxf(m, -2000.f), 2000.f));
@@ -687,8 +686,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 
   using BT = std::integral_constant<bool, true>;
   using BF = std::integral_constant<bool, false>;
-  typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-  u16x2 trip = {0, 0};
   auto tile = [&](auto full_c, auto fold_c, const char* st, int kt) {
     constexpr bool FULL = decltype(full_c)::value;
     constexpr bool FOLDT = decltype(fold_c)::value;
@@ -760,7 +757,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     if constexpr (FOLDT) {
       // P = 2^(MFMA result), rounded TOWARDS ZERO to fp16 (the denominator is the sum of the same rounded values, so the
       // bias cancels); P >= 0, so the unsigned order of the bit patterns is the value order.
-      union PW { f16x8 v; u16x2 w[4]; };
       qk();
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -777,10 +773,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
             if constexpr (!ONES) psum += (p0 + p1) + (p2 + p3);
           }
           pf[qt][kk] = f.v;
-          PW pw;
-          pw.v = f.v;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) trip = __builtin_elementwise_max(trip, pw.w[i]);
         }
         if constexpr (!ONES) lrun[qt] += psum;
       }
@@ -865,12 +857,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   };
   if constexpr (FOLD) {
     sweep(BT{});
-    // one check per block: did any P reach 2^15 (0x7800)?  Then phase A's result is discarded: phase B = the classic
-    // running-maximum sweep over the same keys with the unscaled Q.  (K's ones column then meets a zero k-slot.)
+    // one check per block: could any P have saturated?  P >= 0, so a query's denominator (the sum of its P, accumulated in
+    // fp32 by the ones row of the PV MFMA, or in lrun) bounds every one of them: denominator < 65504 => every P was below
+    // fp16's largest value, i.e. exact.  A saturated P (stored as 65504) always trips it; the test is conservative (flat
+    // attention over more than 65504 keys would trip it too) and costs nothing per tile.
+    // Then phase A's result is discarded: phase B = the classic running-maximum sweep over the same keys with the unscaled Q
+    // (K's ones column then meets a zero k-slot).
     __shared__ int trip_flag;
     if (tid == 0) trip_flag = 0;
     __syncthreads();
-    if ((trip[0] > trip[1] ? trip[0] : trip[1]) >= 0x7800) trip_flag = 1;
+    bool trip = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if constexpr (ONES) trip |= (g == (DH % 16) / 4) && !(o[qt][DH / 16][(DH % 16) % 4] < 65504.f);
+      else trip |= !(lrun[qt] < 65504.f);
+    }
+    if (trip) trip_flag = 1;
     __syncthreads();
     if (trip_flag) {
       load_q(BF{});
