@@ -311,7 +311,7 @@ __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&ac
     for (int jj = 0; jj < NO; ++jj) {
       float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * a.alpha * gelu_erf_fast(acc[2 * jj + 1][i][r] * a.alpha);
+      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * gelu_sigpoly(acc[2 * jj + 1][i][r]);   // alpha == 1 (me_gemm checks)
       o[i][jj].h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
       o[i][jj].h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
     }
@@ -868,7 +868,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->res2 && (a->ldr2 % 4 || ((uintptr_t)a->res2 & 7))) { me_set_error("me_gemm: bad second residual"); return ME_EINVAL; }
   if (a->act < 0 || a->act > 2) { me_set_error("me_gemm: bad activation"); return ME_EINVAL; }
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
-  if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act)) { me_set_error("me_gemm: geglu needs N % 32 == 0 and no rowvec/res/act"); return ME_EINVAL; }
+  if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act || a->alpha != 1.0f)) { me_set_error("me_gemm: geglu needs N % 32 == 0, alpha == 1 and no rowvec/res/act"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // N tile: every channel count of the model (320 ... 10240) is a multiple of 160 -> exact 128x160 tiles;
   // GEGLU needs whole (value, gate) 32-row pairs per wave -> 128; leftovers (4, 16, 32, 96, 256) -> 128 / 64 with a tail
