@@ -224,6 +224,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 }
 
 
+// C = 320 (level 0: two thirds of all LayerNorm rows of a step): 40 of a wave's 64 lanes would hold a row, and a wave that
+// lives for one 640-byte row spends its life being launched.  Here HALF a wave holds a row -- lane l of the half loads
+// columns [8l, 8l+8) and [256 + 2l, 256 + 2l + 2) -- every lane is busy, a wave walks U = 2 row pairs per trip with all four
+// rows' loads in flight before the first reduction, and gamma / beta stay in registers for the whole walk.
+__global__ __launch_bounds__(256) void layernorm320_kernel(const f16* __restrict__ X, f16* __restrict__ Y, const f16* __restrict__ gamma,
+                                                           const f16* __restrict__ beta, long rows, int ldx, int ldy, float eps) {
+  constexpr int U = 2;
+  const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  U128 g8, b8;
+  g8.u = ldg128(gamma + 8 * l32);
+  b8.u = ldg128(beta + 8 * l32);
+  const f16x2 g2 = *reinterpret_cast<const f16x2*>(gamma + 256 + 2 * l32), b2 = *reinterpret_cast<const f16x2*>(beta + 256 + 2 * l32);
+  auto half_sum = [](float v) {   // over the 32 lanes of this half
+    v = xor16_sum(v);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (long r0 = wave * 2 * U; r0 < rows; r0 += nwaves * 2 * U) {
+    U128 a[U];
+    f16x2 c[U];
+    long row[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      row[k] = r0 + 2 * k + half;
+      const bool ok = row[k] < rows;
+      a[k].u = ok ? ldg128(X + row[k] * ldx + 8 * l32) : zero128();
+      c[k] = ok ? *reinterpret_cast<const f16x2*>(X + row[k] * ldx + 256 + 2 * l32) : f16x2{(f16)0.f, (f16)0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      float s = (float)c[k][0] + (float)c[k][1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)a[k].e[e];
+      const float mean = half_sum(s) * (1.0f / 320.0f);
+      float d0 = (float)c[k][0] - mean, d1 = (float)c[k][1] - mean;
+      float q = d0 * d0 + d1 * d1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)a[k].e[e] - mean;
+        q += d * d;
+      }
+      const float rstd = rsqrtf(half_sum(q) * (1.0f / 320.0f) + eps);
+      if (row[k] < rows) {
+        U128 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = (f16)(((float)a[k].e[e] - mean) * rstd * (float)g8.e[e] + (float)b8.e[e]);
+        *reinterpret_cast<uint4*>(Y + row[k] * ldy + 8 * l32) = o.u;
+        const f16x2 o2 = {(f16)(d0 * rstd * (float)g2[0] + (float)b2[0]), (f16)(d1 * rstd * (float)g2[1] + (float)b2[1])};
+        *reinterpret_cast<f16x2*>(Y + row[k] * ldy + 256 + 2 * l32) = o2;
+      }
+    }
+  }
+}
+
 // Row softmax, one wave per row, the row held in registers (cols <= 8192 -> <= 16 vectors of 8 per lane).
 template <int NV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* X, f16* Y, long rows, int cols, int ldx, int ldy) {
@@ -362,7 +418,10 @@ extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {
   const f16* gm = reinterpret_cast<const f16*>(a->gamma);
   const f16* bt = reinterpret_cast<const f16*>(a->beta);
   (void)hipGetLastError();
-  if (nv == 1) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
+  if (a->C == 320 && a->rows >= 4096) {
+    const unsigned nb = (unsigned)min((long)((a->rows + 15) / 16), 256L * 24);   // 16 rows per block and trip; <= 24 blocks per CU, the rest by grid stride
+    hipLaunchKernelGGL(layernorm320_kernel, dim3(nb), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->ldx, a->ldy, a->eps);
+  } else if (nv == 1) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_layernorm: kernel launch failed"); return ME_EHIP; }

@@ -358,7 +358,7 @@ def test_groupnorm_is_bitwise_reproducible(ops):
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("C,rows", [(320, 1000), (640, 77), (1280, 130)])
+@pytest.mark.parametrize("C,rows", [(320, 1000), (320, 4096 * 3 + 5), (320, 70001), (640, 77), (1280, 130)])   # >= 4096 rows of 320: the half-wave-per-row kernel, odd tails
 def test_layernorm(ops, C, rows):
     x = (rnd(rows, C, seed=1) * 3 - 0.4).half()
     gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()

@@ -145,6 +145,13 @@ def bench_attn(only_first=False):
         ms = timeit(fn)
         units = segments.KEY_UNITS[si.data_ptr()]
         print(f"{name:28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
+        if name == "L0 prev|cur" and not only_first:
+            # worst case of the speculative fixed-offset softmax: a key far heavier than the first tile late in every row ->
+            # every block discards phase A and re-runs the classic sweep
+            for it in range(items):
+                q[it * N + N - 100, C:2 * C] *= 40.0
+            ms = timeit(fn)
+            print(f"{name + ' (all blocks fall back)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
         del q
 
 
