@@ -645,13 +645,38 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   };
   reset_acc();
   __syncthreads();   // LDS image initialised before the first DMA lands
-  prime();
+  // FOLD: the probe -- the K rows at the block's OWN query positions in the item's last segment (its own frame in every table
+  // of the model) go into the K regions of the stage buffers first.  A query's heaviest keys are itself and its neighbours
+  // in the row order; the fixed offset of phase A is taken from this 64-key neighbourhood (below), not from whatever the
+  // first keys of the first segment happen to be, so that trained, peaky attention maps do not trip the overflow check.
+  constexpr int NPROBE = FOLD ? ((BQ / KT) < NBUF * NSUB ? (BQ / KT > 0 ? BQ / KT : 1) : NBUF * NSUB) : 0;
+  if constexpr (FOLD) {
+    if (T > 0) {
+      const int kitp = nvalid == 1 ? kit3[0] : (nvalid == 2 ? kit3[1] : kit3[2]);   // (no dynamic index: the array would move to scratch)
+      const char* kseg = K + (long)kitp * a.nk * a.ldk * 2;
+#pragma unroll
+      for (int t = 0; t < NPROBE; ++t) {
+        const int ktp = min(qb * (BQ / KT) + t, ntk - 1);
+        const unsigned st = smem_base + (t / NSUB) * STAGE + (t % NSUB) * SUB;
+        const bool tail = (ktp + 1) * KT > a.nk;
+        if (a.nk % KT != 0 && wave == NW - 1)
+          *reinterpret_cast<f16*>(smem + (t / NSUB) * STAGE + (t % NSUB) * SUB + lane * KPB + DH * 2 + 2) = (ktp * KT + lane >= a.nk) ? (f16)60000.f : (f16)0.f;
+#pragma unroll
+        for (int i = 0; i < NSLOT; ++i) {
+          const int q = wave + NW * i;
+          if (q < CK) dma16_masked(st + q * 1024, kseg + (long)ktp * KT * a.ldk * 2, tail ? max(slot_off(i, a.nk - 1 - ktp * KT), 0) : off[i], msk[i]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
 
   // FOLD (phase A, the speculative fast path): the reference offset m~ of a query (mrun) rides in k-slot DH of its Q fragment,
   // against the ones column of K: the QK^T MFMA then delivers  s * c - m~  directly and P = 2^(that), no VALU pass between.
-  // m~ = ceil(row maximum over the FIRST 64-key tile), an integer (exact in fp16), and stays fixed: a softmax is exact for
-  // any offset as long as P stays inside fp16's range.  Keys lighter than the first tile's maximum underflow exactly as
-  // they do under a running maximum; a key more than 2^16 x HEAVIER would overflow fp16, which is checked ONCE, after the
+  // m~ = ceil(row maximum over the query's PROBE tile: the 64 keys around its own position in its own frame), an integer
+  // (exact in fp16), and stays fixed: a softmax is exact for any offset as long as P stays inside fp16's range.  Keys
+  // lighter than the probe's maximum underflow exactly as they do under a running maximum; a key more than 2^16 x HEAVIER would overflow fp16, which is checked ONCE, after the
   // sweep, on the denominators (below): if any query of the block may have seen a saturated P, the block discards phase A
   // and recomputes with the classic online softmax (phase B).  Conversions round towards zero, so such a P saturates at 65504 -- finite -- and phase A can
   // neither produce inf / NaN nor fault while it runs to its end.
@@ -661,8 +686,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     mrun[qt] = -(float)hm;
   };
   if constexpr (FOLD) {
-    if (T > 0) {   // initial offset = ceil(row maximum over the first 64-key tile): one extra QK^T per block, no P, no PV
-      const char* sK = smem;
+    if (T > 0) {   // initial offset = ceil(row maximum over the probe tile that holds this wave's queries): one extra QK^T, no P, no PV
+      const int tw = min((wave * QT * 16) / KT, NPROBE - 1);
+      const char* sK = smem + (tw / NSUB) * STAGE + (tw % NSUB) * SUB;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         f32x4 s0[4];
@@ -682,7 +708,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
         set_ref(qt, ceilf(mr));
       }
     }
+    __syncthreads();   // every wave has read its probe tile: the buffers may be overwritten
   }
+  prime();
 
   using BT = std::integral_constant<bool, true>;
   using BF = std::integral_constant<bool, false>;

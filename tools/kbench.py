@@ -152,6 +152,12 @@ def bench_attn(only_first=False):
                 q[it * N + N - 100, C:2 * C] *= 40.0
             ms = timeit(fn)
             print(f"{name + ' (all blocks fall back)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
+            # trained-model-like: every query's heaviest key is its own position (k_i parallel to q_i, ~ +30 nats over the rest);
+            # the probe takes the offset from there, so nothing falls back
+            q = rnd(items * N, 3 * C)
+            q[:, C:2 * C] = q[:, :C] * 4.0
+            ms = timeit(fn)
+            print(f"{name + ' (diagonal-dominant)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
         del q
 
 
