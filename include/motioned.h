@@ -137,14 +137,16 @@ typedef struct me_attn_args {
   const void* mask;        /* fp16 [8][nk] mask planes (only for DUAL_CUR / DUAL_PREV)     */
   float scale;
   int32_t general_dual;    /* 1 when any seg_mode is DUAL_CUR / DUAL_PREV (selects the kernel built with that path) */
-  /* Required when any seg_mode is ME_SEG_DUAL_BIN: fp32 scratch [n_kv_items][heads*dh].  me_attn fills it with the
-   * per-kv-item column sums of V (the query-independent "+1" part of every binary dual key, fully_control.py:381-413)
-   * on `stream` before the attention kernel, which adds it in its epilogue.  NULL when no segment is DUAL_BIN. */
+  /* Required when any seg_mode is ME_SEG_DUAL_BIN: device scratch of me_attn_vsum_bytes(n_kv_items, heads*dh) bytes, 16-byte
+   * aligned.  me_attn fills its head, fp32 [n_kv_items][heads*dh], with the per-kv-item column sums of V (the
+   * query-independent "+1" part of every binary dual key, fully_control.py:381-413) on `stream` before the attention kernel,
+   * which adds it in its epilogue; the rest holds the partials of the fixed-order reduction.  NULL when no segment is DUAL_BIN. */
   void* vsum;
   int32_t n_kv_items;      /* kv items in K / V (rows / nk); only read with vsum */
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);
+int64_t me_attn_vsum_bytes(int32_t n_kv_items, int32_t channels);
 
 /* ---- temporal (per-pixel, over frames) causal attention ------------------------------------- *
  * rows (b*frames + fr)*npix + p.  For batch b, K/V are read from batch kv_map[b] (the temporal

@@ -953,26 +953,44 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 }
 
 // column sums of V per kv item: vsum[kit][c] = sum_key V[kit*nk + key][c], fp32 (the query-independent "+1" part of the
-// binary dual segments).  Block = one kv item x 128 columns; 4 row groups x 64 column pairs.
-__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ V, int ldv, int nk, int C, float* __restrict__ out) {
-  __shared__ float red[4][128];
-  const int kit = blockIdx.x, c0 = blockIdx.y * 128 + (threadIdx.x & 63) * 2, rg = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f;
-  if (c0 < C) {
-    const f16* p = V + (long)kit * nk * ldv + c0;
-    for (int r = rg; r < nk; r += 4) {
-      const f16x2 v = *reinterpret_cast<const f16x2*>(p + (long)r * ldv);
-      s0 += (float)v[0];
-      s1 += (float)v[1];
+// binary dual segments).  Two deterministic passes: block (kit, row split rs) sums its rows with 16-byte loads -- a thread owns
+// one 8-column vector and walks down the rows, row lanes are folded through LDS in a fixed order -- into part[rs][kit][C];
+// the second pass adds the RS partials in order.  (The first version gave every kv item to ONE block per 128 columns: 288
+// blocks of 4-byte loads, 0.9 TB/s.)
+constexpr int COLSUM_RS = 16;
+__global__ __launch_bounds__(256) void colsum_part_kernel(const f16* __restrict__ V, int ldv, int nk, int C, float* __restrict__ part, int n_items) {
+  __shared__ float red[256][8];
+  const int kit = blockIdx.x, rs = blockIdx.y;
+  const int tpr = C / 8, RL = 256 / tpr;          // vectors per row, row lanes (C <= 2048)
+  const int rl = threadIdx.x / tpr, vc = threadIdx.x - rl * tpr;
+  const int rows = (nk + COLSUM_RS - 1) / COLSUM_RS, r0 = rs * rows, r1 = min(r0 + rows, nk);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    const f16* p = V + (long)kit * nk * ldv + vc * 8;
+#pragma unroll 4
+    for (int r = r0 + rl; r < r1; r += RL) {
+      U128 u;
+      u.u = ldg128(p + (long)r * ldv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)u.e[e];
     }
   }
-  red[rg][(threadIdx.x & 63) * 2] = s0;
-  red[rg][(threadIdx.x & 63) * 2 + 1] = s1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
   __syncthreads();
-  if (threadIdx.x < 128) {
-    const int c = blockIdx.y * 128 + threadIdx.x;
-    if (c < C) out[(long)kit * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float sacc = 0.f;
+    for (int l = 0; l < RL; ++l) sacc += red[l * tpr + c / 8][c % 8];
+    part[((long)rs * n_items + kit) * C + c] = sacc;
   }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ part, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float sacc = 0.f;
+#pragma unroll
+  for (int rs = 0; rs < COLSUM_RS; ++rs) sacc += part[rs * n + i];
+  out[i] = sacc;
 }
 
 template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD = (DH % 32 != 0)>
@@ -1008,6 +1026,10 @@ int launch_attn(const me_attn_args* a, hipStream_t st) {
 
 extern "C" void me_set_error(const char* msg);
 
+extern "C" int64_t me_attn_vsum_bytes(int32_t n_kv_items, int32_t channels) {
+  return n_kv_items > 0 && channels > 0 ? (int64_t)(1 + COLSUM_RS) * n_kv_items * channels * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (!a || !a->Q || !a->K || !a->V || !a->O || !a->seg_item || !a->seg_mode) { me_set_error("me_attn: null pointer"); return ME_EINVAL; }
   if (a->n_items <= 0 || a->nq <= 0 || a->nk <= 0 || a->heads <= 0 || a->nseg < 1 || a->nseg > 3) { me_set_error("me_attn: bad sizes"); return ME_EINVAL; }
@@ -1026,8 +1048,13 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
     if (a->vsum) {   // binary dual segments: per-kv-item column sums of V first (same stream)
       if (a->n_kv_items <= 0) { me_set_error("me_attn: vsum needs n_kv_items"); return ME_EINVAL; }
       const int C = a->heads * a->dh;
-      hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)a->n_kv_items, (unsigned)((C + 127) / 128)), dim3(256), 0, st,
-                         reinterpret_cast<const f16*>(a->V), a->ldv, a->nk, C, reinterpret_cast<float*>(a->vsum));
+      if (C % 8 || C > 2048 || ((uintptr_t)a->vsum & 15)) { me_set_error("me_attn: vsum needs heads * dh to be a multiple of 8 and <= 2048, 16-byte aligned scratch"); return ME_EINVAL; }
+      // vsum = [n_kv_items][C] sums, followed by COLSUM_RS x [n_kv_items][C] partials (scratch of the two-pass reduction)
+      float* vs = reinterpret_cast<float*>(a->vsum);
+      const long n = (long)a->n_kv_items * C;
+      hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)a->n_kv_items, COLSUM_RS), dim3(256), 0, st, reinterpret_cast<const f16*>(a->V), a->ldv, a->nk, C, vs + n,
+                         a->n_kv_items);
+      hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vs + n, vs, n);
     }
     // 8 waves x 32 queries when the launch has whole 256-query blocks (halves the K/V fill per query), else 4 waves
     static const bool fold_on = !(getenv("ME_ATTN_FOLD") && atoi(getenv("ME_ATTN_FOLD")) == 0);

@@ -180,7 +180,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
     a.general_dual = 1 if gd else 0
     if bd and not gd:   # binary dual keys: me_attn needs fp32 scratch for the per-kv-item column sums of V
         n_kv = k.shape[0] // nk
-        vsum = torch.empty((n_kv, heads * dh), dtype=torch.float32, device=q.device)
+        vsum = torch.empty(capi.lib().me_attn_vsum_bytes(n_kv, heads * dh) // 4, dtype=torch.float32, device=q.device)
         a.vsum, a.n_kv_items = vsum.data_ptr(), n_kv
     e0 = _pb()
     capi.check(capi.lib().me_attn(C.byref(a), _stream()), "me_attn")
