@@ -897,8 +897,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     bool trip = false;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-      if constexpr (ONES) trip |= (g == (DH % 16) / 4) && !(o[qt][DH / 16][(DH % 16) % 4] < 65504.f);
-      else trip |= !(lrun[qt] < 65504.f);
+      // (rows past nq carry a zero query: P = 1 for every key, a denominator of n keys -- they must not trip the block)
+      if constexpr (ONES) trip |= qrow[qt] >= 0 && (g == (DH % 16) / 4) && !(o[qt][DH / 16][(DH % 16) % 4] < 65504.f);
+      else trip |= qrow[qt] >= 0 && !(lrun[qt] < 65504.f);
     }
     if (trip) trip_flag = 1;
     __syncthreads();
