@@ -370,13 +370,15 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_clips * args.steps / dt
         tf_ref, tf_exact = step_tflop(f, h, w)
+        xch = ("frame<->pixel all-to-all for temporal attention (RCCL), <= 2 halo frames of K|V for the adapter's sparse-causal attention (p2p)"
+               if args.shard_exchange == "lean" else "RCCL all-gather of K|V (adapter sparse-causal + temporal attention)")
         desc = {"single": "single GPU",
                 "cfg": f"cfg2 x dp{n_clips}: each GPU pair splits one clip along the classifier-free-guidance axis (one RCCL all-gather of the noise prediction per step)"
                        + (f", {n_clips} clips side by side" if n_clips > 1 else ""),
                 "cfg-frames": f"cfg2 x frames{n_shards}: one clip; GPU pairs split the CFG axis, {f // max(n_shards, 1)} frames per GPU; per layer: attn1 one-frame K|V halo (p2p), "
-                              f"RCCL all-gather of K|V (adapter sparse-causal + temporal attention), TemporalConv halos, GroupNorm-statistic all-reduce, all at batch 2",
-                "frames": f"frames{n_shards}: one clip, {f // max(n_shards, 1)} frames per GPU; per layer: attn1 one-frame K|V halo (p2p), RCCL all-gather of K|V (adapter sparse-causal + "
-                          f"temporal attention), TemporalConv halos, GroupNorm-statistic all-reduce",
+                              f"{xch}, TemporalConv halos, GroupNorm-statistic all-reduce, all at batch 2",
+                "frames": f"frames{n_shards}: one clip, {f // max(n_shards, 1)} frames per GPU; per layer: attn1 one-frame K|V halo (p2p), {xch}, "
+                          f"TemporalConv halos, GroupNorm-statistic all-reduce",
                 "replicas": f"dp{world}: one independent clip per GPU, no data-path collective"}[mode]
         out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
                           f"denoise-steps/sec, {f}f x {8 * h}^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
