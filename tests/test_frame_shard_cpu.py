@@ -100,6 +100,16 @@ def test_frame_sharded_step_equals_single_process(tmp_path, f, temporal):
     assert err < 1e-4, err
 
 
+def test_four_frame_shards_equal_single_process(tmp_path):
+    """4 frame shards of 6 frames: the frame<->pixel all-to-all runs over 4 ranks, and the adapter's chunk-first / previous frames
+    come from other ranks for every rank but the first (ranges start at frames 6, 12, 18 of chunks that start at 0, 8, 16)."""
+    out = tmp_path / "r.pt"
+    port = 29700 + (os.getpid() % 2000) + 55
+    mp.spawn(_worker, args=(4, port, 24, str(out), False, "a2a", "halo"), nprocs=4, join=True)
+    err = torch.load(out)["err"]
+    assert err < 1e-4, err
+
+
 def test_hybrid_cfg_x_frame_sharded_step_equals_single_process(tmp_path):
     """4 ranks = CFG pair x 2 frame shards (the 8-GPU layout at half size): every frame-shard exchange runs at batch 2 and the
     pair trades its noise predictions once; the result must be the single-process step."""
