@@ -118,6 +118,32 @@ def _ref_function(path: Path, name: str):
     return ns[name]
 
 
+def prepare_image_golden():
+    """MotionEditorPipeline.prepare_image (pipeline_motion_editor.py:418-459) executed as written -- PIL and tensor inputs, one
+    image broadcast over the batch, classifier-free-guidance doubling -- on seeded uint8 images; the images travel with the
+    expected tensors (tests/golden/prepare_image.npz)."""
+    import PIL.Image
+    lanczos = PIL.Image.Resampling.LANCZOS if hasattr(PIL.Image, "Resampling") else PIL.Image.LANCZOS
+    tree = ast.parse((REF / "motion_editor/pipelines/pipeline_motion_editor.py").read_text())
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "prepare_image")
+    ns = {"torch": torch, "np": np, "PIL": PIL, "PIL_INTERPOLATION": {"lanczos": lanczos}}     # diffusers.utils.PIL_INTERPOLATION["lanczos"]
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "ref_prepare_image", "exec"), ns)
+    prepare_image = ns["prepare_image"]
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (40, 56), dtype=np.uint8)            # a grey ("L") image: .convert("RGB") replicates it
+    ims = [PIL.Image.fromarray(a), PIL.Image.fromarray(b)]
+    out = {"img_a": a, "img_b": b}
+    out["pil_list_cfg"] = prepare_image(None, ims, 32, 24, 2, 1, "cpu", torch.float32, True).numpy()
+    out["pil_one_b3"] = prepare_image(None, ims[0], 32, 24, 3, 1, "cpu", torch.float32, False).numpy()
+    t = torch.from_numpy(rng.random((2, 3, 24, 32), dtype=np.float32))
+    out["tensor_in"] = t.numpy()
+    out["tensor_cfg"] = prepare_image(None, t, 32, 24, 2, 1, "cpu", torch.float32, True).numpy()
+    out["tensor_list"] = prepare_image(None, [t[:1], t[1:]], 32, 24, 2, 1, "cpu", torch.float32, False).numpy()
+    np.savez_compressed(GOLD / "prepare_image.npz", **out)
+    print("prepare_image.npz written:", {k: v.shape for k, v in out.items()})
+
+
 def inversion_goldens(unet, sd):
     """DDIM inversion (util.py:111-124 as inference.py:289-293 calls it): normal_infer UNet forward + next_step."""
     next_step = _ref_function(REF / "motion_editor/util.py", "next_step")
@@ -171,7 +197,11 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
     GOLD.mkdir(parents=True, exist_ok=True)
+    if "--only-prepare-image" in sys.argv:
+        prepare_image_golden()
+        return
     reference_ddim_vectors()
+    prepare_image_golden()
 
     t0 = time.time()
     schema = synth.unet_schema()

@@ -85,3 +85,21 @@ def test_prepare_image_accepts_pil_and_tensor_lists_like_the_reference():
     ts = [torch.rand(1, 3, 8, 16), torch.rand(1, 3, 8, 16)]
     cat = pipe.prepare_image(ts, 16, 8, 2, 1, "cpu", torch.float32, False)
     assert torch.equal(cat, torch.cat(ts))
+
+
+def test_prepare_image_matches_the_reference_function_golden():
+    """tests/golden/prepare_image.npz = outputs of the reference's own prepare_image (oracle/make_golden.py executes the
+    function as written) on seeded uint8 images, which travel in the fixture."""
+    import numpy as np
+    import PIL.Image
+    from conftest import GOLD
+    from motioneditor_amd.pipelines.pipeline_motion_editor import MotionEditorPipeline
+    g = np.load(GOLD / "prepare_image.npz")
+    pipe = MotionEditorPipeline.__new__(MotionEditorPipeline)
+    ims = [PIL.Image.fromarray(g["img_a"]), PIL.Image.fromarray(g["img_b"])]
+    T = torch.from_numpy
+    assert torch.equal(pipe.prepare_image(ims, 32, 24, 2, 1, "cpu", torch.float32, True), T(g["pil_list_cfg"]))
+    assert torch.equal(pipe.prepare_image(ims[0], 32, 24, 3, 1, "cpu", torch.float32, False), T(g["pil_one_b3"]))
+    t = T(g["tensor_in"])
+    assert torch.equal(pipe.prepare_image(t, 32, 24, 2, 1, "cpu", torch.float32, True), T(g["tensor_cfg"]))
+    assert torch.equal(pipe.prepare_image([t[:1], t[1:]], 32, 24, 2, 1, "cpu", torch.float32, False), T(g["tensor_list"]))
