@@ -103,7 +103,8 @@ def conv3x3(P: Packed, name: str, x: Act, stride: int = 1, ups: int = 0, **epi) 
     return x.like(out, ho, wo)
 
 
-def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *, per_frame_stats: bool, eps: float = 1e-5, shard=None) -> Act:
+def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *, per_frame_stats: bool, eps: float = 1e-5, shard=None,
+                 out: Optional[torch.Tensor] = None) -> Act:
     """ResnetBlock2D.forward (resnet_2d.py:199-249).  GroupNorm statistics span all frames of a batch row
     for the 3-D UNet (5-D GroupNorm, :202,230) and one image for the 2-D ControlNet."""
     rpg = x.N if per_frame_stats else x.f * x.N
@@ -134,9 +135,9 @@ def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *
     if has_t2:
         hx = torch.empty((_ext_rows(x, shard), cout), dtype=P.dtype, device=x.t.device)
         h = conv3x3(P, p + ".conv2", x.like(h), out=hx).t
-        h = _tconv(P, p + ".temp_conv2", hx, x, ftot, shard, res=h, res2=sc)
+        h = _tconv(P, p + ".temp_conv2", hx, x, ftot, shard, res=h, res2=sc, **({} if out is None else {"out": out}))
     else:
-        h = conv3x3(P, p + ".conv2", x.like(h), res=sc).t
+        h = conv3x3(P, p + ".conv2", x.like(h), res=sc, **({} if out is None else {"out": out})).t
     return x.like(h)
 
 
@@ -234,13 +235,14 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
 
 
 def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, temporal=None, place: str = "", sc_attn: bool = True,
-                  has_temp: bool = True, shard=None) -> Act:
-    """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out."""
+                  has_temp: bool = True, shard=None, out: Optional[torch.Tensor] = None) -> Act:
+    """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out.
+    out: where the block's result is written (a column slice of the next skip-concat buffer)."""
     n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
     t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
     t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
                     sc_attn=sc_attn, has_temp=has_temp, shard=shard).t
-    return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t))
+    return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t, **({} if out is None else {"out": out})))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -430,18 +432,30 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
 
     if adapter_done is not None:
         torch.cuda.current_stream().wait_event(adapter_done)
+    cat = None   # torch.cat([hidden, res], dim=1) of the coming resnet, when its hidden half has already been written in place
     for i in range(4):
         for j in range(3):
             s = skips.pop()
-            cat = torch.empty((x.t.shape[0], x.C + s.C), dtype=P.dtype, device=dev)  # torch.cat([hidden, res], dim=1)
-            ops.copy_rows(cat[:, :x.C], x.t)
+            if cat is None:
+                cat = torch.empty((x.t.shape[0], x.C + s.C), dtype=P.dtype, device=dev)
+                ops.copy_rows(cat[:, :x.C], x.t)
             ops.copy_rows(cat[:, x.C:], s.t)
+            # the LAST op of this block (resnet / transformer / upsampler) writes its result straight into the left columns of
+            # the next block's concat buffer: one copy per concat instead of two
             n = f"up_blocks.{i}.resnets.{j}"
-            x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False, shard=shard)
+            cout = P.vec(n + ".conv1.bias").shape[0]
+            ups = j == 2 and i < 3
+            nxt = None
+            if skips:
+                nxt = torch.empty((x.t.shape[0] * (4 if ups else 1), cout + skips[-1].C), dtype=P.dtype, device=dev)
+            tgt = None if nxt is None else nxt[:, :cout]
+            last = "ups" if ups else ("attn" if UP_HAS_ATTN[i] else "res")
+            x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False, shard=shard, out=tgt if last == "res" else None)
             if UP_HAS_ATTN[i]:
-                x = transformer2d(P, f"up_blocks.{i}.attentions.{j}", x, text, tseg, place="up", **kw)
-        if i < 3:
-            x = conv3x3(P, f"up_blocks.{i}.upsamplers.0.conv", x, ups=1)
+                x = transformer2d(P, f"up_blocks.{i}.attentions.{j}", x, text, tseg, place="up", out=tgt if last == "attn" else None, **kw)
+            if ups:
+                x = conv3x3(P, f"up_blocks.{i}.upsamplers.0.conv", x, ups=1, **({} if tgt is None else {"out": tgt}))
+            cat = nxt
     gn = dict(reduce=shard.allreduce_, rows_per_group_total=shard.f_total * x.N) if shard is not None else {}
     y = ops.groupnorm(x.t, P.vec("conv_norm_out.weight"), P.vec("conv_norm_out.bias"), rows_per_group=x.f * x.N, eps=1e-5, silu=True, **gn)
     return conv3x3(P, "conv_out", x.like(y))
