@@ -144,6 +144,68 @@ def prepare_image_golden():
     print("prepare_image.npz written:", {k: v.shape for k, v in out.items()})
 
 
+def null_text_golden(unet, sd):
+    """MyNullInversion.null_optimization (p2p/null_text_optimization.py:133-166) executed AS WRITTEN -- the class body is compiled
+    from the reference file with only the methods the optimisation touches, NUM_DDIM_STEPS set to 2 (the file's global is 50) --
+    around the reference UNet with the synthetic weights: the optimised unconditional embeddings of two DDIM steps x two inner
+    Adam steps, plus the first inner step's gradient (computed here with the reference UNet and the reference prev_step).
+    The oracle's restatement is checked against both before the fixture is written."""
+    from types import SimpleNamespace
+    src = (REF / "motion_editor/p2p/null_text_optimization.py").read_text()
+    cls = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.ClassDef) and n.name == "MyNullInversion")
+    keep = {"prev_step", "get_noise_pred_single", "get_noise_pred", "null_optimization", "scheduler"}
+    cls.body = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in keep]
+
+    class _Bar:
+        def __init__(self, *a, **k): pass
+        def update(self, *a): pass
+        def close(self): pass
+
+    ns = {"Union": __import__("typing").Union, "torch": torch, "np": np, "nnf": torch.nn.functional, "Adam": torch.optim.Adam,
+          "tqdm": _Bar, "NUM_DDIM_STEPS": 2}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "ref_null_inversion", "exec"), ns)
+    d = ref_cpu.DDIM()
+
+    class Sched:
+        class config:
+            num_train_timesteps = 1000
+        num_inference_steps = 50
+        alphas_cumprod = d.alphas_cumprod
+        final_alpha_cumprod = d.alphas_cumprod[0]
+        timesteps = torch.tensor(d.timesteps)
+
+    g = torch.Generator().manual_seed(123)
+    f, h, w = 4, 8, 8
+    latents = [torch.randn(1, 4, f, h, w, generator=g) for _ in range(3)]          # stands for the inversion trajectory x_0 .. x_2
+    context = torch.randn(2, 77, 768, generator=g) * 0.3                              # [uncond, cond]
+    obj = ns["MyNullInversion"].__new__(ns["MyNullInversion"])
+    obj.model = SimpleNamespace(unet=lambda x, t, encoder_hidden_states=None, normal_infer=False: {"sample": quiet(unet, x, t, encoder_hidden_states, normal_infer=normal_infer).sample},
+                                scheduler=Sched)
+    obj.context = context
+    t0 = time.time()
+    ref_list = obj.null_optimization(latents, 2, 1e-5)
+    print(f"reference null_optimization (2 steps x 2 inner) {time.time()-t0:.1f}s")
+    # first inner step's gradient, with the reference pieces
+    unc = context[:1].clone().requires_grad_(True)
+    t = Sched.timesteps[0]
+    with torch.no_grad():
+        eps_c = obj.get_noise_pred_single(latents[-1], t, context[1:])
+    eps_u = obj.get_noise_pred_single(latents[-1], t, unc)
+    loss = torch.nn.functional.mse_loss(obj.prev_step(eps_u + 7.5 * (eps_c - eps_u), t, latents[-1]), latents[1])
+    loss.backward()
+    grads = []
+    mine = ref_cpu.null_optimization(sd, d, latents, context, 2, 1e-5, num_steps=2, grads=grads)
+    eg = relerr(grads[0], unc.grad)
+    # Adam's first update is lr * sign(g): elements whose gradient is at rounding level may flip; compare where |g| is not tiny
+    big = unc.grad.abs() > 1e-3 * unc.grad.abs().max()
+    ee = [float(((m - r).abs() * big).max()) for m, r in zip(mine, ref_list)]
+    print("null-text oracle vs reference: grad rel err", eg, " max |emb diff| on significant elements", ee, " first loss", float(loss))
+    assert eg < 1e-3 and max(ee) < 2e-3, (eg, ee)
+    np.savez_compressed(GOLD / "null_text.npz", latents=torch.stack(latents).numpy(), context=context.numpy(),
+                        uncond_out=torch.stack(ref_list).numpy(), grad0=unc.grad.numpy(), loss0=float(loss), oracle_grad_relerr=eg)
+    print("null_text.npz written")
+
+
 def inversion_goldens(unet, sd):
     """DDIM inversion (util.py:111-124 as inference.py:289-293 calls it): normal_infer UNet forward + next_step."""
     next_step = _ref_function(REF / "motion_editor/util.py", "next_step")
@@ -217,6 +279,9 @@ def main():
 
     if "--only-inversion" in sys.argv:
         inversion_goldens(unet, sd)
+        return
+    if "--only-null-text" in sys.argv:
+        null_text_golden(unet, sd)
         return
 
     from motion_editor.attn_control.fully_control import FullySelfAttentionControlMask

@@ -530,6 +530,48 @@ def ddim_loop(unet_sd: SD, ddim: DDIM, latent: torch.Tensor, num_inv_steps: int,
 # --------------------------------------------------------------------------------------------
 # P1: one denoising step (pipeline_motion_editor.py:603-648)
 # --------------------------------------------------------------------------------------------
+def null_optimization(unet_sd: SD, ddim: DDIM, latents: Sequence[torch.Tensor], context: torch.Tensor, null_inner_steps: int,
+                      epsilon: float, num_steps: Optional[int] = None, guidance: float = 7.5,
+                      grads: Optional[list] = None) -> List[torch.Tensor]:
+    """MyNullInversion.null_optimization (p2p/null_text_optimization.py:133-166): per DDIM step, a fresh Adam
+    (lr 1e-2 * (1 - i / 100)) pulls the unconditional embedding so that the guided prev_step of the current latent lands on
+    the inversion latent one step earlier; early stop at loss < epsilon + i * 2e-5; the latent then advances with the
+    optimised embedding.  The UNet runs with normal_infer=False whatever the caller asked for (:49-51, :54-58) -- sparse-causal
+    attn1 on batch 1 / 2.  latents = the DDIM inversion trajectory (x_0 ... x_T), context = [uncond, cond] (2, 77, 768).
+    num_steps: NUM_DDIM_STEPS of the reference (50); a shorter sweep uses the first num_steps timesteps.
+    grads: if a list, receives the gradient of every inner step (test hook, not part of the reference)."""
+    n = ddim.num_inference_steps if num_steps is None else num_steps
+    uncond, cond = context.chunk(2)
+    out = []
+    latent_cur = latents[-1]
+    for i in range(n):
+        uncond = uncond.clone().detach().requires_grad_(True)
+        opt = torch.optim.Adam([uncond], lr=1e-2 * (1.0 - i / 100.0))
+        latent_prev = latents[len(latents) - i - 2]
+        t = ddim.timesteps[i]
+        ca, cb = ddim.coeffs(t)
+        with torch.no_grad():
+            eps_c = unet_forward(unet_sd, latent_cur, t, cond)
+        for _ in range(null_inner_steps):
+            eps_u = unet_forward(unet_sd, latent_cur, t, uncond)
+            eps = eps_u + guidance * (eps_c - eps_u)
+            rec = ca * latent_cur + cb * eps                       # prev_step (:26-36)
+            loss = torch.nn.functional.mse_loss(rec, latent_prev)
+            opt.zero_grad()
+            loss.backward()
+            if grads is not None:
+                grads.append(uncond.grad.detach().clone())
+            opt.step()
+            if loss.item() < epsilon + i * 2e-5:
+                break
+        out.append(uncond[:1].detach())
+        with torch.no_grad():                                      # get_noise_pred(latent_cur, t, False, context) (:53-65)
+            e2 = unet_forward(unet_sd, torch.cat([latent_cur] * 2), t, torch.cat([uncond, cond]))
+            eu, ec = e2.chunk(2)
+            latent_cur = ca * latent_cur + cb * (eu + guidance * (ec - eu))
+    return out
+
+
 def denoise_step(unet_sd: SD, cn_sd: Optional[SD], ddim: DDIM, latents: torch.Tensor, t: int,
                  uncond: torch.Tensor, cond: torch.Tensor, ctrl_images: Optional[torch.Tensor],
                  spatial: Optional[SpatialEditor], temporal: Optional[TemporalEditor],

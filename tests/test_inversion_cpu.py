@@ -88,3 +88,22 @@ def test_normal_infer_rejects_editors_and_controlnet_residuals(emu, unet_sd_np):
     c = synth.make_case_inputs("two", B=4, f=8, h=16, w=16)
     with pytest.raises(NotImplementedError):
         unet(c["sample"], 1, c["ehs"], normal_infer=True, down_block_additional_residuals=c["down_res"], mid_block_additional_residual=c["mid_res"])
+
+
+def test_oracle_null_text_optimization_matches_the_reference_class_as_written():
+    """SURVEY.md 8f rank 1, the OTHER half: tests/golden/null_text.npz holds the unconditional embeddings that the reference's own
+    MyNullInversion.null_optimization (p2p/null_text_optimization.py:133-166, compiled from the reference file as written, with
+    NUM_DDIM_STEPS = 2) produces around the reference UNet, and the first inner step's gradient.  The oracle restatement must
+    land on them: the gradient to 1e-3, the embeddings wherever the gradient is above rounding level (Adam's first update is
+    lr * sign(g)).  The HIP path for this row (activation backward of the UNet) is not built yet; this pins its oracle."""
+    g = np.load(GOLD / "null_text.npz")
+    sd = {k: T(v) for k, v in synth.synth_state_dict(synth.unet_schema()).items()}
+    lat = [t for t in T(g["latents"])]
+    grads = []
+    out = ref_cpu.null_optimization(sd, ref_cpu.DDIM(), lat, T(g["context"]), 2, 1e-5, num_steps=2, grads=grads)
+    g0 = T(g["grad0"])
+    assert float((grads[0] - g0).norm() / g0.norm()) < 1e-3
+    big = g0.abs() > 1e-3 * g0.abs().max()
+    for mine, ref in zip(out, T(g["uncond_out"])):
+        assert float(((mine - ref).abs() * big).max()) < 2e-3
+    assert float((out[0] - T(g["context"])[:1]).abs().max()) > 5e-3      # the embedding did move
