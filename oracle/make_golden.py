@@ -206,6 +206,58 @@ def null_text_golden(unet, sd):
     print("null_text.npz written")
 
 
+def adapter_train_golden(unet, sd):
+    """The arithmetic of one adapter training step (train_adaptor.py:364-368): model_pred = unet(noisy_latents, t, ehs,
+    down_block_additional_residuals, mid_block_additional_residual).sample on ONE clip (batch 1: the adapter sees every row,
+    unet_2d_condition.py:482-485), loss = mse(model_pred, noise), backward.  The script itself is one accelerate loop and
+    cannot be executed piecewise, so the fixture holds what its lines 364-368 compute with the REFERENCE UNet: the loss and
+    the gradient of every controlnet_adapter parameter (norms of all, two tensors in full).  Checked against the oracle
+    (ref_cpu.unet_forward under autograd) before it is written."""
+    B, f, h, w = 1, 8, 8, 8
+    g = torch.Generator().manual_seed(77)
+    r16 = lambda x: x.half().float()   # fp16-representable inputs: the fixture stores them as fp16 without loss  # noqa: E731
+    noisy = r16(torch.randn(B, 4, f, h, w, generator=g))
+    noise = r16(torch.randn(B, 4, f, h, w, generator=g))
+    ehs = r16(torch.randn(B, 77, 768, generator=g) * 0.3)
+    sizes = [h, h, h, h // 2, h // 2, h // 2, h // 4, h // 4, h // 4, h // 8, h // 8, h // 8]
+    down = [r16(torch.randn(B, c, f, sizes[i], sizes[i], generator=g) * 0.3) for i, c in enumerate(synth.ADAPTER_CH)]
+    mid = r16(torch.randn(B, 1280, f, h // 8, w // 8, generator=g) * 0.3)
+    t = 501
+    names = [k for k in sd if k.startswith("controlnet_adapter.")]
+    unet.zero_grad(set_to_none=True)
+    for p_ in unet.parameters():
+        p_.requires_grad_(False)
+    ref_params = dict(unet.named_parameters())
+    for k in names:
+        ref_params[k].requires_grad_(True)
+    t0 = time.time()
+    pred = quiet(unet, noisy, torch.tensor(t), ehs, down_block_additional_residuals=down, mid_block_additional_residual=mid).sample
+    loss = torch.nn.functional.mse_loss(pred.float(), noise.float(), reduction="mean")
+    loss.backward()
+    print(f"reference adapter training forward+backward {time.time()-t0:.1f}s, loss {float(loss):.6f}")
+    ref_g = {k: ref_params[k].grad.detach().clone() for k in names}
+    # oracle
+    sd2 = dict(sd)
+    for k in names:
+        sd2[k] = sd[k].clone().requires_grad_(True)
+    pred2 = ref_cpu.unet_forward(sd2, noisy, t, ehs, down, mid)
+    loss2 = torch.nn.functional.mse_loss(pred2, noise)
+    gr = torch.autograd.grad(loss2, [sd2[k] for k in names])
+    tot = (sum(float((a - ref_g[k]).pow(2).sum()) for a, k in zip(gr, names)) / sum(float(ref_g[k].pow(2).sum()) for k in names)) ** 0.5
+    print("adapter-training oracle vs reference: loss", float(loss2), "vs", float(loss), " gradient rel err (all adapter parameters)", tot)
+    assert abs(float(loss2) - float(loss)) < 1e-4 * float(loss) and tot < 1e-3, (float(loss2), float(loss), tot)
+    full = ["controlnet_adapter.body.0.block2.weight", "controlnet_adapter.body.11.attn_self_temp.to_out.0.bias"]
+    full = [k for k in full if k in ref_g] or names[:2]
+    h16 = lambda x: x.numpy().astype(np.float16)  # noqa: E731
+    np.savez_compressed(GOLD / "adapter_train.npz", noisy=h16(noisy), noise=h16(noise), ehs=h16(ehs), mid=h16(mid), t=t,
+                        **{f"down{i}": h16(d_) for i, d_ in enumerate(down)}, loss=float(loss), names=np.array(names),
+                        grad_norms=np.array([float(ref_g[k].norm()) for k in names], dtype=np.float64),
+                        **{"full_" + str(i): ref_g[k].numpy() for i, k in enumerate(full)}, full_names=np.array(full), oracle_grad_relerr=tot)
+    for p_ in unet.parameters():
+        p_.requires_grad_(True)
+    print("adapter_train.npz written:", len(names), "adapter parameters")
+
+
 def inversion_goldens(unet, sd):
     """DDIM inversion (util.py:111-124 as inference.py:289-293 calls it): normal_infer UNet forward + next_step."""
     next_step = _ref_function(REF / "motion_editor/util.py", "next_step")
@@ -282,6 +334,9 @@ def main():
         return
     if "--only-null-text" in sys.argv:
         null_text_golden(unet, sd)
+        return
+    if "--only-adapter-train" in sys.argv:
+        adapter_train_golden(unet, sd)
         return
 
     from motion_editor.attn_control.fully_control import FullySelfAttentionControlMask

@@ -107,3 +107,27 @@ def test_oracle_null_text_optimization_matches_the_reference_class_as_written():
     for mine, ref in zip(out, T(g["uncond_out"])):
         assert float(((mine - ref).abs() * big).max()) < 2e-3
     assert float((out[0] - T(g["context"])[:1]).abs().max()) > 5e-3      # the embedding did move
+
+
+def test_oracle_adapter_training_gradients_match_the_reference_unet():
+    """the arithmetic of one adapter training step (train_adaptor.py:364-368 -- UNet forward with the
+    ControlNet residuals on one clip, mse against the noise, backward into controlnet_adapter.*) as the REFERENCE UNet computes
+    it under autograd (tests/golden/adapter_train.npz); the oracle must reproduce the loss and every parameter's gradient.
+    The HIP path for this row is not built; this pins its oracle."""
+    g = np.load(GOLD / "adapter_train.npz")
+    sd = {k: T(v) for k, v in synth.synth_state_dict(synth.unet_schema()).items()}
+    names = [str(n) for n in g["names"]]
+    for k in names:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    F32 = lambda k: T(g[k].astype(np.float32))   # inputs are stored as fp16 (they are fp16-representable)  # noqa: E731
+    down = [F32(f"down{i}") for i in range(12)]
+    pred = ref_cpu.unet_forward(sd, F32("noisy"), int(g["t"]), F32("ehs"), down, F32("mid"))
+    loss = torch.nn.functional.mse_loss(pred, F32("noise"))
+    assert abs(float(loss) - float(g["loss"])) < 1e-4 * float(g["loss"])
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    norms = np.array([float(x.norm()) for x in grads])
+    assert np.allclose(norms, g["grad_norms"], rtol=1e-3, atol=1e-9)
+    for i, k in enumerate(str(n) for n in g["full_names"]):
+        want = T(g[f"full_{i}"])
+        got = grads[names.index(k)]
+        assert float((got - want).norm() / want.norm().clamp_min(1e-30)) < 1e-3
