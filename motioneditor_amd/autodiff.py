@@ -1,0 +1,233 @@
+"""Reverse-mode tape over the C-ABI operators: the host side of the input-gradient (activation) backward that the
+null-text optimisation needs (reference: p2p/null_text_optimization.py:133-166 differentiates the guided prev_step loss
+w.r.t. the unconditional text embedding through the whole UNet with torch autograd).
+
+The forward launch graph (models/graph.py) stays as it is.  While a tape is recording, every operator call that has a
+backward rule is logged with the tensors it read and wrote; `backward()` then walks the log in reverse and calls the
+operator's `*_bwd` / `*_dx` primitive of the same backend.  Gradients live in one fp32 buffer per ALLOCATION (a fused
+q|k|v tensor, a skip-concat buffer, ...): a view's gradient is the same view of its allocation's buffer, so column slices
+and `out=` targets accumulate where they belong without any graph surgery.
+
+The primitives (`ops.gemm_dx`, `ops.geglu_bwd`, `ops.attention_bwd`, `ops.temporal_attention_bwd`, `ops.groupnorm_bwd`,
+`ops.layernorm_bwd`) are the kernel-level contract of the backward pass.  tests/emu_ops.py implements them on the CPU
+(each as the vector-Jacobian product of its forward emulation) and pins this module, through `util.null_optimization`,
+against the reference's own optimisation (tests/golden/null_text.npz).  The HIP kernels behind them are not built yet:
+on a GPU the primitives raise, loudly -- there is no fallback.
+
+Restrictions (asserted): single assignment -- no allocation region is written twice while recording (true for the
+single-branch UNet forward; the in-place motion / ControlNet residual adds of the two-branch step are not differentiated).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+
+class Tape:
+    def __init__(self):
+        self.entries: List[Tuple[Sequence[torch.Tensor], Callable]] = []
+        self.keep: List[torch.Tensor] = []   # every tensor a rule needs stays alive (and un-recycled) until the tape dies
+
+    def record(self, outs: Sequence[torch.Tensor], rule: Callable, *saved: Optional[torch.Tensor]) -> None:
+        self.entries.append((tuple(outs), rule))
+        self.keep.extend(t for t in saved if t is not None)
+        self.keep.extend(outs)
+
+
+def _base(t: torch.Tensor) -> torch.Tensor:
+    """The allocation `t` lives in.  Operator outputs are fresh contiguous 2-D allocations (or `out=` views of one) on the GPU;
+    the CPU emulation sometimes returns a view of a permuted temporary -- such a tensor counts as its own allocation."""
+    b = t._base
+    return b if (b is not None and b.is_contiguous()) else t
+
+
+class Grads:
+    """fp32 gradient buffers, one per allocation; `view(t)` is the part of it that `t` covers."""
+
+    def __init__(self):
+        self.buf: Dict[int, torch.Tensor] = {}
+        self.keep: List[torch.Tensor] = []
+
+    def has(self, t: torch.Tensor) -> bool:
+        return id(_base(t)) in self.buf
+
+    def view(self, t: torch.Tensor) -> torch.Tensor:
+        b = _base(t)
+        g = self.buf.get(id(b))
+        if g is None:
+            g = torch.zeros(b.shape, dtype=torch.float32, device=b.device)
+            self.buf[id(b)] = g
+            self.keep.append(b)          # keeps id(b) unique for the life of the buffers
+        if b is t:
+            return g
+        return g.as_strided(t.shape, t.stride(), t.storage_offset() - b.storage_offset())
+
+    def add(self, t: Optional[torch.Tensor], g: torch.Tensor) -> None:
+        if t is None:
+            return
+        v = self.view(t)
+        if g.dim() == 2 and v.dim() == 2:
+            v[:g.shape[0], :g.shape[1]].add_(g.float())
+        else:
+            v.add_(g.float().reshape(v.shape))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operator rules: (backend, grads) -> None, closed over what the forward call saw
+# ---------------------------------------------------------------------------------------------------------------------
+def _rule_gemm(B, x, w, out, kw):
+    def rule(G: Grads):
+        N, taps, K = w.shape
+        dy = G.view(out)
+        M = out.shape[0]
+        if kw.get("act", 0):
+            raise NotImplementedError("autodiff: gemm with an activation epilogue lies on no differentiated path")
+        for r in (kw.get("res"), kw.get("res2")):           # epilogue residual adds: the gradient passes straight through
+            if r is not None:
+                G.add(r[:M, :dy.shape[1]], dy)
+        alpha = kw.get("alpha", 1.0)
+        if kw.get("geglu"):
+            # y = value * gelu(gate) of the biased pre-activation: recompute it (one GEMM) instead of stashing [M, N] per layer
+            pre = B.gemm(x, w, M=kw.get("M"), bias=kw.get("bias"))
+            dpre = B.geglu_bwd(pre, dy)
+        else:
+            dpre = dy
+        dx = B.gemm_dx(dpre, w, x_rows=x.shape[0], M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
+        G.add(x[:, :K], dx)
+    return rule
+
+
+def _rule_attention(B, q, k, v, out, kw):
+    def rule(G: Grads):
+        dq, dk, dv = B.attention_bwd(q, k, v, out, G.view(out), **kw)
+        G.add(q, dq)
+        G.add(k, dk)
+        G.add(v, dv)
+    return rule
+
+
+def _rule_tattn(B, q, k, v, out, kw):
+    def rule(G: Grads):
+        dq, dk, dv = B.temporal_attention_bwd(q, k, v, out, G.view(out), **kw)
+        G.add(q, dq)
+        G.add(k, dk)
+        G.add(v, dv)
+    return rule
+
+
+def _rule_groupnorm(B, x, gamma, beta, out, kw):
+    def rule(G: Grads):
+        if kw.get("reduce") is not None:
+            raise NotImplementedError("autodiff: frame-sharded GroupNorm is not differentiated")
+        G.add(x, B.groupnorm_bwd(x, gamma, beta, G.view(out), rows_per_group=kw["rows_per_group"], eps=kw["eps"], silu=kw["silu"], groups=kw.get("groups", 32)))
+    return rule
+
+
+def _rule_layernorm(B, x, gamma, out, eps):
+    def rule(G: Grads):
+        G.add(x, B.layernorm_bwd(x, gamma, G.view(out), eps=eps))
+    return rule
+
+
+class Recorder:
+    """Stands in for the `ops` module of models/graph.py while a tape records: same functions, same results, plus the log."""
+
+    def __init__(self, backend, tape: Tape):
+        self._b, self._t = backend, tape
+        self._written: Dict[int, List[Tuple[int, int, int, int]]] = {}
+
+    def __getattr__(self, name):
+        return getattr(self._b, name)
+
+    # -- single-assignment check: (row0, row1, col0, col1) boxes written per allocation must not overlap
+    def _mark(self, t: torch.Tensor) -> None:
+        b = _base(t)
+        off = t.storage_offset() - b.storage_offset()
+        ld = t.stride(0) if t.dim() == 2 else t.shape[-1]
+        r0, c0 = (off // ld, off % ld) if ld else (0, 0)
+        box = (r0, r0 + t.shape[0], c0, c0 + (t.shape[1] if t.dim() == 2 else ld))
+        for o in self._written.setdefault(id(b), []):
+            if box[0] < o[1] and o[0] < box[1] and box[2] < o[3] and o[2] < box[3]:
+                raise RuntimeError("autodiff: a tensor region is written twice while recording (the tape assumes single assignment)")
+        self._written[id(b)].append(box)
+        self._t.keep.append(b)
+
+    @staticmethod
+    def _own(out, kw):
+        """An output that is not an `out=` target must be an allocation of its own (the CPU emulation may hand back a view)."""
+        return out if (kw.get("out") is not None or out._base is None) else out.contiguous().clone()
+
+    def gemm(self, x, w, **kw):
+        out = self._own(self._b.gemm(x, w, **kw), kw)
+        self._mark(out)
+        self._t.record([out], _rule_gemm(self._b, x, w, out, kw), x, w, kw.get("res"), kw.get("res2"), kw.get("bias"))
+        return out
+
+    def attention(self, q, k, v, **kw):
+        out = self._own(self._b.attention(q, k, v, **kw), kw)
+        self._mark(out)
+        kw = {a: b for a, b in kw.items() if a != "out"}
+        self._t.record([out], _rule_attention(self._b, q, k, v, out, kw), q, k, v, kw.get("mask"))
+        return out
+
+    def temporal_attention(self, q, k, v, **kw):
+        out = self._own(self._b.temporal_attention(q, k, v, **kw), kw)
+        self._mark(out)
+        self._t.record([out], _rule_tattn(self._b, q, k, v, out, kw), q, k, v)
+        return out
+
+    def groupnorm(self, x, gamma, beta, **kw):
+        out = self._own(self._b.groupnorm(x, gamma, beta, **kw), kw)
+        self._mark(out)
+        self._t.record([out], _rule_groupnorm(self._b, x, gamma, beta, out, {a: b for a, b in kw.items() if a != "out"}), x, gamma, beta)
+        return out
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        out = self._own(self._b.layernorm(x, gamma, beta, eps), {})
+        self._mark(out)
+        self._t.record([out], _rule_layernorm(self._b, x, gamma, out, eps), x, gamma)
+        return out
+
+    def copy_rows(self, y, x):
+        out = self._b.copy_rows(y, x)
+        self._mark(y)
+        self._t.record([y], lambda G: G.add(x, G.view(y)), x)
+        return out
+
+    def axpy_rows(self, y, x, a_, alpha=1.0):
+        if _base(y) is _base(x):
+            raise RuntimeError("autodiff: in-place axpy_rows is not differentiated")
+        out = self._b.axpy_rows(y, x, a_, alpha)
+        self._mark(y)
+        self._t.record([y], lambda G: (G.add(x, G.view(y)), G.add(a_, G.view(y) * alpha)), x, a_)
+        return out
+
+
+class record:
+    """`with autodiff.record(graph) as tape:` -- the module's `ops` is a Recorder for the duration."""
+
+    def __init__(self, module):
+        self.m = module
+
+    def __enter__(self) -> Tape:
+        self.tape = Tape()
+        self.saved = self.m.ops
+        self.m.ops = Recorder(self.saved, self.tape)
+        return self.tape
+
+    def __exit__(self, *exc):
+        self.m.ops = self.saved
+        return False
+
+
+def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> Grads:
+    """seeds: (tensor the forward produced, gradient of the loss w.r.t. it).  Returns the gradient store; `G.view(t)` of any
+    tensor the forward read is its gradient (zeros if nothing depended on it)."""
+    G = Grads()
+    for t, g in seeds:
+        G.add(t, g)
+    for outs, rule in reversed(tape.entries):
+        if any(G.has(o) for o in outs):
+            rule(G)
+    return G

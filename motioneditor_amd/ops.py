@@ -389,3 +389,41 @@ def rows_to_nchw5(rows: torch.Tensor, B: int, Cc: int, f: int, h: int, w: int) -
         capi.check(capi.lib().me_rows_to_nchw(out[b].data_ptr(), h * w, f * h * w, rows[b * f * h * w:].data_ptr(), rows.stride(0), f, Cc, h * w, _stream()),
                    "me_rows_to_nchw")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Backward primitives (the kernel-level contract of motioneditor_amd/autodiff.py; SURVEY.md 8f rank 1 "null-text" and rank 4
+# "adapter training").  Their CPU statements live in tests/emu_ops.py and are pinned, through util.null_optimization, against
+# the reference's own optimisation.  The HIP kernels are not built yet: these entries fail loudly -- no fallback.
+# ---------------------------------------------------------------------------------------------------------------------
+def _no_kernel(name: str):
+    raise NotImplementedError(f"ops.{name}: the backward kernel is not built yet (DESIGN.md section 9); there is no CPU fallback")
+
+
+def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
+    """dX [x_rows, K] of me_gemm's y = alpha * gather(x) @ w^T: me_gemm on [K][taps][N]-repacked, tap-flipped weights
+    (dense / stride-1 3x3 / TemporalConv); a zero-insertion gather for the stride-2 convolution, a 2x2 sum for the upsampled one."""
+    _no_kernel("gemm_dx")
+
+
+def geglu_bwd(pre, dy):
+    """d(pre-activation) [M, N] from dy [M, N/2], pre in the packed (16 value | 16 gate) column order."""
+    _no_kernel("geglu_bwd")
+
+
+def attention_bwd(q, k, v, out, dout, **kw):
+    """(dq, dk, dv) of me_attn for plain segments: recompute S and P per tile, dV = P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dO * O)),
+    dQ = dS K, dK = dS^T Q; dk / dv accumulate over every query item that names the kv item."""
+    _no_kernel("attention_bwd")
+
+
+def temporal_attention_bwd(q, k, v, out, dout, **kw):
+    _no_kernel("temporal_attention_bwd")
+
+
+def groupnorm_bwd(x, gamma, beta, dy, *, rows_per_group, eps, silu, groups=32):
+    _no_kernel("groupnorm_bwd")
+
+
+def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
+    _no_kernel("layernorm_bwd")

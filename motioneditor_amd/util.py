@@ -60,3 +60,70 @@ def ddim_inversion(pipeline, ddim_scheduler, video_latent: torch.Tensor, num_inv
                    text_embeddings: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """util.py:127-130."""
     return ddim_loop(pipeline, ddim_scheduler, video_latent, num_inv_steps, prompt, normal_infer=normal_infer, text_embeddings=text_embeddings)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Null-text optimisation (p2p/null_text_optimization.py:133-166; inference.py:277-287 runs it before the editing loop)
+# ---------------------------------------------------------------------------------------------------------------------
+def null_optimization(pipeline, ddim_scheduler, latents, context: torch.Tensor, null_inner_steps: int = 10, epsilon: float = 1e-5,
+                      num_ddim_steps: Optional[int] = None, guidance_scale: float = 7.5, grads: Optional[list] = None) -> List[torch.Tensor]:
+    """MyNullInversion.null_optimization: for each DDIM step a fresh Adam (lr 1e-2 (1 - i / 100)) moves the unconditional text
+    embedding so that the guided prev_step of the current latent reproduces the inversion latent one step earlier; early stop at
+    loss < epsilon + 2e-5 i; the latent then advances with the optimised embedding.  latents = the DDIM inversion trajectory
+    (util.ddim_inversion), context = [uncond, cond] (2, 77, 768).  Returns the list of optimised [1, 77, 768] embeddings
+    (what the pipeline takes as `uncond_embeddings`).
+
+    The reference differentiates with torch autograd; here the forward is the same launch graph as everywhere else and the
+    gradient comes from motioneditor_amd.autodiff (a tape over the C-ABI operators and their backward primitives).  As in the
+    reference (`:49-51` hard-codes it) the UNet runs with normal_infer=False -- sparse-causal attn1 -- and without editors."""
+    from . import autodiff
+    from .models import graph
+    unet = pipeline.unet
+    dev = unet.device
+    n = len(ddim_scheduler.timesteps) if num_ddim_steps is None else num_ddim_steps
+    uncond, cond = context.to(dev).float().chunk(2)
+    out: List[torch.Tensor] = []
+    latent_cur = latents[-1].to(dev).float()
+
+    def eps_of(lat, emb, tape_on=False):
+        # the rows the UNet projects to K / V: handed over as OUR allocation, so that the gradient store can be asked for it
+        rows = emb.to(unet.P.dtype).reshape(-1, emb.shape[-1]).contiguous().clone()
+        if not tape_on:
+            return graph.unet_forward(unet.P, lat, float(t), rows), None, None
+        with autodiff.record(graph) as tape:
+            act = graph.unet_forward(unet.P, lat, float(t), rows)
+        return act, tape, rows
+
+    B, _, f, h, w = latent_cur.shape
+    for i in range(n):
+        uncond = uncond.clone().detach().requires_grad_(True)
+        opt = torch.optim.Adam([uncond], lr=1e-2 * (1.0 - i / 100.0))
+        latent_prev = latents[len(latents) - i - 2].to(dev).float()
+        t = ddim_scheduler.timesteps[i]
+        ca, cb = ddim_scheduler.coeffs(int(t))
+        eps_c = graph.ops.rows_to_nchw5(eps_of(latent_cur, cond)[0].t, B, 4, f, h, w).float()
+        for _ in range(null_inner_steps):
+            act, tape, text = eps_of(latent_cur, uncond.detach(), tape_on=True)
+            eps_u = graph.ops.rows_to_nchw5(act.t, B, 4, f, h, w).float()
+            rec = ca * latent_cur + cb * (eps_u + guidance_scale * (eps_c - eps_u))          # prev_step (:26-36)
+            diff = rec - latent_prev
+            loss = float((diff * diff).mean())
+            # d loss / d eps_u, back in the row layout of the UNet output: [(b f h w), 4]
+            d_eps = (2.0 / diff.numel()) * diff * (cb * (1.0 - guidance_scale))
+            d_rows = d_eps.permute(0, 2, 3, 4, 1).reshape(-1, 4)
+            G = autodiff.backward(tape, [(act.t, d_rows)])
+            g = G.view(text).reshape(uncond.shape).to(uncond.dtype)
+            if grads is not None:
+                grads.append(g.clone())
+            opt.zero_grad()
+            uncond.grad = g
+            opt.step()
+            del tape, G
+            if loss < epsilon + i * 2e-5:
+                break
+        out.append(uncond[:1].detach().clone())
+        both = graph.unet_forward(unet.P, torch.cat([latent_cur] * 2), float(t), torch.cat([uncond.detach(), cond]))
+        e2 = graph.ops.rows_to_nchw5(both.t, 2 * B, 4, f, h, w).float()
+        eu, ec = e2.chunk(2)
+        latent_cur = ca * latent_cur + cb * (eu + guidance_scale * (ec - eu))
+    return out

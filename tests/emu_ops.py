@@ -273,3 +273,52 @@ def nchw_to_rows(x, n_img, C, npix, img_stride, ch_stride):
         for c in range(C):
             out[i * npix:(i + 1) * npix, c] = flat[i * img_stride + c * ch_stride: i * img_stride + c * ch_stride + npix]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward primitives (motioneditor_amd/autodiff.py): each is the vector-Jacobian product of its forward emulation above,
+# taken with torch autograd -- the CPU statement of what the backward kernels have to compute.
+# ---------------------------------------------------------------------------------------------------------------------
+def _leaf(t):
+    return t.detach().float().clone().requires_grad_(True)
+
+
+def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
+    """dX [x_rows, K] of y = alpha * gather(x) @ w^T (any gather mode): linear in x, so the point of linearisation is irrelevant."""
+    K = w.shape[2]
+    x0 = torch.zeros((x_rows, K), dtype=torch.float32, requires_grad=True)
+    y = gemm(x0, w.float(), M=M, alpha=alpha, conv=conv, tconv=tconv)
+    return torch.autograd.grad(y, x0, dy.float()[:y.shape[0], :y.shape[1]])[0]
+
+
+def geglu_bwd(pre, dy):
+    """pre: biased pre-activation [M, N] in the packed (16 value | 16 gate) column order; dy [M, N/2] -> d pre [M, N]."""
+    p0 = _leaf(pre)
+    M, N = p0.shape
+    q = p0.reshape(M, N // 32, 2, 16)
+    y = (q[:, :, 0] * F.gelu(q[:, :, 1])).reshape(M, N // 2)
+    return torch.autograd.grad(y, p0, dy.float())[0]
+
+
+def attention_bwd(q, k, v, out, dout, **kw):
+    q0, k0, v0 = _leaf(q), _leaf(k), _leaf(v)
+    y = attention(q0, k0, v0, **kw)
+    return torch.autograd.grad(y, (q0, k0, v0), dout.float())
+
+
+def temporal_attention_bwd(q, k, v, out, dout, **kw):
+    q0, k0, v0 = _leaf(q), _leaf(k), _leaf(v)
+    y = temporal_attention(q0, k0, v0, **kw)
+    return torch.autograd.grad(y, (q0, k0, v0), dout.float())
+
+
+def groupnorm_bwd(x, gamma, beta, dy, *, rows_per_group, eps, silu, groups=32):
+    x0 = _leaf(x)
+    y = groupnorm(x0, gamma, beta, rows_per_group=rows_per_group, eps=eps, silu=silu, groups=groups)
+    return torch.autograd.grad(y, x0, dy.float())[0]
+
+
+def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
+    x0 = _leaf(x)
+    y = layernorm(x0, gamma, torch.zeros_like(gamma), eps)
+    return torch.autograd.grad(y, x0, dy.float())[0]

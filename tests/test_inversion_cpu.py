@@ -131,3 +131,28 @@ def test_oracle_adapter_training_gradients_match_the_reference_unet():
         want = T(g[f"full_{i}"])
         got = grads[names.index(k)]
         assert float((got - want).norm() / want.norm().clamp_min(1e-30)) < 1e-3
+
+
+def test_null_optimization_on_the_emulated_abi_matches_the_reference_golden(monkeypatch, unet_sd_np):
+    """The product's null-text optimisation -- util.null_optimization: the ordinary launch graph recorded on a tape
+    (motioneditor_amd/autodiff.py), the backward primitives of the emulated ABI, Adam on the embedding -- against the
+    reference class as written (tests/golden/null_text.npz): first gradient and the optimised embeddings of 2 steps x 2 inner."""
+    import motioneditor_amd.models.unet_2d_condition as u
+    for m in (graph, u, util):
+        monkeypatch.setattr(m, "ops", emu_ops)
+    g = np.load(GOLD / "null_text.npz")
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    sched = DDIMScheduler()
+    sched.set_timesteps(50)
+
+    class Pipe:
+        pass
+    pipe = Pipe()
+    pipe.unet = unet
+    grads = []
+    out = util.null_optimization(pipe, sched, [t for t in T(g["latents"])], T(g["context"]), 2, 1e-5, num_ddim_steps=2, grads=grads)
+    g0 = T(g["grad0"])
+    assert float((grads[0] - g0).norm() / g0.norm()) < 1e-3
+    big = g0.abs() > 1e-3 * g0.abs().max()
+    for mine, ref in zip(out, T(g["uncond_out"])):
+        assert float(((mine - ref).abs() * big).max()) < 2e-3
