@@ -400,10 +400,59 @@ def _no_kernel(name: str):
     raise NotImplementedError(f"ops.{name}: the backward kernel is not built yet (DESIGN.md section 9); there is no CPU fallback")
 
 
+_wT_cache = {}
+
+
+def _w_transposed(w: torch.Tensor) -> torch.Tensor:
+    """[N][taps][K] -> [K][taps reversed][N] (padded to N % 8 == 0): the weights of the input-gradient GEMM / correlation.  Built
+    once per weight tensor (a transpose of constants at first use) and kept: the backward doubles the weight memory."""
+    key = (w.data_ptr(), tuple(w.shape))
+    hit = _wT_cache.get(key)
+    if hit is None:
+        N, taps, K = w.shape
+        n8 = (N + 7) // 8 * 8
+        t = torch.zeros((K, taps, n8), dtype=w.dtype, device=w.device)
+        t[:, :, :N] = w.flip(1).permute(2, 1, 0)
+        hit = _wT_cache[key] = (t.contiguous(), w)   # keep w alive: the key is its address
+    return hit[0]
+
+
 def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
-    """dX [x_rows, K] of me_gemm's y = alpha * gather(x) @ w^T: me_gemm on [K][taps][N]-repacked, tap-flipped weights
-    (dense / stride-1 3x3 / TemporalConv); a zero-insertion gather for the stride-2 convolution, a 2x2 sum for the upsampled one."""
-    _no_kernel("gemm_dx")
+    """dX [x_rows, K] of me_gemm's y = alpha * gather(x) @ w^T, by me_gemm itself on [K][taps reversed][N] weights: a dense GEMM,
+    the same stride-1 3x3 correlation / TemporalConv with the taps reversed; the stride-2 convolution's input gradient is that
+    correlation over the zero-upsampled dy, the nearest-upsampled convolution's the 2x2 sum of it.  dy arrives in fp32 from the
+    tape (loss-scaled by the caller so that fp16 holds it) and is rounded to fp16 like every activation."""
+    N, taps, K = w.shape
+    wt = _w_transposed(w)
+    n8 = wt.shape[2]
+    d16 = torch.zeros((dy.shape[0], n8), dtype=F16, device=dy.device) if n8 != dy.shape[1] else None
+    if d16 is None:
+        d16 = dy.to(F16)
+    else:
+        d16[:, :dy.shape[1]] = dy
+    if conv is not None:
+        Hin, Win, Hout, Wout, stride, ups = conv[:6]
+        if len(conv) > 6 and conv[6]:
+            raise NotImplementedError("gemm_dx: the pad-(0,1,0,1) convolution (VAE encoder) is not differentiated")
+        n_img = M // (Hout * Wout)
+        if stride == 2:      # dX = corr(zero-upsample(dy), reversed taps) at the input resolution (pad 1, kernel 3)
+            up = torch.zeros((n_img, Hin, Win, n8), dtype=F16, device=dy.device)
+            up[:, ::2, ::2] = d16.reshape(n_img, Hout, Wout, n8)
+            return gemm(up.reshape(-1, n8), wt, alpha=alpha, conv=(Hin, Win, Hin, Win, 1, 0))
+        du = gemm(d16, wt, alpha=alpha, conv=(Hout, Wout, Hout, Wout, 1, 0))
+        if ups:              # y = conv(nearest2x(x)): every input pixel collects its 2 x 2 block
+            return du.float().reshape(n_img, Hin, 2, Win, 2, K).sum(dim=(2, 4)).reshape(-1, K)
+        return du
+    if tconv is not None:
+        if len(tconv) > 3:
+            raise NotImplementedError("gemm_dx: the frame-sharded TemporalConv is not differentiated")
+        return gemm(d16, wt, alpha=alpha, tconv=tuple(tconv))
+    dx = gemm(d16, wt, alpha=alpha)
+    if x_rows > dx.shape[0]:
+        full = torch.zeros((x_rows, K), dtype=dx.dtype, device=dx.device)
+        full[:dx.shape[0]] = dx
+        return full
+    return dx
 
 
 def geglu_bwd(pre, dy):

@@ -482,3 +482,30 @@ def test_groupnorm_with_cross_rank_statistic_reduction_hook(ops):
     gm, bt = (1 + 0.1 * rnd(C, seed=2)).half(), (0.1 * rnd(C, seed=3)).half()
     got = ops.groupnorm(cu(x), cu(gm), cu(bt), rows_per_group=rpg, eps=1e-5, silu=True, reduce=lambda st: st.mul_(2.0), rows_per_group_total=2 * rpg)
     check(got, emu.groupnorm(x, gm, bt, rows_per_group=rpg, eps=1e-5, silu=True), "groupnorm split stats/apply")
+
+
+# ------------------------------------------------------------------ backward primitives (motioneditor_amd/autodiff.py)
+@pytest.mark.parametrize("mode", ["dense", "dense_n4", "conv", "conv_s2", "conv_ups", "tconv", "geglu_w"])
+def test_gemm_dx_matches_the_vjp_of_the_forward_emulation(ops, mode):
+    """Input gradient of me_gemm in every gather mode the UNet uses, computed by me_gemm itself on transposed / tap-reversed weights
+    (the stride-2 case over a zero-upsampled dy, the upsampled case with a 2 x 2 sum) vs torch autograd through the forward emulation."""
+    g = torch.Generator().manual_seed(5)
+    conv = tconv = None
+    if mode in ("dense", "geglu_w"):
+        M, N, K, taps, xr = 384, 320 if mode == "dense" else 640, 192, 1, 384
+    elif mode == "dense_n4":
+        M, N, K, taps, xr = 256, 4, 320, 1, 256
+    elif mode == "conv":
+        M, N, K, taps, xr, conv = 2 * 16 * 16, 128, 64, 9, 2 * 16 * 16, (16, 16, 16, 16, 1, 0)
+    elif mode == "conv_s2":
+        M, N, K, taps, xr, conv = 2 * 8 * 8, 128, 64, 9, 2 * 16 * 16, (16, 16, 8, 8, 2, 0)
+    elif mode == "conv_ups":
+        M, N, K, taps, xr, conv = 2 * 16 * 16, 128, 64, 9, 2 * 8 * 8, (8, 8, 16, 16, 1, 1)
+    else:
+        M, N, K, taps, xr, tconv = 2 * 8 * 12, 128, 64, 3, 2 * 8 * 12, (8, 12, 8)
+    w = (torch.randn(N, taps, K, generator=g) * (taps * K) ** -0.5).half()
+    dy = torch.randn(M, N, generator=g)
+    want = emu.gemm_dx(dy.half().float(), w, x_rows=xr, M=M, conv=conv, tconv=tconv)
+    got = ops.gemm_dx(cu(dy), cu(w), x_rows=xr, M=M, conv=conv, tconv=tconv)
+    assert tuple(got.shape) == tuple(want.shape)
+    check(got, want, f"gemm_dx {mode}")
