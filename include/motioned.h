@@ -265,6 +265,21 @@ int me_rows_to_nchw(float* Y, int64_t img_stride, int64_t ch_stride, const void*
  * cols % 8 == 0, cols <= 8192; X and Y may alias. */
 int me_softmax_rows(void* Y, int32_t ldy, const void* X, int32_t ldx, int64_t rows, int32_t cols, void* stream);
 
+/* ---- backward (input-gradient) primitives ---------------------------------------------------- *
+ * What motioneditor_amd/autodiff.py calls for the null-text optimisation (p2p/null_text_optimization.py:133-166 differentiates
+ * the guided prev_step loss through these layers with torch autograd).  Gradients are fp32 [rows, ld] views, activations fp16.
+ * The input gradient of me_gemm needs no entry of its own: it is me_gemm on transposed, tap-reversed weights.
+ */
+/* GEGLU (attention_2d.py FeedForward/GEGLU): pre = biased pre-activation [M, N] fp16 in the packed (16 value | 16 gate) column
+ * order, dy fp32 [M, N/2] -> dpre fp16 [M, N] */
+int me_geglu_bwd(void* dpre, int32_t ldd, const void* pre, int32_t ldp, const void* dy, int32_t lddy, int64_t M, int32_t N, void* stream);
+/* nn.LayerNorm: dx fp32 [rows, C] from x fp16, gamma fp16, dy fp32 */
+int me_layernorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* dy, int32_t lddy, int64_t rows, int32_t C, float eps,
+                     void* stream);
+/* GroupNorm (+ SiLU when silu != 0; statistics over rows_per_group rows x C/groups channels, as me_groupnorm): dx fp32 */
+int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* beta, const void* dy, int32_t lddy, int64_t rows,
+                     int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

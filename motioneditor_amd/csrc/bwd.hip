@@ -1,0 +1,168 @@
+// Backward (input-gradient) kernels of the element-wise / normalisation operators: what motioneditor_amd/autodiff.py calls for
+// the null-text optimisation (reference p2p/null_text_optimization.py:133-166 differentiates through these layers with torch
+// autograd).  Gradients travel in fp32 (the tape's buffers; strided views of them arrive with their row stride), activations in
+// fp16 as in the forward.  First, straightforward versions: these run a few times per optimisation step on a batch-1 clip and are
+// HBM-bound at worst; they have not been tuned.
+#include "me_common.h"
+#include "../../include/motioned.h"
+
+extern "C" void me_set_error(const char* msg);
+extern "C" void me_set_hip_error(const char* what, int err);
+
+namespace {
+
+__device__ __forceinline__ float gelu_erf_grad(float g) {   // d/dg [g Phi(g)] = Phi(g) + g phi(g)
+  const float cdf = 0.5f * (1.0f + erff(g * 0.70710678118654752f));
+  return cdf + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+// GEGLU: pre [M][N] fp16 in the packed (16 value | 16 gate) column order, dy [M][N/2] fp32 -> dpre [M][N] fp16
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ pre, int ldp, const float* __restrict__ dy, int lddy, f16* __restrict__ dpre, int ldd,
+                                                        long M, int N) {
+  const long total = M * (N / 2);
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long m = idx / (N / 2);
+    const int c = (int)(idx - m * (N / 2));
+    const int b = c >> 4, j = c & 15;
+    const float val = (float)pre[m * ldp + 32 * b + j], gate = (float)pre[m * ldp + 32 * b + 16 + j];
+    const float d = dy[m * lddy + c];
+    dpre[m * ldd + 32 * b + j] = (f16)(d * gelu_erf_f(gate));
+    dpre[m * ldd + 32 * b + 16 + j] = (f16)(d * val * gelu_erf_grad(gate));
+  }
+}
+
+// LayerNorm: one wave per row.  xhat = (x - mean) rstd, g = dy gamma, dx = rstd (g - mean(g) - xhat mean(g xhat))
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restrict__ X, int ldx, const f16* __restrict__ gamma, const float* __restrict__ dY, int lddy,
+                                                            float* __restrict__ dX, int lddx, long rows, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* x = X + row * ldx;
+  const float* dy = dY + row * lddy;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += (float)x[c];
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float d = (float)x[c] - mean;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  float a = 0.f, b = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dy[c] * (float)gamma[c], xh = ((float)x[c] - mean) * rstd;
+    a += g;
+    b += g * xh;
+  }
+  const float ma = wave_sum(a) / (float)C, mb = wave_sum(b) / (float)C;
+  float* dx = dX + row * lddx;
+  for (int c = lane; c < C; c += 64) {
+    const float g = dy[c] * (float)gamma[c], xh = ((float)x[c] - mean) * rstd;
+    dx[c] = rstd * (g - ma - xh * mb);
+  }
+}
+
+// GroupNorm (+ SiLU): one block per (sample group, channel group); three sweeps over the group's rows_per_group x cg elements
+// (statistics; the two gradient sums; apply), fp64 block reductions.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const f16* __restrict__ X, int ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                            const float* __restrict__ dY, int lddy, float* __restrict__ dX, int lddx, int rows_per_group, int C,
+                                                            int groups, float eps, int silu) {
+  __shared__ double red[256];
+  const int sg = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = C / groups, c0 = g * cg;
+  const long r0 = (long)sg * rows_per_group;
+  const long n = (long)rows_per_group * cg;
+  double s = 0.0, q = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const long r = i / cg;
+    const int c = (int)(i - r * cg);
+    const double v = (double)(float)X[(r0 + r) * ldx + c0 + c];
+    s += v;
+    q += v * v;
+  }
+  const double S = block_sum(s, red), Q = block_sum(q, red);
+  const double mean_d = S / (double)n;
+  const float mean = (float)mean_d, rstd = rsqrtf(fmaxf((float)(Q / (double)n - mean_d * mean_d), 0.f) + eps);
+  auto grad_in = [&](long r, int c, float& xh) {   // dL/d(gamma xhat + beta) * gamma
+    xh = ((float)X[(r0 + r) * ldx + c0 + c] - mean) * rstd;
+    const float gm = (float)gamma[c0 + c];
+    float d = dY[(r0 + r) * lddy + c0 + c];
+    if (silu) {
+      const float y = xh * gm + (float)beta[c0 + c];
+      const float sig = 1.0f / (1.0f + __expf(-y));
+      d *= sig * (1.0f + y * (1.0f - sig));
+    }
+    return d * gm;
+  };
+  double a = 0.0, b = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const long r = i / cg;
+    const int c = (int)(i - r * cg);
+    float xh;
+    const float gi = grad_in(r, c, xh);
+    a += gi;
+    b += (double)gi * xh;
+  }
+  const float ma = (float)(block_sum(a, red) / (double)n), mb = (float)(block_sum(b, red) / (double)n);
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const long r = i / cg;
+    const int c = (int)(i - r * cg);
+    float xh;
+    const float gi = grad_in(r, c, xh);
+    dX[(r0 + r) * lddx + c0 + c] = rstd * (gi - ma - xh * mb);
+  }
+}
+
+}  // namespace
+
+#define ME_BWD_LAUNCH_CHECK(name)                                                   \
+  {                                                                                 \
+    const hipError_t e_ = hipGetLastError();                                        \
+    if (e_ != hipSuccess) { me_set_hip_error(name, (int)e_); return ME_EHIP; }      \
+    return ME_OK;                                                                   \
+  }
+
+extern "C" int me_geglu_bwd(void* dpre, int32_t ldd, const void* pre, int32_t ldp, const void* dy, int32_t lddy, int64_t M, int32_t N, void* stream) {
+  if (!dpre || !pre || !dy || M <= 0 || N <= 0 || N % 32) { me_set_error("me_geglu_bwd: bad arguments (N must be a multiple of 32)"); return ME_EINVAL; }
+  (void)hipGetLastError();
+  const long total = (long)M * (N / 2);
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65536L * 16 ? (total + 255) / 256 : 65536L * 16);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(pre), ldp,
+                     reinterpret_cast<const float*>(dy), lddy, reinterpret_cast<f16*>(dpre), ldd, (long)M, N);
+  ME_BWD_LAUNCH_CHECK("me_geglu_bwd")
+}
+
+extern "C" int me_layernorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* dy, int32_t lddy, int64_t rows, int32_t C, float eps,
+                                void* stream) {
+  if (!dx || !x || !gamma || !dy || rows <= 0 || C <= 0) { me_set_error("me_layernorm_bwd: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(x), ldx,
+                     reinterpret_cast<const f16*>(gamma), reinterpret_cast<const float*>(dy), lddy, reinterpret_cast<float*>(dx), lddx, (long)rows, C, eps);
+  ME_BWD_LAUNCH_CHECK("me_layernorm_bwd")
+}
+
+extern "C" int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* beta, const void* dy, int32_t lddy, int64_t rows,
+                                int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* stream) {
+  if (!dx || !x || !gamma || !beta || !dy || rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || groups <= 0 || C % groups) {
+    me_set_error("me_groupnorm_bwd: bad arguments");
+    return ME_EINVAL;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)((rows / rows_per_group) * groups)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(beta), reinterpret_cast<const float*>(dy), lddy,
+                     reinterpret_cast<float*>(dx), lddx, rows_per_group, C, groups, eps, silu);
+  ME_BWD_LAUNCH_CHECK("me_groupnorm_bwd")
+}

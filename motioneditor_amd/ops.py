@@ -455,9 +455,19 @@ def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
     return dx
 
 
+def _chk_grad(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a CUDA fp32 2-D gradient view with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
 def geglu_bwd(pre, dy):
-    """d(pre-activation) [M, N] from dy [M, N/2], pre in the packed (16 value | 16 gate) column order."""
-    _no_kernel("geglu_bwd")
+    """d(pre-activation) fp16 [M, N] from dy fp32 [M, N/2], pre in the packed (16 value | 16 gate) column order."""
+    _chk2d(pre, "geglu_bwd.pre")
+    _chk_grad(dy, "geglu_bwd.dy")
+    M, N = pre.shape
+    out = empty(M, N, pre)
+    capi.check(capi.lib().me_geglu_bwd(out.data_ptr(), out.stride(0), pre.data_ptr(), pre.stride(0), dy.data_ptr(), dy.stride(0), M, N, _stream()), "me_geglu_bwd")
+    return out
 
 
 def attention_bwd(q, k, v, out, dout, **kw):
@@ -471,8 +481,18 @@ def temporal_attention_bwd(q, k, v, out, dout, **kw):
 
 
 def groupnorm_bwd(x, gamma, beta, dy, *, rows_per_group, eps, silu, groups=32):
-    _no_kernel("groupnorm_bwd")
+    _chk2d(x, "groupnorm_bwd.x")
+    _chk_grad(dy, "groupnorm_bwd.dy")
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().me_groupnorm_bwd(dx.data_ptr(), dx.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), dy.stride(0),
+                                           x.shape[0], rows_per_group, x.shape[1], groups, eps, 1 if silu else 0, _stream()), "me_groupnorm_bwd")
+    return dx
 
 
 def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
-    _no_kernel("layernorm_bwd")
+    _chk2d(x, "layernorm_bwd.x")
+    _chk_grad(dy, "layernorm_bwd.dy")
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().me_layernorm_bwd(dx.data_ptr(), dx.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), x.shape[0], x.shape[1],
+                                           eps, _stream()), "me_layernorm_bwd")
+    return dx

@@ -509,3 +509,34 @@ def test_gemm_dx_matches_the_vjp_of_the_forward_emulation(ops, mode):
     got = ops.gemm_dx(cu(dy), cu(w), x_rows=xr, M=M, conv=conv, tconv=tconv)
     assert tuple(got.shape) == tuple(want.shape)
     check(got, want, f"gemm_dx {mode}")
+
+
+def test_geglu_bwd(ops):
+    g = torch.Generator().manual_seed(6)
+    M, N = 300, 640
+    pre = (torch.randn(M, N, generator=g) * 1.5).half()
+    dy = torch.randn(M, N // 2, generator=g)
+    check(ops.geglu_bwd(cu(pre), cu(dy)), emu.geglu_bwd(pre, dy), "geglu_bwd")
+    big = torch.zeros(M, N // 2 + 8)                       # a strided gradient view, as the tape hands them over
+    big[:, :N // 2] = dy
+    check(ops.geglu_bwd(cu(pre), cu(big)[:, :N // 2]), emu.geglu_bwd(pre, dy), "geglu_bwd strided")
+
+
+@pytest.mark.parametrize("C,rows", [(320, 257), (640, 64), (1280, 33)])
+def test_layernorm_bwd(ops, C, rows):
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
+    gm = (1 + 0.2 * torch.randn(C, generator=g)).half()
+    dy = torch.randn(rows, C, generator=g)
+    check(ops.layernorm_bwd(cu(x), cu(gm), cu(dy), eps=1e-5), emu.layernorm_bwd(x, gm, dy, eps=1e-5), f"layernorm_bwd C={C}")
+
+
+@pytest.mark.parametrize("C,rpg,nsg,silu", [(320, 96, 2, True), (640, 50, 3, False), (1920, 24, 1, True)])
+def test_groupnorm_bwd(ops, C, rpg, nsg, silu):
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(nsg * rpg, C, generator=g) * 1.5 + 0.5).half()
+    gm = (1 + 0.2 * torch.randn(C, generator=g)).half()
+    bt = (0.2 * torch.randn(C, generator=g)).half()
+    dy = torch.randn(nsg * rpg, C, generator=g)
+    want = emu.groupnorm_bwd(x, gm, bt, dy, rows_per_group=rpg, eps=1e-5, silu=silu)
+    check(ops.groupnorm_bwd(cu(x), cu(gm), cu(bt), cu(dy), rows_per_group=rpg, eps=1e-5, silu=silu), want, f"groupnorm_bwd C={C} silu={silu}")
