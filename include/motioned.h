@@ -280,6 +280,11 @@ int me_layernorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const v
 int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* beta, const void* dy, int32_t lddy, int64_t rows,
                      int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
 
+/* Temporal causal attention (me_tattn, plain row order, identity kv_map): dq, dk, dv fp32 [batch*frames*npix, ld] from q, k, v fp16
+ * and dout fp32; frames <= 64 */
+int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
+                 const void* dout, int32_t lddo, int32_t batch, int32_t frames, int32_t npix, int32_t heads, int32_t dh, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -126,6 +126,82 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const f16* __restric
   }
 }
 
+
+// Temporal causal attention backward: one block per (batch row, pixel, head); F <= 64 frames, dh <= 160.  The head's q, k, v, dO rows
+// (F x dh each) sit in LDS as fp32; thread i < F owns query row i for the score pass (P, dS into LDS) and dQ, and key row i for
+// dK / dV.  P = softmax(causal(s q.k)), dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(P dP)), dQ = s dS K, dK = s dS^T Q.
+__global__ __launch_bounds__(64) void tattn_bwd_kernel(const f16* __restrict__ Q, int ldq, const f16* __restrict__ K, int ldk, const f16* __restrict__ V, int ldv,
+                                                      const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq, float* __restrict__ dK, int lddk,
+                                                      float* __restrict__ dV, int lddv, int batch, int F, int npix, int heads, int dh, float scale) {
+  extern __shared__ float sm[];
+  float* sq = sm;                 // [F][dh]
+  float* sk = sq + F * dh;
+  float* sv = sk + F * dh;
+  float* sdo = sv + F * dh;
+  float* sp = sdo + F * dh;       // [F][F]
+  float* sds = sp + F * F;        // [F][F]
+  int bid = blockIdx.x;
+  const int h = bid % heads;
+  bid /= heads;
+  const int p = bid % npix;
+  const int b = bid / npix;
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < F * dh; idx += 64) {
+    const int j = idx / dh, d = idx - j * dh;
+    const long row = ((long)b * F + j) * npix + p;
+    sq[idx] = (float)Q[row * ldq + h * dh + d];
+    sk[idx] = (float)K[row * ldk + h * dh + d];
+    sv[idx] = (float)V[row * ldv + h * dh + d];
+    sdo[idx] = dO[row * lddo + h * dh + d];
+  }
+  __syncthreads();
+  if (tid < F) {
+    const int i = tid;
+    float mx = -1.0e30f;
+    for (int j = 0; j <= i; ++j) {
+      float acc = 0.f;
+      for (int d = 0; d < dh; ++d) acc += sq[i * dh + d] * sk[j * dh + d];
+      sp[i * F + j] = acc * scale;
+      mx = fmaxf(mx, acc * scale);
+    }
+    float l = 0.f;
+    for (int j = 0; j <= i; ++j) {
+      const float e = __expf(sp[i * F + j] - mx);
+      sp[i * F + j] = e;
+      l += e;
+    }
+    const float inv = 1.0f / l;
+    float delta = 0.f;
+    for (int j = 0; j < F; ++j) {
+      float pij = 0.f, dp = 0.f;
+      if (j <= i) {
+        pij = sp[i * F + j] * inv;
+        for (int d = 0; d < dh; ++d) dp += sdo[i * dh + d] * sv[j * dh + d];
+      }
+      sp[i * F + j] = pij;
+      sds[i * F + j] = dp;          // dP for now
+      delta += pij * dp;
+    }
+    for (int j = 0; j < F; ++j) sds[i * F + j] = sp[i * F + j] * (sds[i * F + j] - delta) * scale;
+  }
+  __syncthreads();
+  if (tid < F) {
+    const int i = tid;
+    const long row = ((long)b * F + i) * npix + p;
+    for (int d = 0; d < dh; ++d) {
+      float aq = 0.f, ak = 0.f, av = 0.f;
+      for (int j = 0; j < F; ++j) {
+        aq += sds[i * F + j] * sk[j * dh + d];      // dQ_i = sum_j dS_ij K_j
+        ak += sds[j * F + i] * sq[j * dh + d];      // dK_i = sum_j dS_ji Q_j
+        av += sp[j * F + i] * sdo[j * dh + d];      // dV_i = sum_j P_ji dO_j
+      }
+      dQ[row * lddq + h * dh + d] = aq;
+      dK[row * lddk + h * dh + d] = ak;
+      dV[row * lddv + h * dh + d] = av;
+    }
+  }
+}
+
 }  // namespace
 
 #define ME_BWD_LAUNCH_CHECK(name)                                                   \
@@ -165,4 +241,19 @@ extern "C" int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t l
                      reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(beta), reinterpret_cast<const float*>(dy), lddy,
                      reinterpret_cast<float*>(dx), lddx, rows_per_group, C, groups, eps, silu);
   ME_BWD_LAUNCH_CHECK("me_groupnorm_bwd")
+}
+
+extern "C" int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v,
+                            int32_t ldv, const void* dout, int32_t lddo, int32_t batch, int32_t frames, int32_t npix, int32_t heads, int32_t dh, float scale, void* stream) {
+  if (!dq || !dk || !dv || !q || !k || !v || !dout || batch <= 0 || frames <= 0 || frames > 64 || npix <= 0 || heads <= 0 || dh <= 0) {
+    me_set_error("me_tattn_bwd: bad arguments (frames <= 64)");
+    return ME_EINVAL;
+  }
+  const size_t lds = ((size_t)4 * frames * dh + (size_t)2 * frames * frames) * sizeof(float);
+  if (lds > 64 * 1024) { me_set_error("me_tattn_bwd: frames * head dim too large for the LDS tile"); return ME_EINVAL; }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)((long)batch * npix * heads)), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(q), ldq,
+                     reinterpret_cast<const f16*>(k), ldk, reinterpret_cast<const f16*>(v), ldv, reinterpret_cast<const float*>(dout), lddo, reinterpret_cast<float*>(dq), lddq,
+                     reinterpret_cast<float*>(dk), lddk, reinterpret_cast<float*>(dv), lddv, batch, frames, npix, heads, dh, scale);
+  ME_BWD_LAUNCH_CHECK("me_tattn_bwd")
 }

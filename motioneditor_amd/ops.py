@@ -476,8 +476,20 @@ def attention_bwd(q, k, v, out, dout, **kw):
     _no_kernel("attention_bwd")
 
 
-def temporal_attention_bwd(q, k, v, out, dout, **kw):
-    _no_kernel("temporal_attention_bwd")
+def temporal_attention_bwd(q, k, v, out, dout, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1, q_parts=1):
+    """(dq, dk, dv) fp32 of me_tattn in the plain row order (no editor kv_map, no frame / pixel sharding: the differentiated UNet
+    runs un-edited on one GPU)."""
+    if (kv_map is not None and list(kv_map) != list(range(batch))) or q_frames or kv_parts > 1 or q_parts > 1:
+        raise NotImplementedError("temporal_attention_bwd: editor kv_map / sharded row orders are not differentiated")
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk2d(t, "temporal_attention_bwd." + n)
+    _chk_grad(dout, "temporal_attention_bwd.dout")
+    rows, C_ = batch * frames * npix, heads * dh
+    dq, dk, dv = (torch.empty((rows, C_), dtype=torch.float32, device=q.device) for _ in range(3))
+    capi.check(capi.lib().me_tattn_bwd(dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), q.data_ptr(), q.stride(0),
+                                       k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), dout.data_ptr(), dout.stride(0), batch, frames, npix, heads, dh,
+                                       dh ** -0.5 if scale is None else scale, _stream()), "me_tattn_bwd")
+    return dq, dk, dv
 
 
 def groupnorm_bwd(x, gamma, beta, dy, *, rows_per_group, eps, silu, groups=32):

@@ -540,3 +540,16 @@ def test_groupnorm_bwd(ops, C, rpg, nsg, silu):
     dy = torch.randn(nsg * rpg, C, generator=g)
     want = emu.groupnorm_bwd(x, gm, bt, dy, rows_per_group=rpg, eps=1e-5, silu=silu)
     check(ops.groupnorm_bwd(cu(x), cu(gm), cu(bt), cu(dy), rows_per_group=rpg, eps=1e-5, silu=silu), want, f"groupnorm_bwd C={C} silu={silu}")
+
+
+@pytest.mark.parametrize("F,dh,npix", [(24, 40, 5), (8, 80, 3), (16, 160, 2)])
+def test_temporal_attention_bwd(ops, F, dh, npix):
+    g = torch.Generator().manual_seed(9)
+    B, C = 2, 8 * dh
+    qkv = (torch.randn(B * F * npix, 3 * C, generator=g) * 0.7).half()
+    dout = torch.randn(B * F * npix, C, generator=g)
+    args = dict(heads=8, dh=dh, batch=B, frames=F, npix=npix)
+    want = emu.temporal_attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], None, dout, **args)
+    got = ops.temporal_attention_bwd(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], None, cu(dout), **args)
+    for a, b, n in zip(got, want, "qkv"):
+        check(a, b, f"tattn_bwd d{n} F={F} dh={dh}")
