@@ -285,6 +285,10 @@ int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const v
 int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32_t lddv, const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv,
                  const void* dout, int32_t lddo, int32_t batch, int32_t frames, int32_t npix, int32_t heads, int32_t dh, float scale, void* stream);
 
+/* Row softmax backward, fp16: dS = P * (dP - sum_j P_j dP_j) * scale (the first, matrix-materialising form of the spatial
+ * attention backward composes it with me_gemm and me_softmax_rows) */
+int me_softmax_bwd_rows(void* dS, int32_t ldds, const void* P, int32_t ldp, const void* dP, int32_t lddp, int64_t rows, int32_t cols, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,7 @@ SYMBOLS = {
     "me_layernorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i64, _i32, C.c_float, _vp]),
     "me_groupnorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, C.c_float, _i32, _vp]),
     "me_tattn_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp]),
+    "me_softmax_bwd_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, C.c_float, _vp]),
     "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_copy_blocks": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _i64, _i64, _i64, _i64, _vp]),
     "me_silu": (C.c_int, [_vp, _vp, _i64, _vp]),

@@ -202,6 +202,36 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const f16* __restrict__ Q
   }
 }
 
+
+// Row softmax backward: dS = P * (dP - sum_j P_j dP_j) * scale, one wave per row (cols a multiple of 8).  Used by the first,
+// matrix-materialising form of the spatial attention backward (ops.attention_bwd).
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const f16* __restrict__ P, int ldp, const f16* __restrict__ dP, int lddp, f16* __restrict__ dS, int ldds,
+                                                              long rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* p = P + row * ldp;
+  const f16* dp = dP + row * lddp;
+  float acc = 0.f;
+  for (int c = lane * 8; c < cols; c += 512) {
+    U128 a, b;
+    a.u = ldg128(p + c);
+    b.u = ldg128(dp + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (float)a.e[e] * (float)b.e[e];
+  }
+  const float delta = wave_sum(acc);
+  f16* ds = dS + row * ldds;
+  for (int c = lane * 8; c < cols; c += 512) {
+    U128 a, b, o;
+    a.u = ldg128(p + c);
+    b.u = ldg128(dp + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = (f16)((float)a.e[e] * ((float)b.e[e] - delta) * scale);
+    *reinterpret_cast<uint4*>(ds + c) = o.u;
+  }
+}
+
 }  // namespace
 
 #define ME_BWD_LAUNCH_CHECK(name)                                                   \
@@ -256,4 +286,15 @@ extern "C" int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void
                      reinterpret_cast<const f16*>(k), ldk, reinterpret_cast<const f16*>(v), ldv, reinterpret_cast<const float*>(dout), lddo, reinterpret_cast<float*>(dq), lddq,
                      reinterpret_cast<float*>(dk), lddk, reinterpret_cast<float*>(dv), lddv, batch, frames, npix, heads, dh, scale);
   ME_BWD_LAUNCH_CHECK("me_tattn_bwd")
+}
+
+extern "C" int me_softmax_bwd_rows(void* dS, int32_t ldds, const void* P, int32_t ldp, const void* dP, int32_t lddp, int64_t rows, int32_t cols, float scale, void* stream) {
+  if (!dS || !P || !dP || rows <= 0 || cols <= 0 || cols % 8 || ldds % 8 || ldp % 8 || lddp % 8 || (((uintptr_t)dS | (uintptr_t)P | (uintptr_t)dP) & 15)) {
+    me_set_error("me_softmax_bwd_rows: bad arguments (cols and strides multiples of 8, 16-byte aligned)");
+    return ME_EINVAL;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(P), ldp,
+                     reinterpret_cast<const f16*>(dP), lddp, reinterpret_cast<f16*>(dS), ldds, (long)rows, cols, scale);
+  ME_BWD_LAUNCH_CHECK("me_softmax_bwd_rows")
 }

@@ -470,10 +470,59 @@ def geglu_bwd(pre, dy):
     return out
 
 
-def attention_bwd(q, k, v, out, dout, **kw):
-    """(dq, dk, dv) of me_attn for plain segments: recompute S and P per tile, dV = P^T dO, dP = dO V^T, dS = P * (dP - rowsum(dO * O)),
-    dQ = dS K, dK = dS^T Q; dk / dv accumulate over every query item that names the kv item."""
-    _no_kernel("attention_bwd")
+def attention_bwd(q, k, v, out, dout, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None):
+    """(dq, dk, dv) fp32 of me_attn for PLAIN segments ([prev | cur], self, text): first, matrix-materialising form.  Per (query item,
+    head) the logits, P, dP and dS are real [nq, keys] fp16 matrices built by kernels that already exist -- me_gemm (S = q K^T,
+    dP = dO V^T, dQ = dS K, dK = dS^T q, dV = P^T dO), me_softmax_rows, me_softmax_bwd_rows -- with torch only moving data (head
+    slices made contiguous and padded to 64 columns, transposes, the scatter of dk / dv back to the kv items).  Correct and
+    slow (~100 launches per item); the fused flash-style backward replaces it.  dout arrives loss-scaled."""
+    if mask is not None or bool((seg_mode != 0).any().item()):
+        raise NotImplementedError("attention_bwd: only plain segments are differentiated (the edited / masked attention is not)")
+    scale = dh ** -0.5 if scale is None else scale
+    C_ = heads * dh
+    dev = q.device
+    dq = torch.zeros((n_items * nq, C_), dtype=torch.float32, device=dev)
+    dk = torch.zeros((k.shape[0], C_), dtype=torch.float32, device=dev)
+    dv = torch.zeros((k.shape[0], C_), dtype=torch.float32, device=dev)
+    D = 64 * ((dh + 63) // 64)                       # head dim padded to whole 64-wide K slabs of me_gemm
+    nq_p = 64 * ((nq + 63) // 64)
+
+    def head(t, r0, rows, h, rows_p):               # [rows, dh] column slice -> contiguous, zero-padded [rows_p, D] fp16
+        o = torch.zeros((rows_p, D), dtype=F16, device=dev)
+        o[:rows, :dh] = t[r0:r0 + rows, h * dh:(h + 1) * dh]
+        return o
+
+    table = seg_item.tolist()
+    for it in range(n_items):
+        kits = [kit for kit in table[it] if kit >= 0]
+        nkt = len(kits) * nk
+        nkt_p = 64 * ((nkt + 63) // 64)
+        if nkt_p > 8192:
+            raise NotImplementedError("attention_bwd: more than 8192 keys per query item (me_softmax_rows row length)")
+        for h in range(heads):
+            qh = head(q, it * nq, nq, h, nq_p)
+            doh = head(dout, it * nq, nq, h, nq_p)
+            kc = torch.zeros((nkt_p, D), dtype=F16, device=dev)
+            vc = torch.zeros((nkt_p, D), dtype=F16, device=dev)
+            for s_, kit in enumerate(kits):
+                kc[s_ * nk:(s_ + 1) * nk, :dh] = k[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh]
+                vc[s_ * nk:(s_ + 1) * nk, :dh] = v[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh]
+            S = gemm(qh, kc.reshape(nkt_p, 1, D), alpha=scale)                       # [nq_p, nkt_p]
+            if nkt_p > nkt:
+                S[:, nkt:] = -60000.0                                                # pad keys: weight 0
+            P = softmax_rows(S)
+            dP = gemm(doh, vc.reshape(nkt_p, 1, D))
+            dS = torch.empty_like(P)
+            capi.check(capi.lib().me_softmax_bwd_rows(dS.data_ptr(), dS.stride(0), P.data_ptr(), P.stride(0), dP.data_ptr(), dP.stride(0), nq_p, nkt_p, scale, _stream()),
+                       "me_softmax_bwd_rows")
+            dqh = gemm(dS, kc.t().contiguous().reshape(D, 1, nkt_p))                 # dQ = dS K
+            dkc = gemm(dS.t().contiguous(), qh.t().contiguous().reshape(D, 1, nq_p))    # dK = dS^T q
+            dvc = gemm(P.t().contiguous(), doh.t().contiguous().reshape(D, 1, nq_p))    # dV = P^T dO
+            dq[it * nq:(it + 1) * nq, h * dh:(h + 1) * dh] = dqh[:nq, :dh]
+            for s_, kit in enumerate(kits):
+                dk[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh] += dkc[s_ * nk:(s_ + 1) * nk, :dh]
+                dv[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh] += dvc[s_ * nk:(s_ + 1) * nk, :dh]
+    return dq, dk, dv
 
 
 def temporal_attention_bwd(q, k, v, out, dout, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1, q_parts=1):

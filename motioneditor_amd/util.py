@@ -4,6 +4,7 @@
 (`p2p/null_text_optimization.py`) needs autograd through the UNet and is out of scope."""
 from __future__ import annotations
 
+import math
 from typing import List, Optional
 
 import torch
@@ -111,8 +112,12 @@ def null_optimization(pipeline, ddim_scheduler, latents, context: torch.Tensor, 
             # d loss / d eps_u, back in the row layout of the UNet output: [(b f h w), 4]
             d_eps = (2.0 / diff.numel()) * diff * (cb * (1.0 - guidance_scale))
             d_rows = d_eps.permute(0, 2, 3, 4, 1).reshape(-1, 4)
-            G = autodiff.backward(tape, [(act.t, d_rows)])
-            g = G.view(text).reshape(uncond.shape).to(uncond.dtype)
+            # loss scaling: the backward kernels carry gradients between layers in fp16 (like every activation); a power of two
+            # brings the seed's largest element to ~64 and is divided out of the result
+            amax = float(d_rows.abs().max())
+            ls = 2.0 ** math.floor(math.log2(64.0 / amax)) if amax > 0.0 else 1.0
+            G = autodiff.backward(tape, [(act.t, d_rows * ls)])
+            g = (G.view(text).reshape(uncond.shape) / ls).to(uncond.dtype)
             if grads is not None:
                 grads.append(g.clone())
             opt.zero_grad()

@@ -553,3 +553,30 @@ def test_temporal_attention_bwd(ops, F, dh, npix):
     got = ops.temporal_attention_bwd(cu(qkv)[:, :C], cu(qkv)[:, C:2 * C], cu(qkv)[:, 2 * C:], None, cu(dout), **args)
     for a, b, n in zip(got, want, "qkv"):
         check(a, b, f"tattn_bwd d{n} F={F} dh={dh}")
+
+
+@pytest.mark.parametrize("kind,dh,nq,nk", [("pc", 40, 128, 128), ("pc", 80, 96, 96), ("cross", 40, 64, 77), ("self", 160, 64, 64)])
+def test_attention_bwd_plain_segments(ops, kind, dh, nq, nk):
+    """(dq, dk, dv) of the fused attention for the tables the un-edited UNet uses -- [prev | cur] (a kv item is named by two query
+    items: its gradients add up), self, text -- vs the vjp of the forward emulation."""
+    from motioneditor_amd import segments
+    g = torch.Generator().manual_seed(10)
+    C, f = 8 * dh, 3
+    if kind == "pc":
+        si, sm = segments.prev_cur(1, f, "cpu")
+        n_items, n_kv = f, f
+    elif kind == "self":
+        si, sm = segments.self_items(2, "cpu")
+        n_items, n_kv = 2, 2
+    else:
+        si, sm = segments.cross_text(1, f, "cpu")
+        n_items, n_kv = f, 1
+    q = (torch.randn(n_items * nq, C, generator=g) * 0.7).half()
+    k = (torch.randn(n_kv * nk, C, generator=g) * 0.7).half()
+    v = torch.randn(n_kv * nk, C, generator=g).half()
+    dout = torch.randn(n_items * nq, C, generator=g)
+    args = dict(heads=8, dh=dh, n_items=n_items, nq=nq, nk=nk)
+    want = emu.attention_bwd(q, k, v, None, dout, seg_item=si, seg_mode=sm, **args)
+    got = ops.attention_bwd(cu(q), cu(k), cu(v), None, cu(dout), seg_item=cu(si), seg_mode=cu(sm), **args)
+    for a, b, n in zip(got, want, "qkv"):
+        check(a, b, f"attention_bwd d{n} {kind} dh={dh}", rel=4e-3, mx=6e-2)
