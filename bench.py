@@ -64,6 +64,8 @@ def parse_args():
                     help="secondary measurement (SURVEY 8f rank 1): DDIM-inversion steps/s -- single-branch UNet with normal_infer + next_step, B = 1")
     ap.add_argument("--vae-decode", action="store_true",
                     help="secondary measurement (SURVEY 8f rank 2): frames/s of the VAE decoder (64x64 latents -> 512x512), no UNet involved")
+    ap.add_argument("--null-text", action="store_true",
+                    help="secondary measurement: inner iterations of the null-text optimisation (UNet forward on a tape + backward + Adam, batch 1)")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
     ap.add_argument("--graph", action="store_true",
                     help="A/B: replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from "
@@ -222,6 +224,38 @@ def main():
     else:
         from motioneditor_amd import capi
         capi.lib()  # no HIP library -> hard failure (no fallback path exists)
+
+    if args.null_text:
+        if dist_on or args.emulate:
+            raise SystemExit("--null-text is a single-GPU secondary measurement")
+        from motioneditor_amd import util
+        from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+        from motioneditor_amd.schedulers import DDIMScheduler
+        usd = synth.synth_state_dict(synth.unet_schema())
+
+        class Pipe:
+            pass
+        pipe = Pipe()
+        pipe.unet = UNet2DConditionModel(usd, device)
+        sched = DDIMScheduler()
+        sched.set_timesteps(50)
+        f, h = args.frames, args.latent
+        lat = [torch.from_numpy(synth.synth_normal(f"bench.nt{i}", (1, 4, f, h, h), 33)).to(device) for i in range(2)]
+        ctx = torch.from_numpy(synth.synth_normal("bench.ntctx", (2, 77, 768), 33, 0.3)).to(device)
+        run = lambda k: util.null_optimization(pipe, sched, lat, ctx, k, -1.0, num_ddim_steps=1)   # epsilon < 0: no early stop  # noqa: E731
+        if args.warmup:
+            run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "null-text inner iterations/sec (UNet forward on a tape + backward + Adam, batch 1; each timed call also runs the 2 plain forwards of its DDIM step)",
+                          "value": round(args.steps / dt, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "dtype": "f16 (fp32 gradient buffers, loss-scaled fp16 between layers)",
+                          "data": "synthetic", "config": {"workload": f"{f} frames x {8*h}x{8*h}, single-branch UNet3D, sparse-causal attn1 (normal_infer=False as the reference hard-codes)",
+                                                          "attention_backward": "matrix-materialising first form (me_gemm + me_softmax_rows + me_softmax_bwd_rows)"}}))
+        return
 
     if args.vae_decode:
         if dist_on or args.emulate:

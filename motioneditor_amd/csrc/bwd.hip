@@ -280,7 +280,19 @@ extern "C" int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void
     return ME_EINVAL;
   }
   const size_t lds = ((size_t)4 * frames * dh + (size_t)2 * frames * frames) * sizeof(float);
-  if (lds > 64 * 1024) { me_set_error("me_tattn_bwd: frames * head dim too large for the LDS tile"); return ME_EINVAL; }
+  if (lds > 150 * 1024) { me_set_error("me_tattn_bwd: frames * head dim too large for the LDS tile"); return ME_EINVAL; }
+  if (lds > 48 * 1024) {   // per device: the attribute raises the dynamic LDS limit of this kernel
+    static bool attr_set_dev[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (!attr_set_dev[dev_id & 63]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        me_set_error("me_tattn_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        return ME_EHIP;
+      }
+      attr_set_dev[dev_id & 63] = true;
+    }
+  }
   (void)hipGetLastError();
   hipLaunchKernelGGL(tattn_bwd_kernel, dim3((unsigned)((long)batch * npix * heads)), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(q), ldq,
                      reinterpret_cast<const f16*>(k), ldk, reinterpret_cast<const f16*>(v), ldv, reinterpret_cast<const float*>(dout), lddo, reinterpret_cast<float*>(dq), lddq,
