@@ -45,9 +45,18 @@ def _base(t: torch.Tensor) -> torch.Tensor:
 class Grads:
     """fp32 gradient buffers, one per allocation; `view(t)` is the part of it that `t` covers."""
 
-    def __init__(self):
+    def __init__(self, trainable: Optional[Dict[int, str]] = None):
         self.buf: Dict[int, torch.Tensor] = {}
         self.keep: List[torch.Tensor] = []
+        self.trainable = trainable or {}              # id(packed parameter tensor) -> its key in weights.Packed.cache
+        self.params: Dict[str, torch.Tensor] = {}     # key -> fp32 gradient in the packed layout
+
+    def wants(self, t: Optional[torch.Tensor]) -> bool:
+        return t is not None and id(t) in self.trainable
+
+    def add_param(self, t: torch.Tensor, g: torch.Tensor) -> None:
+        k = self.trainable[id(t)]
+        self.params[k] = self.params[k] + g.float() if k in self.params else g.float().clone()
 
     def has(self, t: torch.Tensor) -> bool:
         return id(_base(t)) in self.buf
@@ -81,11 +90,16 @@ def _rule_gemm(B, x, w, out, kw):
         N, taps, K = w.shape
         dy = G.view(out)
         M = out.shape[0]
-        if kw.get("act", 0):
-            raise NotImplementedError("autodiff: gemm with an activation epilogue lies on no differentiated path")
-        for r in (kw.get("res"), kw.get("res2")):           # epilogue residual adds: the gradient passes straight through
+        act = kw.get("act", 0)
+        for r in (kw.get("res"), kw.get("res2")):           # epilogue residual adds come AFTER the activation: straight through
             if r is not None:
                 G.add(r[:M, :dy.shape[1]], dy)
+        if act == 1:                                         # ReLU epilogue (adapter block1): needs the output WITHOUT the residuals
+            if kw.get("res") is not None or kw.get("res2") is not None:
+                raise NotImplementedError("autodiff: ReLU epilogue together with residual terms")
+            dy = B.relu_bwd(dy, out)
+        elif act:
+            raise NotImplementedError("autodiff: gemm with a SiLU epilogue lies on no differentiated path")
         alpha = kw.get("alpha", 1.0)
         if kw.get("geglu"):
             # y = value * gelu(gate) of the biased pre-activation: recompute it (one GEMM) instead of stashing [M, N] per layer
@@ -93,6 +107,10 @@ def _rule_gemm(B, x, w, out, kw):
             dpre = B.geglu_bwd(pre, dy)
         else:
             dpre = dy
+        if G.wants(w):                                       # trainable weight: dW[n, tap, k] = sum_m dpre[m, n] * gather(x)[m, tap, k]
+            G.add_param(w, B.gemm_dw(dpre, x, taps=taps, K=K, M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv")))
+        if G.wants(kw.get("bias")):
+            G.add_param(kw["bias"], B.colsum_grad(dpre))
         dx = B.gemm_dx(dpre, w, x_rows=x.shape[0], M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
         G.add(x[:, :K], dx)
     return rule
@@ -124,14 +142,23 @@ def _rule_groupnorm(B, x, gamma, beta, out, kw):
     return rule
 
 
-def _rule_layernorm(B, x, gamma, out, eps):
+def _rule_layernorm(B, x, gamma, beta, out, eps):
     def rule(G: Grads):
-        G.add(x, B.layernorm_bwd(x, gamma, G.view(out), eps=eps))
+        dy = G.view(out)
+        if G.wants(gamma) or G.wants(beta):
+            dg, db = B.layernorm_bwd_params(x, dy, eps=eps)
+            if G.wants(gamma):
+                G.add_param(gamma, dg)
+            if G.wants(beta):
+                G.add_param(beta, db)
+        G.add(x, B.layernorm_bwd(x, gamma, dy, eps=eps))
     return rule
 
 
 class Recorder:
     """Stands in for the `ops` module of models/graph.py while a tape records: same functions, same results, plus the log."""
+
+    recording = True   # models/graph.py keeps single assignment while this is its `ops` (out-of-place residual adds)
 
     def __init__(self, backend, tape: Tape):
         self._b, self._t = backend, tape
@@ -186,7 +213,7 @@ class Recorder:
     def layernorm(self, x, gamma, beta, eps=1e-5):
         out = self._own(self._b.layernorm(x, gamma, beta, eps), {})
         self._mark(out)
-        self._t.record([out], _rule_layernorm(self._b, x, gamma, out, eps), x, gamma)
+        self._t.record([out], _rule_layernorm(self._b, x, gamma, beta, out, eps), x, gamma, beta)
         return out
 
     def copy_rows(self, y, x):
@@ -221,10 +248,11 @@ class record:
         return False
 
 
-def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]]) -> Grads:
+def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]], trainable: Optional[Dict[int, str]] = None) -> Grads:
     """seeds: (tensor the forward produced, gradient of the loss w.r.t. it).  Returns the gradient store; `G.view(t)` of any
-    tensor the forward read is its gradient (zeros if nothing depended on it)."""
-    G = Grads()
+    tensor the forward read is its gradient (zeros if nothing depended on it).  trainable: id(packed parameter tensor) -> key
+    (weights.Packed.trainable_ids); their gradients, in the packed layout, end up in `G.params[key]`."""
+    G = Grads(trainable)
     for t, g in seeds:
         G.add(t, g)
     for outs, rule in reversed(tape.entries):

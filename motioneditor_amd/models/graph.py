@@ -406,6 +406,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                     n = s.f * s.N
                     for k, eb in enumerate(edit_rows):
                         ops.axpy_rows(tgt.rows_of(eb), tgt.rows_of(eb), m[k * n:(k + 1) * n])
+                elif getattr(ops, "recording", False):   # differentiated run (autodiff tape): single assignment, the un-updated skip stays readable
+                    tgt = s.like(ops.axpy_rows(torch.empty_like(s.t), s.t, m))
                 else:
                     ops.axpy_rows(tgt.t, tgt.t, m)
                 new_skips.append(tgt)
@@ -425,6 +427,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             for k, eb in enumerate(edit_rows):
                 mk = mid_res[:nr] if mid_res.shape[0] == nr else mid_res[k * nr:(k + 1) * nr]   # shared or per-entry residual
                 ops.axpy_rows(x.rows_of(eb), x.rows_of(eb), mk)
+        elif getattr(ops, "recording", False):
+            x = x.like(ops.axpy_rows(torch.empty_like(x.t), x.t, mid_res))
         else:
             ops.axpy_rows(x.t, x.t, mid_res)
     if taps is not None:

@@ -557,3 +557,21 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
     capi.check(capi.lib().me_layernorm_bwd(dx.data_ptr(), dx.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), dy.data_ptr(), dy.stride(0), x.shape[0], x.shape[1],
                                            eps, _stream()), "me_layernorm_bwd")
     return dx
+
+
+# -- parameter-gradient primitives of the adapter training step (train_adaptor.py:364-368): stated on the emulated ABI
+#    (tests/emu_ops.py) and pinned there against the reference; no kernels yet
+def gemm_dw(dy, x, *, taps, K, M, alpha=1.0, conv=None, tconv=None):
+    _no_kernel("gemm_dw")
+
+
+def colsum_grad(dy):
+    _no_kernel("colsum_grad")
+
+
+def relu_bwd(dy, out):
+    _no_kernel("relu_bwd")
+
+
+def layernorm_bwd_params(x, dy, *, eps=1e-5):
+    _no_kernel("layernorm_bwd_params")

@@ -132,3 +132,40 @@ def null_optimization(pipeline, ddim_scheduler, latents, context: torch.Tensor, 
         eu, ec = e2.chunk(2)
         latent_cur = ca * latent_cur + cb * (eu + guidance_scale * (ec - eu))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Adapter training step, the arithmetic of train_adaptor.py:364-368
+# ---------------------------------------------------------------------------------------------------------------------
+def adapter_training_grads(unet, noisy_latents: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor, down_block_res_samples, mid_block_res_sample,
+                           target: torch.Tensor, prefix: str = "controlnet_adapter."):
+    """loss = mse(unet(noisy, t, ehs, down_block_additional_residuals, mid_block_additional_residual), target) on ONE clip and its gradient
+    w.r.t. every parameter under `prefix`, keyed by the reference's parameter names and in the reference's layouts -- what
+    `accelerator.backward(loss)` leaves in `.grad` of the adapter (the reference trains nothing else: train_adaptor.py freezes the
+    rest).  Residuals in the reference layout [b, C, f, h', w'] (ControlNet outputs, no gradient).  The forward is the ordinary
+    launch graph on an autodiff tape; the caller owns the optimiser step (AdamW + clip_grad_norm in the reference) and, across
+    GPUs, the gradient all-reduce.  Parameter-gradient kernels do not exist yet: on a GPU the primitives raise."""
+    from . import autodiff
+    from .models import graph
+    P = unet.P
+    dev = unet.device
+    B, _, f, h, w = noisy_latents.shape
+    rows = lambda r: graph.ops.nchw5_to_rows(r.to(dev))   # noqa: E731
+    down = [rows(r) for r in down_block_res_samples]
+    mid = rows(mid_block_res_sample)
+    ehs = encoder_hidden_states.to(dev).to(P.dtype).reshape(-1, encoder_hidden_states.shape[-1]).contiguous().clone()
+    t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
+    with autodiff.record(graph) as tape:
+        act = graph.unet_forward(P, noisy_latents.to(dev), t, ehs, down_res=down, mid_res=mid, two_branch=False)
+    pred = graph.ops.rows_to_nchw5(act.t, B, 4, f, h, w).float()
+    diff = pred - target.to(dev).float()
+    loss = float((diff * diff).mean())
+    d_rows = ((2.0 / diff.numel()) * diff).permute(0, 2, 3, 4, 1).reshape(-1, 4)
+    amax = float(d_rows.abs().max())
+    ls = 2.0 ** math.floor(math.log2(64.0 / amax)) if amax > 0.0 else 1.0     # loss scaling, as in null_optimization
+    G = autodiff.backward(tape, [(act.t, d_rows * ls)], trainable=P.trainable_ids(prefix))
+    grads = {}
+    for key, g in G.params.items():
+        for name, gn in P.unpack_grad(key, g / ls).items():
+            grads[name] = grads[name] + gn if name in grads else gn
+    return loss, grads

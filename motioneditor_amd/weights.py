@@ -126,5 +126,47 @@ class Packed:
             self.cache[k] = all(bool((self.raw(n) == 0).all()) for n in names)  # type: ignore[assignment]
         return bool(self.cache[k])
 
+    # ---- training support (adapter training step, train_adaptor.py:364-368): packed parameter <-> reference parameter ----
+    def trainable_ids(self, name_prefix: str) -> Dict[int, str]:
+        """id(packed tensor) -> cache key, for every packed tensor built from parameters whose reference name starts with name_prefix."""
+        out = {}
+        for key, t in self.cache.items():
+            kind, _, names = key.partition(":")
+            if isinstance(t, torch.Tensor) and kind in ("mat", "vec", "fused", "fvec", "geglu", "gegluv") and all(n.startswith(name_prefix) for n in names.split("|")):
+                out[id(t)] = key
+        return out
+
+    def unpack_grad(self, key: str, g: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Gradient w.r.t. a packed tensor -> {reference parameter name: gradient in the reference's own layout}."""
+        kind, _, names = key.partition(":")
+        names_l = names.split("|")
+        g = g.float().cpu()
+
+        def untap(n: str, t: torch.Tensor) -> torch.Tensor:   # [N, taps, K] -> the layout of raw(n)
+            shp = self.raw(n).shape
+            if len(shp) == 2:
+                return t[:, 0, :]
+            if len(shp) == 4:
+                return t.reshape(shp[0], shp[2], shp[3], shp[1]).permute(0, 3, 1, 2)
+            return t.permute(0, 2, 1)
+
+        if kind == "mat":
+            return {names: untap(names, g)}
+        if kind == "vec":
+            return {names: g.reshape(self.raw(names).shape)}
+        if kind in ("fused", "fvec"):
+            out, r0 = {}, 0
+            for n in names_l:
+                rows = self.raw(n).shape[0]
+                out[n] = untap(n, g[r0:r0 + rows]) if kind == "fused" else g[r0:r0 + rows]
+                r0 += rows
+            return out
+        if kind in ("geglu", "gegluv"):
+            n_out = g.shape[0] // 2
+            inv = torch.empty(2 * n_out, dtype=torch.long)
+            inv[self._geglu_perm(n_out)] = torch.arange(2 * n_out)
+            return {names: (g[inv][:, 0, :] if kind == "geglu" else g[inv])}
+        raise KeyError(key)
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.cache.values() if isinstance(t, torch.Tensor))

@@ -322,3 +322,26 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
     x0 = _leaf(x)
     y = layernorm(x0, gamma, torch.zeros_like(gamma), eps)
     return torch.autograd.grad(y, x0, dy.float())[0]
+
+
+def gemm_dw(dy, x, *, taps, K, M, alpha=1.0, conv=None, tconv=None):
+    """dW [N, taps, K] of y = alpha * gather(x) @ w^T: linear in w."""
+    N = dy.shape[1]
+    w0 = torch.zeros((N, taps, K), dtype=torch.float32, requires_grad=True)
+    y = gemm(x.float(), w0, M=M, alpha=alpha, conv=conv, tconv=tconv)
+    return torch.autograd.grad(y, w0, dy.float()[:y.shape[0], :y.shape[1]])[0]
+
+
+def colsum_grad(dy):
+    return dy.float().sum(dim=0)
+
+
+def relu_bwd(dy, out):
+    return dy.float() * (out.float() > 0).float()
+
+
+def layernorm_bwd_params(x, dy, *, eps=1e-5):
+    g0 = torch.ones(x.shape[1], requires_grad=True)
+    b0 = torch.zeros(x.shape[1], requires_grad=True)
+    y = layernorm(x.float(), g0, b0, eps)
+    return torch.autograd.grad(y, (g0, b0), dy.float())
