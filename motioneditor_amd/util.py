@@ -169,3 +169,51 @@ def adapter_training_grads(unet, noisy_latents: torch.Tensor, timestep, encoder_
         for name, gn in P.unpack_grad(key, g / ls).items():
             grads[name] = grads[name] + gn if name in grads else gn
     return loss, grads
+
+
+class AdapterTrainer:
+    """One optimisation step of the content-aware motion adapter as train_adaptor.py:364-385 takes it: loss and gradients from
+    `adapter_training_grads`, gradient averaging over the data-parallel ranks (what accelerate's DDP does for the reference; one flat
+    bucket, RCCL-friendly), `clip_grad_norm_(max_grad_norm)` over the adapter's parameters, AdamW on fp32 master copies (the
+    reference's defaults: lr 3e-5, betas (0.9, 0.999), weight decay 1e-2, eps 1e-8), and the updated parameters written back into
+    the UNet's weight store so that the next forward packs them afresh.  The loss is gathered for logging as `:377` does."""
+
+    def __init__(self, unet, lr: float = 3e-5, betas=(0.9, 0.999), weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0,
+                 prefix: str = "controlnet_adapter.", group=None):
+        self.unet, self.prefix, self.group, self.max_grad_norm = unet, prefix, group, max_grad_norm
+        P = unet.P
+        P.state = dict(P.state)          # a private, mutable weight store: updates must not leak into the caller's mapping
+        self.names = sorted(k[len(P.prefix):] for k in P.state if k.startswith(P.prefix + prefix))
+        self.master = {n: torch.nn.Parameter(P.raw(n).clone()) for n in self.names}
+        self.opt = torch.optim.AdamW(list(self.master.values()), lr=lr, betas=betas, weight_decay=weight_decay, eps=eps)
+
+    def step(self, noisy_latents, timestep, encoder_hidden_states, down_block_res_samples, mid_block_res_sample, target) -> float:
+        import torch.distributed as dist
+        loss, grads = adapter_training_grads(self.unet, noisy_latents, timestep, encoder_hidden_states, down_block_res_samples, mid_block_res_sample, target, self.prefix)
+        missing = [n for n in self.names if n not in grads]
+        if missing:
+            raise RuntimeError(f"no gradient reached {missing[:3]} ...")
+        flat = torch.cat([grads[n].reshape(-1).float().cpu() for n in self.names])
+        loss_t = torch.tensor([loss], dtype=torch.float64)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            world = dist.get_world_size(self.group)
+            dev = self.unet.device if str(dist.get_backend(self.group)) == "nccl" else torch.device("cpu")
+            flat = flat.to(dev)
+            dist.all_reduce(flat, group=self.group)                    # DP gradient average: ONE bucket of every adapter gradient
+            flat = (flat / world).cpu()
+            loss_t = loss_t.to(dev)
+            dist.all_reduce(loss_t, group=self.group)                  # train_adaptor.py:377 (accelerator.gather(loss).mean())
+            loss_t = (loss_t / world).cpu()
+        total = float(flat.norm())
+        clip = min(1.0, self.max_grad_norm / (total + 1e-6))            # torch.nn.utils.clip_grad_norm_
+        o = 0
+        for n in self.names:
+            p = self.master[n]
+            p.grad = (flat[o:o + p.numel()] * clip).reshape(p.shape).clone()
+            o += p.numel()
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        P = self.unet.P
+        for n in self.names:
+            P.update(n, self.master[n].detach())
+        return float(loss_t[0])

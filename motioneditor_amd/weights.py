@@ -136,6 +136,13 @@ class Packed:
                 out[id(t)] = key
         return out
 
+    def update(self, name: str, value: torch.Tensor) -> None:
+        """Replace a parameter (reference name, reference layout); every packed tensor built from it is dropped and re-packed on its
+        next use.  The state mapping must be mutable (a dict)."""
+        self.state[self.prefix + name] = value.detach().cpu().clone()   # type: ignore[index]
+        for key in [k for k in self.cache if name in k.partition(":")[2].split("|")]:
+            del self.cache[key]
+
     def unpack_grad(self, key: str, g: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Gradient w.r.t. a packed tensor -> {reference parameter name: gradient in the reference's own layout}."""
         kind, _, names = key.partition(":")
