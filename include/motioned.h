@@ -289,6 +289,9 @@ int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void* dv, int32
  * attention backward composes it with me_gemm and me_softmax_rows) */
 int me_softmax_bwd_rows(void* dS, int32_t ldds, const void* P, int32_t ldp, const void* dP, int32_t lddp, int64_t rows, int32_t cols, float scale, void* stream);
 
+/* ReLU epilogue backward (adapter TemporalConv -> ReLU, controlnet_adapter.py:452,504): dx = dy where the forward output > 0 */
+int me_relu_bwd(void* dx, int32_t lddx, const void* dy, int32_t lddy, const void* out, int32_t ldo, int64_t rows, int32_t cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

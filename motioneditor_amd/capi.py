@@ -101,6 +101,7 @@ SYMBOLS = {
     "me_groupnorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, C.c_float, _i32, _vp]),
     "me_tattn_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp]),
     "me_softmax_bwd_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, C.c_float, _vp]),
+    "me_relu_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_copy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_copy_blocks": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _i64, _i64, _i64, _i64, _vp]),
     "me_silu": (C.c_int, [_vp, _vp, _i64, _vp]),

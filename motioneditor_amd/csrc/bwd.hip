@@ -232,6 +232,18 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const f16* __rest
   }
 }
 
+
+// ReLU epilogue backward: dx = dy where the forward output was positive (fp32 gradient views, fp16 output of the forward)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, int lddy, const f16* __restrict__ out, int ldo, float* __restrict__ dx, int lddx,
+                                                       long rows, int cols) {
+  const long total = rows * cols;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    dx[r * lddx + c] = (float)out[r * ldo + c] > 0.f ? dy[r * lddy + c] : 0.f;
+  }
+}
+
 }  // namespace
 
 #define ME_BWD_LAUNCH_CHECK(name)                                                   \
@@ -309,4 +321,14 @@ extern "C" int me_softmax_bwd_rows(void* dS, int32_t ldds, const void* P, int32_
   hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const f16*>(P), ldp,
                      reinterpret_cast<const f16*>(dP), lddp, reinterpret_cast<f16*>(dS), ldds, (long)rows, cols, scale);
   ME_BWD_LAUNCH_CHECK("me_softmax_bwd_rows")
+}
+
+extern "C" int me_relu_bwd(void* dx, int32_t lddx, const void* dy, int32_t lddy, const void* out, int32_t ldo, int64_t rows, int32_t cols, void* stream) {
+  if (!dx || !dy || !out || rows <= 0 || cols <= 0) { me_set_error("me_relu_bwd: bad arguments"); return ME_EINVAL; }
+  (void)hipGetLastError();
+  const long total = (long)rows * cols;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 65536L * 16 ? (total + 255) / 256 : 65536L * 16);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float*>(dy), lddy,
+                     reinterpret_cast<const f16*>(out), ldo, reinterpret_cast<float*>(dx), lddx, (long)rows, cols);
+  ME_BWD_LAUNCH_CHECK("me_relu_bwd")
 }

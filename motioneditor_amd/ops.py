@@ -559,19 +559,78 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
     return dx
 
 
-# -- parameter-gradient primitives of the adapter training step (train_adaptor.py:364-368): stated on the emulated ABI
-#    (tests/emu_ops.py) and pinned there against the reference; no kernels yet
+# -- parameter-gradient primitives of the adapter training step (train_adaptor.py:364-368).  Composed from kernels that exist:
+#    a weight gradient is a GEMM with the token axis as the reduction (dy^T against x^T as "weights"), a bias gradient the same GEMM
+#    against a row of ones, the LayerNorm scale gradient the diagonal of dy^T @ xhat.  torch only moves data (transposes, padding,
+#    the shifted copies of the TemporalConv taps).  The token axis is long (~10^5 rows) and the results leave me_gemm in fp16, so the
+#    GEMMs run with alpha = 2^-12 and the factor is restored in fp32.
+_DW_SHIFT = 4096.0
+
+
+def _t_pad(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """[r, c] (any float dtype) -> contiguous fp16 [cols_p8.., rows_p64] transpose, zero padded: rows_out = c (padded to 8), cols_out = rows (padded to 64)."""
+    c8, r64 = (cols + 7) // 8 * 8, (rows + 63) // 64 * 64
+    o = torch.zeros((c8, r64), dtype=F16, device=t.device)
+    o[:cols, :rows] = t[:rows, :cols].t()
+    return o
+
+
 def gemm_dw(dy, x, *, taps, K, M, alpha=1.0, conv=None, tconv=None):
-    _no_kernel("gemm_dw")
+    """dW fp32 [N, taps, K] of me_gemm's y = alpha * gather(x) @ w^T for dense and TemporalConv layers (the adapter has no 3x3 convolution)."""
+    if conv is not None:
+        raise NotImplementedError("gemm_dw: 3x3 convolution weights are not trained (the adapter has none)")
+    if tconv is not None and len(tconv) > 3:
+        raise NotImplementedError("gemm_dw: the frame-sharded TemporalConv is not differentiated")
+    N = dy.shape[1]
+    dyT = _t_pad(dy, M, N)                                           # [N8, M64]
+    xm = x[:M, :K]
+    if tconv is None:
+        srcs = [xm]
+    else:
+        frames, npix, chunk = tconv
+        nb = M // (frames * npix)
+        x4 = xm.reshape(nb, frames, npix, K)
+        srcs = []
+        for tap in range(3):                                           # rows of tap = the frame tap - 1 away, inside the same chunk; zeros otherwise
+            sh = torch.zeros_like(x4)
+            for fr in range(frames):
+                s_ = fr + tap - 1
+                if 0 <= s_ < frames and s_ // chunk == fr // chunk:
+                    sh[:, fr] = x4[:, s_]
+            srcs.append(sh.reshape(M, K))
+    out = torch.empty((N, taps, K), dtype=torch.float32, device=dy.device)
+    for tap, src in enumerate(srcs):
+        xT = _t_pad(src, M, K)                                           # [K8, M64] = the "weights" [K][1][M64]
+        d = gemm(dyT, xT.reshape(xT.shape[0], 1, xT.shape[1]), alpha=alpha / _DW_SHIFT)
+        out[:, tap, :] = d[:N, :K].float() * _DW_SHIFT
+    return out
 
 
 def colsum_grad(dy):
-    _no_kernel("colsum_grad")
+    """Column sums of a gradient (a bias gradient): ones^T @ dy through me_gemm."""
+    M, N = dy.shape
+    dyT = _t_pad(dy, M, N)
+    ones = torch.ones((64, dyT.shape[1]), dtype=F16, device=dy.device)
+    ones[:, M:] = 0
+    d = gemm(ones, dyT.reshape(dyT.shape[0], 1, dyT.shape[1]), alpha=1.0 / _DW_SHIFT)
+    return d[0, :N].float() * _DW_SHIFT
 
 
 def relu_bwd(dy, out):
-    _no_kernel("relu_bwd")
+    _chk_grad(dy, "relu_bwd.dy")
+    _chk2d(out, "relu_bwd.out")
+    dx = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+    capi.check(capi.lib().me_relu_bwd(dx.data_ptr(), dx.stride(0), dy.data_ptr(), dy.stride(0), out.data_ptr(), out.stride(0), dy.shape[0], dy.shape[1], _stream()),
+               "me_relu_bwd")
+    return dx
 
 
 def layernorm_bwd_params(x, dy, *, eps=1e-5):
-    _no_kernel("layernorm_bwd_params")
+    """(d gamma, d beta) of nn.LayerNorm: d beta = column sums of dy; d gamma = diag(dy^T @ xhat) with xhat from me_layernorm(gamma 1, beta 0)."""
+    M, Cc = x.shape
+    one = torch.ones(Cc, dtype=F16, device=x.device)
+    xhat = layernorm(x, one, torch.zeros_like(one), eps)
+    dyT = _t_pad(dy, M, Cc)
+    xT = _t_pad(xhat, M, Cc)
+    d = gemm(dyT, xT.reshape(xT.shape[0], 1, xT.shape[1]), alpha=1.0 / _DW_SHIFT)
+    return torch.diagonal(d[:Cc, :Cc]).float() * _DW_SHIFT, colsum_grad(dy)

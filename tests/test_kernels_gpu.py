@@ -580,3 +580,36 @@ def test_attention_bwd_plain_segments(ops, kind, dh, nq, nk):
     got = ops.attention_bwd(cu(q), cu(k), cu(v), None, cu(dout), seg_item=cu(si), seg_mode=cu(sm), **args)
     for a, b, n in zip(got, want, "qkv"):
         check(a, b, f"attention_bwd d{n} {kind} dh={dh}", rel=4e-3, mx=6e-2)
+
+
+@pytest.mark.parametrize("mode", ["dense", "tconv", "geglu_n"])
+def test_gemm_dw_and_bias_gradients(ops, mode):
+    """Weight / bias gradients of the adapter's Linear and TemporalConv layers (GEMMs over the token axis through me_gemm itself)
+    vs the vjp of the forward emulation."""
+    g = torch.Generator().manual_seed(12)
+    tconv = None
+    if mode == "dense":
+        M, N, K, taps = 300, 320, 192, 1
+    elif mode == "geglu_n":
+        M, N, K, taps = 200, 2560, 320, 1
+    else:
+        M, N, K, taps, tconv = 2 * 16 * 12, 128, 64, 3, (16, 12, 8)
+    x = (torch.randn(M, K, generator=g)).half()
+    dy = torch.randn(M, N, generator=g)
+    want = emu.gemm_dw(dy.half().float(), x, taps=taps, K=K, M=M, tconv=tconv)
+    got = ops.gemm_dw(cu(dy), cu(x), taps=taps, K=K, M=M, tconv=tconv)
+    check(got, want, f"gemm_dw {mode}", rel=4e-3, mx=6e-2)
+    check(ops.colsum_grad(cu(dy)), emu.colsum_grad(dy.half().float()), f"colsum_grad {mode}", rel=4e-3, mx=6e-2)
+
+
+def test_relu_bwd_and_layernorm_param_gradients(ops):
+    g = torch.Generator().manual_seed(13)
+    rows, C = 257, 320
+    out = torch.randn(rows, C, generator=g).half()
+    dy = torch.randn(rows, C, generator=g)
+    assert torch.equal(ops.relu_bwd(cu(dy), cu(out)).cpu(), emu.relu_bwd(dy, out))
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
+    dg, db = ops.layernorm_bwd_params(cu(x), cu(dy), eps=1e-5)
+    wg, wb = emu.layernorm_bwd_params(x, dy.half().float(), eps=1e-5)
+    check(dg, wg, "layernorm d gamma", rel=4e-3, mx=6e-2)
+    check(db, wb, "layernorm d beta", rel=4e-3, mx=6e-2)

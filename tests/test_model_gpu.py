@@ -528,3 +528,31 @@ def test_null_text_optimization_on_the_gpu_vs_reference_golden(unet_sd_np):
     frac = float((d1 < 2e-3).float().mean())
     print("null-text on GPU: grad rel-L2", rel, "step-1 embedding diff (significant elements)", d0, "step-2 elements within 2e-3:", frac)
     assert rel < 3e-2 and d0 < 3e-3 and frac > 0.995, (rel, d0, frac)
+
+
+def test_adapter_training_gradients_on_the_gpu_vs_reference_golden(unet_sd_np):
+    """util.adapter_training_grads on the GPU: the launch graph on the tape, all backward and parameter-gradient primitives, the packed
+    gradients mapped back to the reference's parameter names -- against what the reference UNet's autograd leaves in .grad
+    (tests/golden/adapter_train.npz).  fp16 activations and loss-scaled fp16 inter-layer gradients vs the reference's fp32."""
+    from conftest import GOLD
+    from motioneditor_amd import util
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    g = np.load(GOLD / "adapter_train.npz")
+    T = torch.from_numpy
+    F32 = lambda k: T(g[k].astype(np.float32))   # noqa: E731
+    unet = UNet2DConditionModel(unet_sd_np, device="cuda")
+    loss, grads = util.adapter_training_grads(unet, F32("noisy"), int(g["t"]), F32("ehs"), [F32(f"down{i}") for i in range(12)], F32("mid"), F32("noise"))
+    names = [str(n) for n in g["names"]]
+    assert set(names) == set(grads)
+    norms = np.array([float(grads[k].norm()) for k in names])
+    live = g["grad_norms"] > 0                   # six 1x1-pixel attn_pose q / k projections get exactly zero gradient (one key: softmax = 1)
+    assert float(norms[~live].max(initial=0.0)) < 1e-6
+    rel = np.abs(norms[live] / g["grad_norms"][live] - 1)
+    tot = float(np.sqrt((norms ** 2).sum()) / np.sqrt((g["grad_norms"] ** 2).sum()))
+    fulls = []
+    for i, k in enumerate(str(n) for n in g["full_names"]):
+        want = T(g[f"full_{i}"])
+        fulls.append(float((grads[k].float().cpu() - want).norm() / want.norm().clamp_min(1e-30)))
+    print("adapter training on GPU: loss", loss, "vs", float(g["loss"]), " total grad norm ratio", tot, " median / max per-parameter norm error", float(np.median(rel)), float(rel.max()),
+          " full tensors rel-L2", fulls)
+    assert abs(loss - float(g["loss"])) < 5e-3 * float(g["loss"]) and abs(tot - 1) < 2e-2 and float(np.median(rel)) < 2e-2 and max(fulls) < 5e-2, (loss, tot, fulls)
