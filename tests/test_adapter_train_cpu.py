@@ -87,3 +87,48 @@ def test_two_rank_adapter_training_step_equals_the_single_process_autograd_step(
     # depend on its last digits, so the whole update is compared in L2 and the single worst element only loosely
     assert r["update_rel_l2"] < 1e-2 and r["worst"] < 0.3, r
     assert r["repacked"] < 1e-6              # and the weight store hands out the updated values
+
+
+def test_training_sequence_of_the_example_matches_the_oracle_loss(monkeypatch, unet_sd_np, cn_sd_np):
+    """examples/train_adapter.py::step -- VAE encode, add_noise, ControlNet, UNet + adapter, loss, AdamW -- on the emulated ABI:
+    the loss it reports is the oracle's for the same tensors, and the adapter's weights moved."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "examples"))
+    import emu_ops
+    import motioneditor_amd.models.controlnet as c
+    import motioneditor_amd.models.unet_2d_condition as u
+    import motioneditor_amd.models.vae as v
+    import train_adapter as ex
+    from motioneditor_amd import synth, util
+    from motioneditor_amd.models import graph
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from oracle import ref_cpu
+    for m in (graph, u, c, v, util):
+        monkeypatch.setattr(m, "ops", emu_ops)
+    vsd = synth.synth_state_dict(synth.vae_encoder_schema(), 33, salt="vae.")
+    vae = AutoencoderKL(vsd, device="cpu", dtype=torch.float32)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    cn = ControlNetModel(cn_sd_np, device="cpu", dtype=torch.float32)
+    tr = util.AdapterTrainer(unet, lr=1e-3)
+    f, H = 8, 64
+    b = ex.training_batch(f, H, H)
+    t = 401
+    before = unet.P.raw("controlnet_adapter.body.0.block2.weight").clone()
+    loss = ex.step(tr, vae, cn, b, t)
+    # oracle: the same sequence in torch
+    T = torch.from_numpy
+    usd = {k: T(x) for k, x in unet_sd_np.items()}
+    csd = {k: T(x) for k, x in cn_sd_np.items()}
+    lat = ref_cpu.vae_encode_sample({k: T(x) for k, x in vsd.items()}, b["pixel_values"].reshape(f, 3, H, H), b["encode_noise"])
+    lat = lat.reshape(1, f, 4, 8, 8).permute(0, 2, 1, 3, 4) * 0.18215
+    a = float(ex.alphas_cumprod()[t])
+    noisy = a ** 0.5 * lat + (1 - a) ** 0.5 * b["noise"]
+    down, mid = ref_cpu.controlnet_forward(csd, noisy.permute(0, 2, 1, 3, 4).reshape(f, 4, 8, 8), t, b["ehs"].repeat(f, 1, 1), b["skeleton"].reshape(f, 3, H, H))
+    down = [d.reshape(1, f, *d.shape[1:]).permute(0, 2, 1, 3, 4) for d in down]
+    mid = mid.reshape(1, f, *mid.shape[1:]).permute(0, 2, 1, 3, 4)
+    with torch.no_grad():
+        want = float(torch.nn.functional.mse_loss(ref_cpu.unet_forward(usd, noisy, t, b["ehs"], down, mid), b["noise"]))
+    assert abs(loss - want) < 1e-3 * want, (loss, want)
+    assert float((unet.P.raw("controlnet_adapter.body.0.block2.weight") - before).abs().max()) > 1e-4
