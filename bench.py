@@ -93,15 +93,8 @@ def spawn_self(args) -> int:
 
 
 def build_inputs(f, h, w, seed=33):
-    import numpy as np
-    import torch
     from motioneditor_amd import synth
-    T = torch.from_numpy
-    return dict(latents=T(synth.synth_normal("bench.latents", (2, 4, f, h, w), seed)),
-                uncond=[T(synth.synth_normal(f"bench.uncond{i}", (1, 77, 768), seed, 0.3)) for i in range(50)],
-                cond=T(synth.synth_normal("bench.cond", (2, 77, 768), seed, 0.3)),
-                skeleton=T(np.clip(synth.synth_normal("bench.skel", (1, f, 3, 8 * h, 8 * w), seed, 0.5) + 0.5, 0, 1).astype(np.float32)),
-                masks=T(synth.synth_masks(f, 8 * h, 8 * w)))
+    return synth.bench_inputs(f, h, w, seed)
 
 
 def make_pipeline(device, usd, csd, masks, dtype=None):

@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 3
+#define ME_ABI_VERSION 4
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -52,7 +52,7 @@ int me_device_info(int* cus, int* lds_bytes, char* arch, int arch_len);
  * (attention_2d.py:307,336), time_emb_proj (resnet_2d.py:172,211).
  */
 #define ME_GATHER_DENSE 0  /* taps = 1, src(m) = m                                                  */
-#define ME_GATHER_CONV3 1  /* taps = 9, 3x3 pad 1 over [img][Hin][Win] pixels; stride 1|2; ups 0|1 */
+#define ME_GATHER_CONV3 1  /* taps = 9, 3x3 pad 1 over [img][Hin][Win] pixels; stride 1|2; ups 0|1|2 */
 #define ME_GATHER_TCONV 2  /* taps = 3, k=3 pad 1 over frames inside chunks of `chunk` frames       */
 
 typedef struct me_gemm_args {
@@ -62,7 +62,9 @@ typedef struct me_gemm_args {
   int32_t M, N, K;    /* K = input channels per tap (multiple of 8)            */
   int32_t ldx, ldc;   /* row strides in elements (multiples of 8 / 4)          */
   int32_t gather;     /* ME_GATHER_*                                           */
-  /* CONV3: M = n_img * Hout * Wout */
+  /* CONV3: M = n_img * Hout * Wout.  ups = 1: the input is read through a nearest-neighbour 2x upsample (Upsample2D folded into
+   * the gather); ups = 2: through a ZERO-STUFFED 2x upsample (virtual pixel (2y, 2x) = input pixel (y, x), every other virtual
+   * pixel is zero) -- the input gradient of a stride-2 convolution is the stride-1 correlation of the zero-stuffed output gradient */
   int32_t Hin, Win, Hout, Wout, stride, ups;
   int32_t pad0;       /* CONV3: 0 = padding 1 on every side; 1 = no padding at the top / left, one row / column at the bottom /
                          right (diffusers Downsample2D(padding=0) of the VAE encoder: F.pad(x, (0,1,0,1)) + stride-2 conv) */
@@ -86,6 +88,9 @@ typedef struct me_gemm_args {
   int32_t geglu;      /* 1: W rows interleaved (16 a-rows, 16 gate-rows); C gets N/2 columns a*gelu(g) */
   int32_t act;        /* applied after bias+rowvec, before residuals: 0 none, 1 ReLU, 2 SiLU */
   float alpha;        /* scale applied to the accumulator before the epilogue adds */
+  int32_t res_rows;   /* > 0: res holds res_rows rows and output row m reads row m % res_rows (a residual shared by several batch entries,
+                         e.g. the adapter's ControlNet-only half broadcast over the edit rows); 0: row m reads row m */
+  int32_t res2_rows;  /* the same for res2 */
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);
@@ -143,6 +148,10 @@ typedef struct me_attn_args {
    * which adds it in its epilogue; the rest holds the partials of the fixed-order reduction.  NULL when no segment is DUAL_BIN. */
   void* vsum;
   int32_t n_kv_items;      /* kv items in K / V (rows / nk); only read with vsum */
+  int32_t q_items;         /* > 0: Q holds q_items query items and item i reads item i % q_items (queries shared by several batch entries:
+                              the adapter's pose queries, controlnet_adapter.py:519-523, broadcast over the edit rows); 0: item i reads item i */
+  void* lse;               /* optional fp32 [n_items * nq][heads]: log2 of the softmax denominator in exp2 units, log2(sum_j 2^(s_j scale log2 e)),
+                              stashed for me_attn_bwd (plain segments only; NULL = not written) */
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);
@@ -291,6 +300,88 @@ int me_softmax_bwd_rows(void* dS, int32_t ldds, const void* P, int32_t ldp, cons
 
 /* ReLU epilogue backward (adapter TemporalConv -> ReLU, controlnet_adapter.py:452,504): dx = dy where the forward output > 0 */
 int me_relu_bwd(void* dx, int32_t lddx, const void* dy, int32_t lddy, const void* out, int32_t ldo, int64_t rows, int32_t cols, void* stream);
+
+/* ---- fused attention backward (plain segments) ------------------------------------------------ *
+ * (dQ, dK, dV) += the input gradients of me_attn for PLAIN key segments -- [prev | cur] (attention_2d.py:705-768), per-frame
+ * self-attention, the text cross-attention (:115-201), the adapter's [first | prev] (controlnet_adapter.py:332-407) -- that torch
+ * autograd computes for the reference (p2p/null_text_optimization.py:149-156: loss.backward() through the UNet;
+ * train_adaptor.py:372: accelerator.backward(loss)).  Flash-style: P is rebuilt per tile from the log-sum-exp me_attn stashed
+ * (me_attn_args.lse); no score matrix is materialised; two deterministic kernels (key-centric for dK / dV, query-centric for dQ),
+ * every output element has one owner and is accumulated into.  dO and the outputs are fp32 views (the tape's gradient buffers;
+ * dO is loss-scaled by the caller: it travels through the MFMAs as fp16).
+ */
+typedef struct me_attn_bwd_args {
+  const void* Q;  /* fp16, as me_attn */
+  const void* K;
+  const void* V;
+  const void* O;      /* fp16 [n_items * nq, ldo]: the forward output */
+  const void* dO;     /* fp32 [n_items * nq, lddo] */
+  const void* lse;    /* fp32 [n_items * nq][heads] written by me_attn */
+  void* dQ;           /* fp32 [n_items * nq, lddq]      += */
+  void* dK;           /* fp32 [n_kv_items * nk, lddk]   += */
+  void* dV;           /* fp32 [n_kv_items * nk, lddv]   += */
+  void* delta;        /* fp32 scratch [n_items * nq][heads]: sum_d dO O */
+  int32_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+  int32_t heads, dh;  /* dh in {40, 80, 160} */
+  int32_t n_items, nq, nk, nseg, n_kv_items;
+  const int32_t* seg_item; /* device int32 [n_items][nseg], as me_attn (every listed segment is PLAIN) */
+  const int32_t* inv_ptr;  /* device int32 [n_kv_items + 1]: CSR of the inverse table ... */
+  const int32_t* inv_item; /* ... inv_item[inv_ptr[k] .. inv_ptr[k + 1]) = the query items that list kv item k (once per listing) */
+  float scale;
+} me_attn_bwd_args;
+
+int me_attn_bwd(const me_attn_bwd_args* a, void* stream);
+
+/* ---- parameter gradients, gradient bookkeeping, optimiser ------------------------------------- *
+ * The adapter training step (train_adaptor.py:364-385: loss.backward() into controlnet_adapter.*, DDP gradient average,
+ * clip_grad_norm_(1.0), AdamW(lr 3e-5, betas (0.9, 0.999), weight_decay 1e-2, eps 1e-8)) and the null-text optimisation's loss
+ * and Adam (p2p/null_text_optimization.py:140-160) on the device.  Reductions over the token axis use fixed-order partials.
+ */
+typedef struct me_gemm_dw_args {
+  const void* dY;     /* [M, lddy] gradient of me_gemm's (pre-epilogue) output: fp32, or fp16 when dy_is_f16 */
+  const void* X;      /* fp16 [rows, ldx]: the input me_gemm read */
+  void* dW;           /* fp32 [N][taps][K]   += alpha * sum_m dY[m, n] X[src(m, tap), k]   (this call: one tap) */
+  void* work;         /* scratch of me_gemm_dw_work_bytes(M, N, K) bytes, 16-byte aligned */
+  int32_t M, N, K, lddy, ldx, dy_is_f16;
+  int32_t taps, tap;
+  int32_t gather;     /* ME_GATHER_DENSE (taps 1) or ME_GATHER_TCONV (taps 3, unsharded) */
+  int32_t frames, npix, chunk;
+  float alpha;
+} me_gemm_dw_args;
+
+int me_gemm_dw(const me_gemm_dw_args* a, void* stream);
+int64_t me_gemm_dw_work_bytes(int32_t M, int32_t N, int32_t K);
+/* out[n] += alpha * sum_m dY[m, n]  (bias gradients); work: me_colsum_work_bytes(N) bytes */
+int me_colsum(float* out, const void* dY, int32_t lddy, int32_t dy_is_f16, int64_t M, int32_t N, float alpha, float* work, void* stream);
+int64_t me_colsum_work_bytes(int32_t N);
+/* nn.LayerNorm parameter gradients: dgamma[c] += alpha * sum_m dy[m, c] xhat[m, c], dbeta[c] += alpha * sum_m dy[m, c] (either may be NULL);
+ * x fp16, dy fp32; work: me_layernorm_bwd_params_work_bytes(rows, C) bytes */
+int me_layernorm_bwd_params(float* dgamma, float* dbeta, const void* x, int32_t ldx, const void* dy, int32_t lddy, int64_t rows, int32_t C, float eps, float alpha,
+                            float* work, void* stream);
+int64_t me_layernorm_bwd_params_work_bytes(int64_t rows, int32_t C);
+/* dst[r, c] += alpha * src[r, c] on an fp32 [rows, cols] view (src fp32 or fp16): the gradient accumulation of the reverse-mode tape.
+ * pool_h, pool_w > 0: dst pixel (img, y, x) of a pool_h x pool_w grid collects the 2 x 2 block (2y + a, 2x + b) of the 2 pool_h x 2 pool_w
+ * source grid -- the input gradient of the nearest-2x upsample in front of a convolution (resnet_2d.py:77) */
+int me_grad_acc(void* dst, int32_t lddst, const void* src, int32_t ldsrc, int32_t src_is_f16, int64_t rows, int32_t cols, float alpha, int32_t pool_h, int32_t pool_w,
+                void* stream);
+/* out = {sum x^2, max |x|} of an fp32 vector (gradient-norm clipping, loss, loss-scale selection); work: me_sumsq_work_bytes() bytes */
+int me_sumsq_absmax(float* out, const float* x, int64_t n, float* work, void* stream);
+int64_t me_sumsq_work_bytes(void);
+/* One AdamW step on fp32 master parameters (torch.optim.AdamW; weight_decay 0 = torch.optim.Adam).  bias_c1 = 1 - beta1^t, bias_c2 = 1 - beta2^t.
+ * The gradient used is g * grad_scale * clip, clip = min(1, max_grad_norm / (sqrt(gnorm_sq[0]) * grad_scale + 1e-6)) when gnorm_sq (a DEVICE
+ * scalar, me_sumsq_absmax's out[0] over the whole gradient bucket) is given -- torch.nn.utils.clip_grad_norm_ without a host round trip */
+int me_adamw(float* p, float* m, float* v, const float* g, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
+             const float* gnorm_sq, float max_grad_norm, float grad_scale, void* stream);
+/* dst fp16 [n] = src fp32 [n]: refresh of the packed fp16 weights from their fp32 masters */
+int me_cast_f16(void* dst, const float* src, int64_t n, void* stream);
+/* dst fp16 [rows, lddst] = src fp32 [rows, ldsrc] over columns [0, cols), zeros in [cols, pad_cols): a gradient view as the fp16 operand of the
+ * input-gradient / weight-gradient MFMA kernels (pad_cols: the next multiple of 8 the transposed weights are padded to) */
+int me_cast_rows_f16(void* dst, int32_t lddst, const float* src, int32_t ldsrc, int64_t rows, int32_t cols, int32_t pad_cols, void* stream);
+/* Loss seed of both optimisations: rec = ca * x + cb * (eps_u + guidance * (eps_c - eps_u)) (eps_c NULL: rec = ca * x + cb * eps_u; x NULL: no x term),
+ * diff = rec - target (fp32 [nb, C, frames, npix], reference layout), d_eps[row, c] = coef * diff on channels-last rows (fp32, ld ldd).
+ * prev_step + mse of p2p/null_text_optimization.py:26-36,150-151; the mse of train_adaptor.py:368 with ca = 0, cb = 1 */
+int me_mse_seed(float* diff, float* d_eps, int32_t ldd, const void* eps_u, int32_t ldu, const void* eps_c, int32_t ldc, const float* x, const float* target, int32_t nb,
+                int32_t C, int32_t frames, int32_t npix, float guidance, float ca, float cb, float coef, void* stream);
 
 #ifdef __cplusplus
 }

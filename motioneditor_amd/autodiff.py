@@ -9,10 +9,13 @@ q|k|v tensor, a skip-concat buffer, ...): a view's gradient is the same view of 
 and `out=` targets accumulate where they belong without any graph surgery.
 
 The primitives (`ops.gemm_dx`, `ops.geglu_bwd`, `ops.attention_bwd`, `ops.temporal_attention_bwd`, `ops.groupnorm_bwd`,
-`ops.layernorm_bwd`) are the kernel-level contract of the backward pass.  tests/emu_ops.py implements them on the CPU
-(each as the vector-Jacobian product of its forward emulation) and pins this module, through `util.null_optimization`,
-against the reference's own optimisation (tests/golden/null_text.npz).  The HIP kernels behind them are not built yet:
-on a GPU the primitives raise, loudly -- there is no fallback.
+`ops.layernorm_bwd`, and for trained parameters `ops.gemm_dw`, `ops.colsum_grad`, `ops.layernorm_bwd_params`, `ops.relu_bwd`) are the
+kernel-level contract of the backward pass; every accumulation into a gradient buffer goes through `ops.grad_acc`.  On the GPU each is a
+HIP kernel of libmotioned (csrc/bwd.hip, attn_bwd.hip, train.hip) or me_gemm itself on transposed weights; tests/emu_ops.py states them on
+the CPU (each as the vector-Jacobian product of its forward emulation) and pins this module, through `util.null_optimization` and
+`util.adapter_training_grads`, against the reference's own optimisation (tests/golden/null_text.npz, adapter_train.npz).  Still raising
+(not differentiated): edited / masked attention segments, shared query items, sharded row orders, the temporal editor's kv_map, the
+pad-(0,1,0,1) convolution and 3x3-convolution weights.
 
 Restrictions (asserted): single assignment -- no allocation region is written twice while recording (true for the
 single-branch UNet forward; the in-place motion / ControlNet residual adds of the two-branch step are not differentiated).
@@ -25,7 +28,8 @@ import torch
 
 
 class Tape:
-    def __init__(self):
+    def __init__(self, backend=None):
+        self.backend = backend
         self.entries: List[Tuple[Sequence[torch.Tensor], Callable]] = []
         self.keep: List[torch.Tensor] = []   # every tensor a rule needs stays alive (and un-recycled) until the tape dies
 
@@ -43,20 +47,27 @@ def _base(t: torch.Tensor) -> torch.Tensor:
 
 
 class Grads:
-    """fp32 gradient buffers, one per allocation; `view(t)` is the part of it that `t` covers."""
+    """fp32 gradient buffers, one per allocation; `view(t)` is the part of it that `t` covers.  Every accumulation is the backend's
+    `grad_acc` (a HIP kernel on the GPU)."""
 
-    def __init__(self, trainable: Optional[Dict[int, str]] = None):
+    def __init__(self, backend, trainable: Optional[Dict[int, str]] = None, param_buffers: Optional[Dict[str, torch.Tensor]] = None):
+        self.B = backend
         self.buf: Dict[int, torch.Tensor] = {}
         self.keep: List[torch.Tensor] = []
         self.trainable = trainable or {}              # id(packed parameter tensor) -> its key in weights.Packed.cache
-        self.params: Dict[str, torch.Tensor] = {}     # key -> fp32 gradient in the packed layout
+        self.params: Dict[str, torch.Tensor] = param_buffers if param_buffers is not None else {}   # key -> fp32 gradient in the packed layout
 
     def wants(self, t: Optional[torch.Tensor]) -> bool:
         return t is not None and id(t) in self.trainable
 
-    def add_param(self, t: torch.Tensor, g: torch.Tensor) -> None:
+    def param(self, t: torch.Tensor) -> torch.Tensor:
+        """The fp32 gradient buffer (packed layout) of trainable tensor `t`: a zeroed tensor at first use, or the caller's (a view of the
+        trainer's flat gradient bucket)."""
         k = self.trainable[id(t)]
-        self.params[k] = self.params[k] + g.float() if k in self.params else g.float().clone()
+        g = self.params.get(k)
+        if g is None:
+            g = self.params[k] = torch.zeros(t.shape, dtype=torch.float32, device=t.device)
+        return g
 
     def has(self, t: torch.Tensor) -> bool:
         return id(_base(t)) in self.buf
@@ -72,14 +83,14 @@ class Grads:
             return g
         return g.as_strided(t.shape, t.stride(), t.storage_offset() - b.storage_offset())
 
-    def add(self, t: Optional[torch.Tensor], g: torch.Tensor) -> None:
+    def add(self, t: Optional[torch.Tensor], g: torch.Tensor, alpha: float = 1.0) -> None:
         if t is None:
             return
         v = self.view(t)
         if g.dim() == 2 and v.dim() == 2:
-            v[:g.shape[0], :g.shape[1]].add_(g.float())
+            self.B.grad_acc(v[:g.shape[0], :g.shape[1]], g, alpha)
         else:
-            v.add_(g.float().reshape(v.shape))
+            self.B.grad_acc(v, g.reshape(v.shape), alpha)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -108,20 +119,16 @@ def _rule_gemm(B, x, w, out, kw):
         else:
             dpre = dy
         if G.wants(w):                                       # trainable weight: dW[n, tap, k] = sum_m dpre[m, n] * gather(x)[m, tap, k]
-            G.add_param(w, B.gemm_dw(dpre, x, taps=taps, K=K, M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv")))
+            B.gemm_dw(dpre, x, dst=G.param(w), taps=taps, K=K, M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
         if G.wants(kw.get("bias")):
-            G.add_param(kw["bias"], B.colsum_grad(dpre))
-        dx = B.gemm_dx(dpre, w, x_rows=x.shape[0], M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
-        G.add(x[:, :K], dx)
+            B.colsum_grad(dpre[:M], dst=G.param(kw["bias"]))
+        B.gemm_dx(dpre, w, dst=G.view(x[:, :K]), M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
     return rule
 
 
-def _rule_attention(B, q, k, v, out, kw):
+def _rule_attention(B, q, k, v, out, lse, kw):
     def rule(G: Grads):
-        dq, dk, dv = B.attention_bwd(q, k, v, out, G.view(out), **kw)
-        G.add(q, dq)
-        G.add(k, dk)
-        G.add(v, dv)
+        B.attention_bwd(q, k, v, out, G.view(out), dq=G.view(q), dk=G.view(k), dv=G.view(v), lse=lse, **kw)
     return rule
 
 
@@ -146,13 +153,16 @@ def _rule_layernorm(B, x, gamma, beta, out, eps):
     def rule(G: Grads):
         dy = G.view(out)
         if G.wants(gamma) or G.wants(beta):
-            dg, db = B.layernorm_bwd_params(x, dy, eps=eps)
-            if G.wants(gamma):
-                G.add_param(gamma, dg)
-            if G.wants(beta):
-                G.add_param(beta, db)
+            B.layernorm_bwd_params(x, dy, dgamma=G.param(gamma) if G.wants(gamma) else None, dbeta=G.param(beta) if G.wants(beta) else None, eps=eps)
         G.add(x, B.layernorm_bwd(x, gamma, dy, eps=eps))
     return rule
+
+
+# operators without a backward rule that may run while a tape records: they read nothing the loss is differentiated through (the timestep
+# embedding, conv_in on the input latents, layout conversions, allocation) or produce gradient-free side data
+_GRADIENT_FREE = {"empty", "timestep_embed", "conv_small", "nchw5_to_rows", "rows_to_nchw5", "rows_to_nchw", "nchw_to_rows", "cfg_ddim", "gaussian_sample",
+                  "grad_acc", "gemm_dx", "gemm_dw", "geglu_bwd", "attention_bwd", "temporal_attention_bwd", "groupnorm_bwd", "layernorm_bwd", "layernorm_bwd_params",
+                  "colsum_grad", "relu_bwd", "sumsq_absmax", "adamw", "cast_f16", "mse_seed", "invalidate_transposed", "PROFILE", "STEP_PARAMS", "F16"}
 
 
 class Recorder:
@@ -165,7 +175,10 @@ class Recorder:
         self._written: Dict[int, List[Tuple[int, int, int, int]]] = {}
 
     def __getattr__(self, name):
-        return getattr(self._b, name)
+        # a compute operator without a rule on a differentiated path would cut the gradient silently: only the gradient-free ones pass
+        if name.startswith("_") or name in _GRADIENT_FREE:
+            return getattr(self._b, name)
+        raise NotImplementedError(f"autodiff: operator `{name}` has no backward rule and is not known to be gradient-free; it may not run while a tape records")
 
     # -- single-assignment check: (row0, row1, col0, col1) boxes written per allocation must not overlap
     def _mark(self, t: torch.Tensor) -> None:
@@ -192,10 +205,11 @@ class Recorder:
         return out
 
     def attention(self, q, k, v, **kw):
-        out = self._own(self._b.attention(q, k, v, **kw), kw)
+        lse = torch.empty((kw["n_items"] * kw["nq"], kw["heads"]), dtype=torch.float32, device=q.device)   # stashed for the fused backward
+        out = self._own(self._b.attention(q, k, v, lse=lse, **kw), kw)
         self._mark(out)
         kw = {a: b for a, b in kw.items() if a != "out"}
-        self._t.record([out], _rule_attention(self._b, q, k, v, out, kw), q, k, v, kw.get("mask"))
+        self._t.record([out], _rule_attention(self._b, q, k, v, out, lse, kw), q, k, v, lse, kw.get("mask"))
         return out
 
     def temporal_attention(self, q, k, v, **kw):
@@ -227,7 +241,7 @@ class Recorder:
             raise RuntimeError("autodiff: in-place axpy_rows is not differentiated")
         out = self._b.axpy_rows(y, x, a_, alpha)
         self._mark(y)
-        self._t.record([y], lambda G: (G.add(x, G.view(y)), G.add(a_, G.view(y) * alpha)), x, a_)
+        self._t.record([y], lambda G: (G.add(x, G.view(y)), G.add(a_, G.view(y), alpha)), x, a_)
         return out
 
 
@@ -238,7 +252,7 @@ class record:
         self.m = module
 
     def __enter__(self) -> Tape:
-        self.tape = Tape()
+        self.tape = Tape(self.m.ops)
         self.saved = self.m.ops
         self.m.ops = Recorder(self.saved, self.tape)
         return self.tape
@@ -248,13 +262,15 @@ class record:
         return False
 
 
-def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]], trainable: Optional[Dict[int, str]] = None) -> Grads:
-    """seeds: (tensor the forward produced, gradient of the loss w.r.t. it).  Returns the gradient store; `G.view(t)` of any
-    tensor the forward read is its gradient (zeros if nothing depended on it).  trainable: id(packed parameter tensor) -> key
-    (weights.Packed.trainable_ids); their gradients, in the packed layout, end up in `G.params[key]`."""
-    G = Grads(trainable)
+def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]], trainable: Optional[Dict[int, str]] = None, backend=None,
+             param_buffers: Optional[Dict[str, torch.Tensor]] = None, seed_scale: float = 1.0) -> Grads:
+    """seeds: (tensor the forward produced, gradient of the loss w.r.t. it), entered as seed_scale * gradient (the loss scale).  Returns
+    the gradient store; `G.view(t)` of any tensor the forward read is its gradient (zeros if nothing depended on it).  trainable:
+    id(packed parameter tensor) -> key (weights.Packed.trainable_ids); their gradients, in the packed layout, end up in `G.params[key]`
+    (accumulated into `param_buffers[key]` when the caller provides the buffers).  backend: the ops module the tape recorded on."""
+    G = Grads(backend if backend is not None else tape.backend, trainable, param_buffers)
     for t, g in seeds:
-        G.add(t, g)
+        G.add(t, g, seed_scale)
     for outs, rule in reversed(tape.entries):
         if any(G.has(o) for o in outs):
             rule(G)

@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 3
+ABI_VERSION = 4
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
         ("frames", _i32), ("npix", _i32), ("chunk", _i32),
         ("frame0", _i32), ("frames_total", _i32), ("halo_prev", _i32), ("halo_next", _i32),
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
-        ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32),
+        ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32), ("res_rows", _i32), ("res2_rows", _i32),
     ]
 
 
@@ -48,7 +48,25 @@ class AttnArgs(C.Structure):
         ("heads", _i32), ("dh", _i32),
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
         ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
-        ("vsum", _vp), ("n_kv_items", _i32),
+        ("vsum", _vp), ("n_kv_items", _i32), ("q_items", _i32), ("lse", _vp),
+    ]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [
+        ("Q", _vp), ("K", _vp), ("V", _vp), ("O", _vp), ("dO", _vp), ("lse", _vp), ("dQ", _vp), ("dK", _vp), ("dV", _vp), ("delta", _vp),
+        ("ldq", _i32), ("ldk", _i32), ("ldv", _i32), ("ldo", _i32), ("lddo", _i32), ("lddq", _i32), ("lddk", _i32), ("lddv", _i32),
+        ("heads", _i32), ("dh", _i32),
+        ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32), ("n_kv_items", _i32),
+        ("seg_item", _vp), ("inv_ptr", _vp), ("inv_item", _vp), ("scale", _f32),
+    ]
+
+
+class GemmDwArgs(C.Structure):
+    _fields_ = [
+        ("dY", _vp), ("X", _vp), ("dW", _vp), ("work", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32), ("lddy", _i32), ("ldx", _i32), ("dy_is_f16", _i32),
+        ("taps", _i32), ("tap", _i32), ("gather", _i32), ("frames", _i32), ("npix", _i32), ("chunk", _i32), ("alpha", _f32),
     ]
 
 
@@ -111,6 +129,20 @@ SYMBOLS = {
     "me_timestep_embed_dev": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "me_cfg_ddim_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "me_gaussian_sample": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp]),
+    "me_attn_bwd": (C.c_int, [C.POINTER(AttnBwdArgs), _vp]),
+    "me_gemm_dw": (C.c_int, [C.POINTER(GemmDwArgs), _vp]),
+    "me_gemm_dw_work_bytes": (_i64, [_i32, _i32, _i32]),
+    "me_colsum": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _i32, _f32, _vp, _vp]),
+    "me_colsum_work_bytes": (_i64, [_i32]),
+    "me_layernorm_bwd_params": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _f32, _vp, _vp]),
+    "me_layernorm_bwd_params_work_bytes": (_i64, [_i64, _i32]),
+    "me_grad_acc": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _i32, _vp]),
+    "me_sumsq_absmax": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "me_sumsq_work_bytes": (_i64, []),
+    "me_adamw": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _f32, _f32, _vp]),
+    "me_cast_f16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "me_cast_rows_f16": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "me_mse_seed": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "me_nchw_to_rows": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "me_rows_to_nchw": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
 }

@@ -516,11 +516,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     for (int qt = 0; qt < QT; ++qt) {
       const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
       qrow[qt] = q < a.nq ? item * a.nq + q : -1;
+      const long qsrc = (long)(a.q_items > 0 ? item % a.q_items : item) * a.nq + q;   // queries shared by several batch entries
 #pragma unroll
       for (int ks = 0; ks < D32; ++ks) {
         const int d = ks * 32 + g * 8;
         U128 u;
-        u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
+        u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + qsrc * a.ldq + h * DH + d) : zero128();
         if constexpr (decltype(scaled_c)::value) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) u.e[e] = (f16)((float)u.e[e] * c);
@@ -923,6 +924,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     } else {
       l = xor32_sum(xor16_sum(lrun[qt]));
     }
+    // log2 of the softmax denominator in exp2 units (offset + log2 of the sum): what me_attn_bwd needs to rebuild P per tile
+    if (a.lse && ndual == 0 && g == 0 && qrow[qt] >= 0) reinterpret_cast<float*>(a.lse)[(long)qrow[qt] * a.heads + h] = mrun[qt] + __log2f(l);
     float f1 = 1.0f, f2 = 0.f;
     if (ndual > 0) {   // wave-uniform
       const float mp = fmaxf(mrun[qt], 0.f);
@@ -1036,6 +1039,8 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (a->n_items <= 0 || a->nq <= 0 || a->nk <= 0 || a->heads <= 0 || a->nseg < 1 || a->nseg > 3) { me_set_error("me_attn: bad sizes"); return ME_EINVAL; }
   if (a->ldq % 8 || a->ldk % 8 || a->ldv % 8 || a->ldo % 4) { me_set_error("me_attn: row strides must be multiples of 8 (Q,K,V) / 4 (O)"); return ME_EINVAL; }
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15 || ((uintptr_t)a->O & 7)) { me_set_error("me_attn: misaligned pointer"); return ME_EINVAL; }
+  if (a->q_items < 0 || (a->general_dual && (a->q_items > 0 || a->lse))) { me_set_error("me_attn: q_items / lse are not served by the general-dual kernel"); return ME_EINVAL; }
+  if (a->lse && a->vsum) { me_set_error("me_attn: lse is written for plain segments only"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (a->general_dual) {   // non-binary masks: the mask-reading kernel

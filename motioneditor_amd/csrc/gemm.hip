@@ -74,9 +74,11 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
   if (a.gather == ME_GATHER_CONV3) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const int iy = r.y0 + ky, ix = r.x0 + kx;
-    const int Hv = a.Hin << a.ups, Wv = a.Win << a.ups;
+    const int sh = a.ups ? 1 : 0;   // ups 1: nearest 2x, ups 2: zero-stuffed 2x (odd virtual pixels are zeros)
+    const int Hv = a.Hin << sh, Wv = a.Win << sh;
     if (iy < 0 || iy >= Hv || ix < 0 || ix >= Wv) return -1;
-    return r.base + (iy >> a.ups) * a.Win + (ix >> a.ups);
+    if (a.ups == 2 && ((iy | ix) & 1)) return -1;
+    return r.base + (iy >> sh) * a.Win + (ix >> sh);
   }
   const int dt = tap - 1;  // TCONV over global frames: same chunk, inside the clip
   const int ftot = a.frames_total > 0 ? a.frames_total : a.frames;
@@ -132,6 +134,8 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
   union P4 { f16x2 h[2]; uint2 u; };
   P4 o[MT][NT];
   int mrow[MT];
+  auto rr = [&](int m) { return a.res_rows > 0 ? m % a.res_rows : m; };   // residual shared by several batch entries (wave-uniform test)
+  auto rr2 = [&](int m) { return a.res2_rows > 0 ? m % a.res2_rows : m; };
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     mrow[i] = rowfn(i);
@@ -190,8 +194,8 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
       }
     };
     if constexpr (has_rv) { add_wide(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); add_narrow_last(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); }
-    if constexpr (has_res) { add_wide(res, [&](int m) { return (long)m * a.ldr; }); add_narrow_last(res, [&](int m) { return (long)m * a.ldr; }); }
-    if constexpr (has_res2) { add_wide(res2, [&](int m) { return (long)m * a.ldr2; }); add_narrow_last(res2, [&](int m) { return (long)m * a.ldr2; }); }
+    if constexpr (has_res) { add_wide(res, [&](int m) { return (long)rr(m) * a.ldr; }); add_narrow_last(res, [&](int m) { return (long)rr(m) * a.ldr; }); }
+    if constexpr (has_res2) { add_wide(res2, [&](int m) { return (long)rr2(m) * a.ldr2; }); add_narrow_last(res2, [&](int m) { return (long)rr2(m) * a.ldr2; }); }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if (mrow[i] < 0) continue;
@@ -223,8 +227,8 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
       }
   };
   if constexpr (has_rv) add_term(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; });
-  if constexpr (has_res) add_term(res, [&](int m) { return (long)m * a.ldr; });
-  if constexpr (has_res2) add_term(res2, [&](int m) { return (long)m * a.ldr2; });
+  if constexpr (has_res) add_term(res, [&](int m) { return (long)rr(m) * a.ldr; });
+  if constexpr (has_res2) add_term(res2, [&](int m) { return (long)rr2(m) * a.ldr2; });
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (mrow[i] < 0) continue;
@@ -272,15 +276,16 @@ __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
       }
+      const int mr = a.res_rows > 0 ? m % a.res_rows : m;
       if (res) {
         U64 b;
-        b.u = *reinterpret_cast<const uint2*>(res + (long)m * a.ldr + n);
+        b.u = *reinterpret_cast<const uint2*>(res + (long)mr * a.ldr + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
       if (res2) {
         U64 b;
-        b.u = *reinterpret_cast<const uint2*>(res2 + (long)m * a.ldr2 + n);
+        b.u = *reinterpret_cast<const uint2*>(res2 + (long)(a.res2_rows > 0 ? m % a.res2_rows : m) * a.ldr2 + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
       }
@@ -855,7 +860,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (((uintptr_t)a->X | (uintptr_t)a->W) & 15 || ((uintptr_t)a->C & 7)) { me_set_error("me_gemm: misaligned pointer"); return ME_EINVAL; }
   if (a->gather < 0 || a->gather > 2) { me_set_error("me_gemm: bad gather mode"); return ME_EINVAL; }
   if (a->gather == ME_GATHER_CONV3) {
-    if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0 || (a->stride != 1 && a->stride != 2) || (a->ups != 0 && a->ups != 1) ||
+    if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0 || (a->stride != 1 && a->stride != 2) || a->ups < 0 || a->ups > 2 ||
         (a->pad0 != 0 && a->pad0 != 1) || a->M % (a->Hout * a->Wout)) { me_set_error("me_gemm: bad conv geometry"); return ME_EINVAL; }
   }
   if (a->gather == ME_GATHER_TCONV) {
@@ -866,6 +871,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->rowvec && (a->rows_per_vec <= 0 || a->ldrv % 4 || ((uintptr_t)a->rowvec & 7))) { me_set_error("me_gemm: bad rowvec"); return ME_EINVAL; }
   if (a->res && (a->ldr % 4 || ((uintptr_t)a->res & 7))) { me_set_error("me_gemm: bad residual"); return ME_EINVAL; }
   if (a->res2 && (a->ldr2 % 4 || ((uintptr_t)a->res2 & 7))) { me_set_error("me_gemm: bad second residual"); return ME_EINVAL; }
+  if (a->res_rows < 0 || a->res2_rows < 0) { me_set_error("me_gemm: negative res_rows"); return ME_EINVAL; }
   if (a->act < 0 || a->act > 2) { me_set_error("me_gemm: bad activation"); return ME_EINVAL; }
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
   if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act || a->alpha != 1.0f)) { me_set_error("me_gemm: geglu needs N % 32 == 0, alpha == 1 and no rowvec/res/act"); return ME_EINVAL; }

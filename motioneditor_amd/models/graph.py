@@ -20,6 +20,7 @@ from ..weights import Packed
 
 HEADS = 8
 ADAPTER_CHUNK = 8  # hard-coded num_frames=8 in the reference adapter (controlnet_adapter.py:414,438,472)
+COND_EMBED_CACHE = True   # ControlNet conditioning embedding of an unchanged skeleton tensor is computed once per run (controlnet_forward)
 
 
 @dataclass
@@ -199,7 +200,7 @@ def _ext_rows(x: "Act", shard) -> int:
 
 
 def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_seg, *, spatial, temporal, place: str,
-                sc_attn: bool, has_temp: bool, shard=None) -> Act:
+                sc_attn: bool, has_temp: bool, shard=None, text_kv: Optional[torch.Tensor] = None) -> Act:
     """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C]."""
     t, C = x.t, x.C
     dh = C // HEADS
@@ -218,7 +219,8 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
     # --- attn2 (CrossAttention, attention_2d.py:115-201): K/V projected once per text row
     if text is not None:
         q = ops.gemm(_ln(P, p + ".norm2", t), P.mat(p + ".attn2.to_q.weight"))
-        kv = ops.gemm(text, P.fused([p + ".attn2.to_k.weight", p + ".attn2.to_v.weight"]))
+        # k | v of the text rows: this block's column slice of the one GEMM that projects the text for every layer (text_kv_all), or its own
+        kv = text_kv if text_kv is not None else ops.gemm(text, P.fused([p + ".attn2.to_k.weight", p + ".attn2.to_v.weight"]))
         call = AttnCall(q, kv[:, :C], kv[:, C:], x.B, x.f, x.N, dh, 77, True)
         if spatial is not None:
             a = spatial(call=call, is_cross=True, place_in_unet=place, num_heads=HEADS, text_seg=text_seg)
@@ -235,13 +237,13 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
 
 
 def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, temporal=None, place: str = "", sc_attn: bool = True,
-                  has_temp: bool = True, shard=None, out: Optional[torch.Tensor] = None) -> Act:
+                  has_temp: bool = True, shard=None, out: Optional[torch.Tensor] = None, text_kv: Optional[dict] = None) -> Act:
     """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out.
     out: where the block's result is written (a column slice of the next skip-concat buffer)."""
     n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
     t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
     t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
-                    sc_attn=sc_attn, has_temp=has_temp, shard=shard).t
+                    sc_attn=sc_attn, has_temp=has_temp, shard=shard, text_kv=None if text_kv is None else text_kv[p]).t
     return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t, **({} if out is None else {"out": out})))
 
 
@@ -271,20 +273,50 @@ def time_embedding(P: Packed, t: float, names: List[str], device):
     return temb, offs
 
 
+def attention_block_names(n_up: bool) -> List[str]:
+    names = [f"down_blocks.{i}.attentions.{j}" for i in range(3) for j in range(2)] + ["mid_block.attentions.0"]
+    if n_up:
+        names += [f"up_blocks.{i}.attentions.{j}" for i in range(1, 4) for j in range(3)]
+    return names
+
+
+def text_kv_all(P: Packed, text: torch.Tensor, names: List[str]) -> dict:
+    """attn2.to_k | attn2.to_v of EVERY transformer block applied to the text rows in one GEMM (the reference projects the text in each
+    CrossAttention.forward, attention_2d.py:146-147, once per frame): 16 (UNet) / 7 (ControlNet) launches on [B*77, 768] become one.
+    Returns block name -> its [rows, 2C] column slice."""
+    ws = []
+    for n in names:
+        t = n + ".transformer_blocks.0.attn2."
+        ws += [t + "to_k.weight", t + "to_v.weight"]
+    kv = ops.gemm(text, P.fused(ws))
+    out, o = {}, 0
+    for n in names:
+        c2 = 2 * P.vec(n + ".norm.weight").shape[0]
+        out[n] = kv[:, o:o + c2]
+        o += c2
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # ControlAdapter (controlnet_adapter.py:437-565)
 # ---------------------------------------------------------------------------------------------
-def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int] = None, shard=None) -> torch.Tensor:
+def adapter_block(P: Packed, p: str, x: Act, src, nb: Optional[int] = None, shard=None) -> torch.Tensor:
     """ResnetBlock.forward (controlnet_adapter.py:497-534).  x: ControlNet residual rows [(b t N), C];
-    src: UNet edit-branch skip rows [(nb t N), C].  Returns motion residual rows [(nb t N), C].
+    src: UNet edit-branch skip rows [(nb t N), C], or a list of nb row tensors [(t N), C] (the edit rows of the batch-4 skip, read in
+    place).  Returns motion residual rows [(nb t N), C].
 
     nb > x.B (x.B == 1): the ControlNet residual is SHARED by the nb batch entries (the reference feeds the
     ControlNet the same edit latent twice, see pipelines.MotionEditorPipeline.dedup_controlnet).  Everything up to
     the pose cross-attention depends on x only -- temporal convs, sparse-causal self-attention, cross_pose_norm,
-    the pose query projection -- so it is computed once and broadcast."""
+    the pose query projection -- so it is computed once and READ by every batch entry: the attention kernel takes the shared
+    queries (q_items), the GEMM epilogues the shared residuals (res_rows / res2_rows); nothing is copied."""
     t, C, dev = x.t, x.C, x.t.device
     dh = C // HEADS
     nb = x.B if nb is None else nb
+    share = nb != x.B
+    if share:
+        assert x.B == 1
+    rows_x = t.shape[0]
     # conv path: TemporalConv(k=3) -> ReLU -> TemporalConv(k=1) -> + x, on independent chunks of 8 frames
     if shard is None:
         tx = t
@@ -301,17 +333,41 @@ def adapter_block(P: Packed, p: str, x: Act, src: torch.Tensor, nb: Optional[int
     a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
     # pose x UNet-feature cross attention, per frame
     q = ops.gemm(a, P.mat(p + ".attn_pose.to_q.weight"))
-    if nb != x.B:   # broadcast the x-only part to every batch entry
-        assert x.B == 1
-        rep = lambda z: torch.cat([z] * nb)  # noqa: E731
-        hc, a, q = rep(hc), rep(a), rep(q)
-    kv = ops.gemm(src, P.fused([p + ".attn_pose.to_k.weight", p + ".attn_pose.to_v.weight"]))
-    ap = AttnCall(q, kv[:, :C], kv[:, C:], nb, x.f, x.N, dh, x.N, True).run(*segments.self_items(nb * x.f, dev))
-    a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a)
+    wkv = P.fused([p + ".attn_pose.to_k.weight", p + ".attn_pose.to_v.weight"])
+    if isinstance(src, (list, tuple)):   # the edit rows of the UNet skip, projected where they lie: one GEMM per batch entry, no gather copy
+        n1 = src[0].shape[0]
+        kv = torch.empty((len(src) * n1, 2 * C), dtype=P.dtype, device=dev)
+        for k, part in enumerate(src):
+            ops.gemm(part, wkv, out=kv[k * n1:(k + 1) * n1])
+    else:
+        kv = ops.gemm(src, wkv)
+    seg = segments.self_items(nb * x.f, dev)
+    ap = ops.attention(q, kv[:, :C], kv[:, C:], heads=HEADS, dh=dh, n_items=nb * x.f, nq=x.N, nk=x.N, seg_item=seg[0], seg_mode=seg[1],
+                       **({"q_items": x.B * x.f} if share else {}))
+    a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a, **({"res_rows": rows_x} if share else {}))
     a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
     # causal temporal attention over the TRUE frame count
     at = _temporal_attn(P, p + ".attn_self_temp", _ln(P, p + ".norm_self_temp", a), C, nb, x.f, x.N, dh, shard)
-    return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc)
+    return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc,
+                    **({"res2_rows": rows_x} if share else {}))
+
+
+def adapter_pack(P: Packed, prefix: str = "controlnet_adapter.") -> List[str]:
+    """Build (in the order and the fusions adapter_block uses them) every packed tensor of the adapter and return their cache keys:
+    what util.AdapterTrainer trains.  A gradient that reaches a packed tensor outside this list is reported by the trainer."""
+    for i in range(12):
+        p = f"{prefix}body.{i}"
+        P.mat(p + ".block1.weight"), P.vec(p + ".block1.bias"), P.mat(p + ".block2.weight"), P.vec(p + ".block2.bias")
+        for a in ("attn_temp", "attn_self_temp"):
+            P.fused([f"{p}.{a}.to_q.weight", f"{p}.{a}.to_k.weight", f"{p}.{a}.to_v.weight"])
+        P.mat(p + ".attn_pose.to_q.weight")
+        P.fused([p + ".attn_pose.to_k.weight", p + ".attn_pose.to_v.weight"])
+        for a in ("attn_temp", "attn_pose", "attn_self_temp"):
+            P.mat(f"{p}.{a}.to_out.0.weight"), P.vec(f"{p}.{a}.to_out.0.bias")
+        for n in ("norm_temp", "cross_pose_norm", "ff_norm", "norm_self_temp"):
+            P.vec(f"{p}.{n}.weight"), P.vec(f"{p}.{n}.bias")
+        P.geglu_mat(p + ".ff.net.0.proj.weight"), P.geglu_vec(p + ".ff.net.0.proj.bias"), P.mat(p + ".ff.net.2.weight"), P.vec(p + ".ff.net.2.bias")
+    return sorted(P.trainable_ids(prefix).values())
 
 
 # ---------------------------------------------------------------------------------------------
@@ -340,7 +396,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     text = text_rows(ehs, P.dtype)
     tseg = segments.cross_text(B, f, dev)
     # normal_infer (DDIM inversion, inference.py:292): attn1 = plain per-frame self-attention (attention_2d.py:770-777)
-    kw = dict(spatial=spatial, temporal=temporal, shard=shard, sc_attn=not normal_infer)   # shard: this rank holds f = f_total / world consecutive frames
+    kw = dict(spatial=spatial, temporal=temporal, shard=shard, sc_attn=not normal_infer,   # shard: this rank holds f = f_total / world consecutive frames
+              text_kv=text_kv_all(P, text, attention_block_names(True)))
 
     x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
                            img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
@@ -354,13 +411,11 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
 
     def adapter_for(i: int, s: Act) -> torch.Tensor:
         r = down_res[i]
-        if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481)
+        if two_branch:   # adapter sees the edit rows only (unet_2d_condition.py:479-481): read in place, batch entry by batch entry
             n = s.f * s.N
-            src = torch.empty((len(edit_rows) * n, s.C), dtype=P.dtype, device=dev)
-            for k, eb in enumerate(edit_rows):
-                ops.copy_rows(src[k * n:(k + 1) * n], s.rows_of(eb))
             shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
-            return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), src, len(edit_rows), shard)
+            return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), [s.rows_of(eb) for eb in edit_rows],
+                                 len(edit_rows), shard)
         return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard)   # (unet_2d_condition.py:483-485)
 
     def push_skip(s: Act) -> None:
@@ -483,13 +538,23 @@ def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int
     text = text_rows(prompt, P.dtype)
     tseg = segments.cross_interleaved(nimg, prompt.shape[0], dev, row_offset)   # row_offset: this rank's first "(b f)" row in the full ControlNet batch
 
-    # conditioning embedding: 3->16 (direct), then 16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2 (SiLU each), 256->320
+    # conditioning embedding: 3->16 (direct), then 16->16, 16->32 s2, 32->32, 32->96 s2, 96->96, 96->256 s2 (SiLU each), 256->320.
+    # Everything up to the last convolution depends on the skeleton images only -- the same tensor in every denoising step of a run
+    # (pipeline_motion_editor.py:556-570 prepares it once, before the loop) -- so it is computed at the first step and kept
+    # (COND_EMBED_CACHE = False recomputes it every step, as the reference does).
     H8, W8 = cond.shape[-2], cond.shape[-1]
     cond = cond.contiguous()
-    c = Act(ops.conv_small(cond, P.mat32("controlnet_cond_embedding.conv_in.weight"), P.vec32("controlnet_cond_embedding.conv_in.bias"),
-                           n_img=nimg, Cin=3, H=H8, Wd=W8, img_stride=3 * H8 * W8, ch_stride=H8 * W8, silu=True), nimg, 1, H8, W8)
-    for i in range(6):
-        c = conv3x3(P, f"controlnet_cond_embedding.blocks.{i}", c, stride=2 if i % 2 == 1 else 1, act=2)
+    ckey = (cond.data_ptr(), cond._version, tuple(cond.shape), cond.dtype, nimg)
+    hit = P.cache.get("cond_embed") if COND_EMBED_CACHE else None
+    if hit is not None and hit[0] == ckey:
+        c = hit[1]
+    else:
+        c = Act(ops.conv_small(cond, P.mat32("controlnet_cond_embedding.conv_in.weight"), P.vec32("controlnet_cond_embedding.conv_in.bias"),
+                               n_img=nimg, Cin=3, H=H8, Wd=W8, img_stride=3 * H8 * W8, ch_stride=H8 * W8, silu=True), nimg, 1, H8, W8)
+        for i in range(6):
+            c = conv3x3(P, f"controlnet_cond_embedding.blocks.{i}", c, stride=2 if i % 2 == 1 else 1, act=2)
+        if COND_EMBED_CACHE:
+            P.cache["cond_embed"] = (ckey, c, cond)   # cond kept alive: the key is its address
     # conv_in(sample) per ControlNet batch entry, then + cond embedding in the last cond conv's epilogue
     x0 = torch.empty((nimg * h * w, 320), dtype=P.dtype, device=dev)
     for bi, li in enumerate(lat_index):
@@ -499,20 +564,21 @@ def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int
     x = conv3x3(P, "controlnet_cond_embedding.conv_out", c, res=x0)
     x = Act(x.t, nimg, 1, h, w)
 
+    tkv = text_kv_all(P, text, attention_block_names(False))
     outs = [x]
     for i in range(4):
         for j in range(2):
             n = f"down_blocks.{i}.resnets.{j}"
             x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
             if DOWN_HAS_ATTN[i]:
-                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, sc_attn=False, has_temp=False)
+                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, sc_attn=False, has_temp=False, text_kv=tkv)
             outs.append(x)
         if i < 3:
             x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
             outs.append(x)
     n = "mid_block.resnets.0"
     x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
-    x = transformer2d(P, "mid_block.attentions.0", x, text, tseg, sc_attn=False, has_temp=False)
+    x = transformer2d(P, "mid_block.attentions.0", x, text, tseg, sc_attn=False, has_temp=False, text_kv=tkv)
     n = "mid_block.resnets.1"
     x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=True)
     down = [ops.gemm(o.t, P.mat(f"controlnet_down_blocks.{i}.weight"), bias=P.vec(f"controlnet_down_blocks.{i}.bias"), alpha=1.0)

@@ -13,7 +13,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import capi
-from .capi import AttnArgs, ConvSmallArgs, GemmArgs, GroupNormArgs, LayerNormArgs, TAttnArgs
+from .capi import AttnArgs, AttnBwdArgs, ConvSmallArgs, GemmArgs, GemmDwArgs, GroupNormArgs, LayerNormArgs, TAttnArgs
 
 F16 = torch.float16
 
@@ -73,11 +73,11 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
          bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
          res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
-         tconv: Optional[Tuple[int, ...]] = None) -> torch.Tensor:
+         tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0) -> torch.Tensor:
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
 
     w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
-    3 for ``tconv=(frames, npix, chunk)``)."""
+    3 for ``tconv=(frames, npix, chunk)``).  res_rows / res2_rows > 0: res / res2 holds that many rows, output row m reads row m % rows."""
     _chk2d(x, "gemm.x")
     if w.dtype != F16 or not w.is_contiguous() or w.dim() != 3:
         raise ValueError("gemm.w: expected contiguous fp16 [N, taps, K]")
@@ -125,6 +125,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.geglu = 1 if geglu else 0
     a.act = act
     a.alpha = alpha
+    a.res_rows, a.res2_rows = res_rows, res2_rows
+    for r_, n_ in ((res, res_rows), (res2, res2_rows)):
+        if r_ is not None and r_.shape[0] < (n_ or M):
+            raise ValueError("gemm: residual has fewer rows than the output reads")
     e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
     if e0 is not None:
@@ -157,9 +161,13 @@ def conv_small(inp: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, dh: int, n_items: int, nq: int, nk: int,
               seg_item: torch.Tensor, seg_mode: torch.Tensor, mask: Optional[torch.Tensor] = None,
-              scale: Optional[float] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_items: int = 0, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q_items > 0: q holds q_items query items, item i reads item i % q_items.  lse: fp32 [n_items * nq, heads] that receives the
+    log2-domain log-sum-exp of every (query, head) -- what attention_bwd rebuilds P from (plain segments only)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk2d(t, "attention." + n)
+    if q.shape[0] < (q_items or n_items) * nq:
+        raise ValueError("attention: q has fewer rows than the items read")
     if seg_item.dtype != torch.int32 or seg_mode.dtype != torch.int32 or seg_item.shape != seg_mode.shape or seg_item.shape[0] != n_items:
         raise ValueError("attention: seg tables must be int32 [n_items, nseg]")
     if out is None:
@@ -178,6 +186,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
         gd = bool(((seg_mode == 1) | (seg_mode == 2)).any().item())
         bd = bool((seg_mode == 3).any().item())
     a.general_dual = 1 if gd else 0
+    a.q_items = q_items
+    if lse is not None:
+        if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != n_items * nq * heads:
+            raise ValueError("attention: lse must be a contiguous fp32 [n_items * nq, heads] tensor")
+        a.lse = lse.data_ptr()
     if bd and not gd:   # binary dual keys: me_attn needs fp32 scratch for the per-kv-item column sums of V
         n_kv = k.shape[0] // nk
         vsum = torch.empty(capi.lib().me_attn_vsum_bytes(n_kv, heads * dh) // 4, dtype=torch.float32, device=q.device)
@@ -393,19 +406,21 @@ def rows_to_nchw5(rows: torch.Tensor, B: int, Cc: int, f: int, h: int, w: int) -
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Backward primitives (the kernel-level contract of motioneditor_amd/autodiff.py; SURVEY.md 8f rank 1 "null-text" and rank 4
-# "adapter training").  Their CPU statements live in tests/emu_ops.py and are pinned, through util.null_optimization, against
-# the reference's own optimisation.  The HIP kernels are not built yet: these entries fail loudly -- no fallback.
+# "adapter training").  Their CPU statements live in tests/emu_ops.py and are pinned, through util.null_optimization /
+# util.adapter_training_grads, against the reference's own optimisation.  Every entry is a HIP kernel (csrc/bwd.hip, attn_bwd.hip,
+# train.hip) or me_gemm itself on transposed weights; torch only allocates and moves data (transposes of constant weights, fp16
+# casts of gradients) -- no torch arithmetic, no CPU fallback.  Contract: gradients are fp32 [rows, ld] views of the tape's
+# buffers; entries that take `dst` ACCUMULATE into it (+=).  Not differentiated (they raise): edited / masked attention segments,
+# shared query items, frame- / pixel-sharded row orders, the temporal editor's kv_map, 3x3-convolution weights, the pad-(0,1,0,1)
+# convolution of the VAE encoder.
 # ---------------------------------------------------------------------------------------------------------------------
-def _no_kernel(name: str):
-    raise NotImplementedError(f"ops.{name}: the backward kernel is not built yet (DESIGN.md section 9); there is no CPU fallback")
-
-
 _wT_cache = {}
 
 
 def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     """[N][taps][K] -> [K][taps reversed][N] (padded to N % 8 == 0): the weights of the input-gradient GEMM / correlation.  Built
-    once per weight tensor (a transpose of constants at first use) and kept: the backward doubles the weight memory."""
+    once per FROZEN weight tensor (a transpose of constants at first use) and kept: the backward doubles the weight memory.
+    Entries of tensors that are rewritten (trained parameters) are dropped by invalidate_transposed()."""
     key = (w.data_ptr(), tuple(w.shape))
     hit = _wT_cache.get(key)
     if hit is None:
@@ -417,47 +432,78 @@ def _w_transposed(w: torch.Tensor) -> torch.Tensor:
     return hit[0]
 
 
-def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
-    """dX [x_rows, K] of me_gemm's y = alpha * gather(x) @ w^T, by me_gemm itself on [K][taps reversed][N] weights: a dense GEMM,
-    the same stride-1 3x3 correlation / TemporalConv with the taps reversed; the stride-2 convolution's input gradient is that
-    correlation over the zero-upsampled dy, the nearest-upsampled convolution's the 2x2 sum of it.  dy arrives in fp32 from the
-    tape (loss-scaled by the caller so that fp16 holds it) and is rounded to fp16 like every activation."""
-    N, taps, K = w.shape
-    wt = _w_transposed(w)
-    n8 = wt.shape[2]
-    d16 = torch.zeros((dy.shape[0], n8), dtype=F16, device=dy.device) if n8 != dy.shape[1] else None
-    if d16 is None:
-        d16 = dy.to(F16)
-    else:
-        d16[:, :dy.shape[1]] = dy
-    if conv is not None:
-        Hin, Win, Hout, Wout, stride, ups = conv[:6]
-        if len(conv) > 6 and conv[6]:
-            raise NotImplementedError("gemm_dx: the pad-(0,1,0,1) convolution (VAE encoder) is not differentiated")
-        n_img = M // (Hout * Wout)
-        if stride == 2:      # dX = corr(zero-upsample(dy), reversed taps) at the input resolution (pad 1, kernel 3)
-            up = torch.zeros((n_img, Hin, Win, n8), dtype=F16, device=dy.device)
-            up[:, ::2, ::2] = d16.reshape(n_img, Hout, Wout, n8)
-            return gemm(up.reshape(-1, n8), wt, alpha=alpha, conv=(Hin, Win, Hin, Win, 1, 0))
-        du = gemm(d16, wt, alpha=alpha, conv=(Hout, Wout, Hout, Wout, 1, 0))
-        if ups:              # y = conv(nearest2x(x)): every input pixel collects its 2 x 2 block
-            return du.float().reshape(n_img, Hin, 2, Win, 2, K).sum(dim=(2, 4)).reshape(-1, K)
-        return du
-    if tconv is not None:
-        if len(tconv) > 3:
-            raise NotImplementedError("gemm_dx: the frame-sharded TemporalConv is not differentiated")
-        return gemm(d16, wt, alpha=alpha, tconv=tuple(tconv))
-    dx = gemm(d16, wt, alpha=alpha)
-    if x_rows > dx.shape[0]:
-        full = torch.zeros((x_rows, K), dtype=dx.dtype, device=dx.device)
-        full[:dx.shape[0]] = dx
-        return full
-    return dx
+def invalidate_transposed(tensors=None) -> None:
+    """Forget the cached transposes of `tensors` (all when None): call after a packed weight has been rewritten in place (the adapter
+    training step) or replaced -- a stale transpose would feed old weights to gemm_dx, a dead one pins device memory."""
+    if tensors is None:
+        _wT_cache.clear()
+        return
+    for t in tensors:
+        _wT_cache.pop((t.data_ptr(), tuple(t.shape)), None)
 
 
 def _chk_grad(t: torch.Tensor, name: str) -> None:
     if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
         raise ValueError(f"{name}: expected a CUDA fp32 2-D gradient view with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
+
+
+def grad_acc(dst: torch.Tensor, src: torch.Tensor, alpha: float = 1.0, pool: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+    """dst (fp32 view) += alpha * src (fp32 or fp16, at least dst's rows x cols; pool=(H, W): src holds the 2H x 2W grid whose 2 x 2 blocks
+    are summed into dst's H x W pixels).  1-D / n-D contiguous operands are treated as one row."""
+    if dst.dim() != 2:
+        if not (dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel() and dst.numel() % 4 == 0):
+            raise ValueError("grad_acc: non-2-D operands must be contiguous, of equal size and a multiple of 4 elements")
+        return grad_acc(dst.reshape(1, -1), src.reshape(1, -1), alpha).reshape(dst.shape)
+    _chk_grad(dst, "grad_acc.dst")
+    if src.dtype not in (torch.float32, F16) or src.dim() != 2 or src.stride(1) != 1:
+        raise ValueError("grad_acc: src must be an fp32 / fp16 2-D view with unit column stride")
+    rows, cols = dst.shape
+    if src.shape[1] < cols or src.shape[0] < (4 * rows if pool else rows):
+        raise ValueError(f"grad_acc: src {tuple(src.shape)} does not cover dst {tuple(dst.shape)}")
+    ph, pw = pool if pool else (0, 0)
+    capi.check(capi.lib().me_grad_acc(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), 1 if src.dtype == F16 else 0, rows, cols, float(alpha), ph, pw,
+                                      _stream()), "me_grad_acc")
+    return dst
+
+
+def _f16(dy: torch.Tensor, cols: int) -> torch.Tensor:
+    """fp32 gradient view -> contiguous fp16 [rows, cols >= dy.shape[1]] (zero-padded columns): the MFMA operand (me_cast_rows_f16)."""
+    if dy.dtype == F16 and dy.shape[1] == cols and dy.stride(1) == 1:
+        return dy
+    _chk_grad(dy, "gradient")
+    d16 = torch.empty((dy.shape[0], cols), dtype=F16, device=dy.device)
+    capi.check(capi.lib().me_cast_rows_f16(d16.data_ptr(), d16.stride(0), dy.data_ptr(), dy.stride(0), dy.shape[0], dy.shape[1], cols, _stream()), "me_cast_rows_f16")
+    return d16
+
+
+def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None):
+    """dst (fp32 view of dX, [x_rows, K]) += the input gradient of me_gemm's y = alpha * gather(x) @ w^T.  me_gemm itself on the
+    [K][taps reversed][N] weights: a dense GEMM, the stride-1 3x3 correlation / TemporalConv with reversed taps; the stride-2
+    convolution's input gradient is that correlation over the ZERO-STUFFED dy (gather mode ups = 2), the nearest-upsampled
+    convolution's the 2 x 2 block sum of it (me_grad_acc's pooling).  dy arrives loss-scaled and is cast to fp16 like every activation."""
+    N, taps, K = w.shape
+    wt = _w_transposed(w)
+    d16 = _f16(dy[:M], wt.shape[2])
+    pool = None
+    if conv is not None:
+        Hin, Win, Hout, Wout, stride, ups = conv[:6]
+        if len(conv) > 6 and conv[6]:
+            raise NotImplementedError("gemm_dx: the pad-(0,1,0,1) convolution (VAE encoder) is not differentiated")
+        if stride == 2:      # dX = corr(zero-stuffed dy, reversed taps) at the input resolution
+            du = gemm(d16, wt, M=(M // (Hout * Wout)) * Hin * Win, alpha=alpha, conv=(Hout, Wout, Hin, Win, 1, 2))
+        else:
+            du = gemm(d16, wt, alpha=alpha, conv=(Hout, Wout, Hout, Wout, 1, 0))
+            if ups:          # y = conv(nearest2x(x)): every input pixel collects its 2 x 2 block
+                pool = (Hin, Win)
+    elif tconv is not None:
+        if len(tconv) > 3:
+            raise NotImplementedError("gemm_dx: the frame-sharded TemporalConv is not differentiated")
+        du = gemm(d16, wt, alpha=alpha, tconv=tuple(tconv))
+    else:
+        du = gemm(d16, wt, alpha=alpha)
+    rows = du.shape[0] // 4 if pool else du.shape[0]
+    grad_acc(dst[:rows], du, 1.0, pool)
+    return dst
 
 
 def geglu_bwd(pre, dy):
@@ -470,59 +516,34 @@ def geglu_bwd(pre, dy):
     return out
 
 
-def attention_bwd(q, k, v, out, dout, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None):
-    """(dq, dk, dv) fp32 of me_attn for PLAIN segments ([prev | cur], self, text): first, matrix-materialising form.  Per (query item,
-    head) the logits, P, dP and dS are real [nq, keys] fp16 matrices built by kernels that already exist -- me_gemm (S = q K^T,
-    dP = dO V^T, dQ = dS K, dK = dS^T q, dV = P^T dO), me_softmax_rows, me_softmax_bwd_rows -- with torch only moving data (head
-    slices made contiguous and padded to 64 columns, transposes, the scatter of dk / dv back to the kv items).  Correct and
-    slow (~100 launches per item); the fused flash-style backward replaces it.  dout arrives loss-scaled."""
-    if mask is not None or bool((seg_mode != 0).any().item()):
+def attention_bwd(q, k, v, out, dout, *, dq, dk, dv, lse, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, q_items=0):
+    """(dq, dk, dv) += the input gradients of me_attn for PLAIN segments ([prev | cur], self, text, [first | prev]): the fused flash-style
+    backward (csrc/attn_bwd.hip): P rebuilt per tile from the forward's log-sum-exp `lse`, no score matrix, any key count.  dq / dk / dv are
+    fp32 views of the tape's gradient buffers; dout arrives loss-scaled."""
+    from . import segments
+    if mask is not None or segments.has_dual(seg_mode):
         raise NotImplementedError("attention_bwd: only plain segments are differentiated (the edited / masked attention is not)")
-    scale = dh ** -0.5 if scale is None else scale
-    C_ = heads * dh
-    dev = q.device
-    dq = torch.zeros((n_items * nq, C_), dtype=torch.float32, device=dev)
-    dk = torch.zeros((k.shape[0], C_), dtype=torch.float32, device=dev)
-    dv = torch.zeros((k.shape[0], C_), dtype=torch.float32, device=dev)
-    D = 64 * ((dh + 63) // 64)                       # head dim padded to whole 64-wide K slabs of me_gemm
-    nq_p = 64 * ((nq + 63) // 64)
-
-    def head(t, r0, rows, h, rows_p):               # [rows, dh] column slice -> contiguous, zero-padded [rows_p, D] fp16
-        o = torch.zeros((rows_p, D), dtype=F16, device=dev)
-        o[:rows, :dh] = t[r0:r0 + rows, h * dh:(h + 1) * dh]
-        return o
-
-    table = seg_item.tolist()
-    for it in range(n_items):
-        kits = [kit for kit in table[it] if kit >= 0]
-        nkt = len(kits) * nk
-        nkt_p = 64 * ((nkt + 63) // 64)
-        if nkt_p > 8192:
-            raise NotImplementedError("attention_bwd: more than 8192 keys per query item (me_softmax_rows row length)")
-        for h in range(heads):
-            qh = head(q, it * nq, nq, h, nq_p)
-            doh = head(dout, it * nq, nq, h, nq_p)
-            kc = torch.zeros((nkt_p, D), dtype=F16, device=dev)
-            vc = torch.zeros((nkt_p, D), dtype=F16, device=dev)
-            for s_, kit in enumerate(kits):
-                kc[s_ * nk:(s_ + 1) * nk, :dh] = k[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh]
-                vc[s_ * nk:(s_ + 1) * nk, :dh] = v[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh]
-            S = gemm(qh, kc.reshape(nkt_p, 1, D), alpha=scale)                       # [nq_p, nkt_p]
-            if nkt_p > nkt:
-                S[:, nkt:] = -60000.0                                                # pad keys: weight 0
-            P = softmax_rows(S)
-            dP = gemm(doh, vc.reshape(nkt_p, 1, D))
-            dS = torch.empty_like(P)
-            capi.check(capi.lib().me_softmax_bwd_rows(dS.data_ptr(), dS.stride(0), P.data_ptr(), P.stride(0), dP.data_ptr(), dP.stride(0), nq_p, nkt_p, scale, _stream()),
-                       "me_softmax_bwd_rows")
-            dqh = gemm(dS, kc.t().contiguous().reshape(D, 1, nkt_p))                 # dQ = dS K
-            dkc = gemm(dS.t().contiguous(), qh.t().contiguous().reshape(D, 1, nq_p))    # dK = dS^T q
-            dvc = gemm(P.t().contiguous(), doh.t().contiguous().reshape(D, 1, nq_p))    # dV = P^T dO
-            dq[it * nq:(it + 1) * nq, h * dh:(h + 1) * dh] = dqh[:nq, :dh]
-            for s_, kit in enumerate(kits):
-                dk[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh] += dkc[s_ * nk:(s_ + 1) * nk, :dh]
-                dv[kit * nk:(kit + 1) * nk, h * dh:(h + 1) * dh] += dvc[s_ * nk:(s_ + 1) * nk, :dh]
-    return dq, dk, dv
+    if q_items:
+        raise NotImplementedError("attention_bwd: shared query items are not differentiated")
+    if lse is None:
+        raise ValueError("attention_bwd: the forward must have stashed its log-sum-exp (attention(..., lse=...))")
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        _chk2d(t, "attention_bwd." + n)
+    for t, n in ((dout, "dout"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        _chk_grad(t, "attention_bwd." + n)
+    n_kv = k.shape[0] // nk
+    inv_ptr, inv_item = segments.inverse(seg_item, n_kv)
+    a = AttnBwdArgs()
+    a.Q, a.K, a.V, a.O, a.dO, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr()
+    a.dQ, a.dK, a.dV = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    delta = torch.empty((n_items * nq, heads), dtype=torch.float32, device=q.device)
+    a.delta = delta.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo, a.lddo = q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0)
+    a.lddq, a.lddk, a.lddv = dq.stride(0), dk.stride(0), dv.stride(0)
+    a.heads, a.dh, a.n_items, a.nq, a.nk, a.nseg, a.n_kv_items = heads, dh, n_items, nq, nk, seg_item.shape[1], n_kv
+    a.seg_item, a.inv_ptr, a.inv_item = seg_item.data_ptr(), inv_ptr.data_ptr(), inv_item.data_ptr()
+    a.scale = dh ** -0.5 if scale is None else scale
+    capi.check(capi.lib().me_attn_bwd(C.byref(a), _stream()), "me_attn_bwd")
 
 
 def temporal_attention_bwd(q, k, v, out, dout, *, heads, dh, batch, frames, npix, kv_map=None, scale=None, q_frames=0, q_frame0=0, kv_parts=1, q_parts=1):
@@ -559,61 +580,52 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
     return dx
 
 
-# -- parameter-gradient primitives of the adapter training step (train_adaptor.py:364-368).  Composed from kernels that exist:
-#    a weight gradient is a GEMM with the token axis as the reduction (dy^T against x^T as "weights"), a bias gradient the same GEMM
-#    against a row of ones, the LayerNorm scale gradient the diagonal of dy^T @ xhat.  torch only moves data (transposes, padding,
-#    the shifted copies of the TemporalConv taps).  The token axis is long (~10^5 rows) and the results leave me_gemm in fp16, so the
-#    GEMMs run with alpha = 2^-12 and the factor is restored in fp32.
-_DW_SHIFT = 4096.0
+# -- parameter-gradient primitives of the adapter training step (train_adaptor.py:364-368): fp32-accumulating, fp32-output kernels
+#    (csrc/train.hip); each ACCUMULATES into `dst`, an fp32 tensor in the packed parameter layout (a view of the trainer's flat bucket).
+_scratch = {}
 
 
-def _t_pad(t: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
-    """[r, c] (any float dtype) -> contiguous fp16 [cols_p8.., rows_p64] transpose, zero padded: rows_out = c (padded to 8), cols_out = rows (padded to 64)."""
-    c8, r64 = (cols + 7) // 8 * 8, (rows + 63) // 64 * 64
-    o = torch.zeros((c8, r64), dtype=F16, device=t.device)
-    o[:cols, :rows] = t[:rows, :cols].t()
-    return o
+def _work(nbytes: int, device, tag: str) -> torch.Tensor:
+    """Grow-only fp32 scratch per (device, stream, purpose)."""
+    key = (str(device), _stream(), tag)
+    t = _scratch.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = _scratch[key] = torch.empty((nbytes + 3) // 4 + 4, dtype=torch.float32, device=device)
+    return t
 
 
-def gemm_dw(dy, x, *, taps, K, M, alpha=1.0, conv=None, tconv=None):
-    """dW fp32 [N, taps, K] of me_gemm's y = alpha * gather(x) @ w^T for dense and TemporalConv layers (the adapter has no 3x3 convolution)."""
+def gemm_dw(dy, x, *, dst, taps, K, M, alpha=1.0, conv=None, tconv=None):
+    """dst (fp32 [N, taps, K]) += dW of me_gemm's y = alpha * gather(x) @ w^T for dense and TemporalConv layers (the adapter has no 3x3
+    convolution): the token axis is the MFMA contraction, per-split fp32 partial tiles are folded in a fixed order."""
     if conv is not None:
         raise NotImplementedError("gemm_dw: 3x3 convolution weights are not trained (the adapter has none)")
     if tconv is not None and len(tconv) > 3:
         raise NotImplementedError("gemm_dw: the frame-sharded TemporalConv is not differentiated")
     N = dy.shape[1]
-    dyT = _t_pad(dy, M, N)                                           # [N8, M64]
-    xm = x[:M, :K]
-    if tconv is None:
-        srcs = [xm]
-    else:
-        frames, npix, chunk = tconv
-        nb = M // (frames * npix)
-        x4 = xm.reshape(nb, frames, npix, K)
-        srcs = []
-        for tap in range(3):                                           # rows of tap = the frame tap - 1 away, inside the same chunk; zeros otherwise
-            sh = torch.zeros_like(x4)
-            for fr in range(frames):
-                s_ = fr + tap - 1
-                if 0 <= s_ < frames and s_ // chunk == fr // chunk:
-                    sh[:, fr] = x4[:, s_]
-            srcs.append(sh.reshape(M, K))
-    out = torch.empty((N, taps, K), dtype=torch.float32, device=dy.device)
-    for tap, src in enumerate(srcs):
-        xT = _t_pad(src, M, K)                                           # [K8, M64] = the "weights" [K][1][M64]
-        d = gemm(dyT, xT.reshape(xT.shape[0], 1, xT.shape[1]), alpha=alpha / _DW_SHIFT)
-        out[:, tap, :] = d[:N, :K].float() * _DW_SHIFT
-    return out
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or tuple(dst.shape) != (N, taps, K):
+        raise ValueError(f"gemm_dw: dst must be a contiguous fp32 [{N}, {taps}, {K}] tensor")
+    _chk2d(x, "gemm_dw.x")
+    a = GemmDwArgs()
+    a.dY, a.X, a.dW = dy.data_ptr(), x.data_ptr(), dst.data_ptr()
+    a.M, a.N, a.K, a.lddy, a.ldx, a.dy_is_f16 = M, N, K, dy.stride(0), x.stride(0), 1 if dy.dtype == F16 else 0
+    a.work = _work(capi.lib().me_gemm_dw_work_bytes(M, N, K), dy.device, "dw").data_ptr()
+    a.taps, a.alpha = taps, alpha
+    a.gather = capi.GATHER_DENSE
+    if tconv is not None:
+        a.gather = capi.GATHER_TCONV
+        a.frames, a.npix, a.chunk = tconv
+    for tap in range(taps):
+        a.tap = tap
+        capi.check(capi.lib().me_gemm_dw(C.byref(a), _stream()), "me_gemm_dw")
+    return dst
 
 
-def colsum_grad(dy):
-    """Column sums of a gradient (a bias gradient): ones^T @ dy through me_gemm."""
+def colsum_grad(dy, *, dst, alpha=1.0):
+    """dst (fp32 [N]) += alpha * column sums of a gradient (a bias gradient)."""
     M, N = dy.shape
-    dyT = _t_pad(dy, M, N)
-    ones = torch.ones((64, dyT.shape[1]), dtype=F16, device=dy.device)
-    ones[:, M:] = 0
-    d = gemm(ones, dyT.reshape(dyT.shape[0], 1, dyT.shape[1]), alpha=1.0 / _DW_SHIFT)
-    return d[0, :N].float() * _DW_SHIFT
+    capi.check(capi.lib().me_colsum(dst.data_ptr(), dy.data_ptr(), dy.stride(0), 1 if dy.dtype == F16 else 0, M, N, float(alpha),
+                                    _work(capi.lib().me_colsum_work_bytes(N), dy.device, "colsum").data_ptr(), _stream()), "me_colsum")
+    return dst
 
 
 def relu_bwd(dy, out):
@@ -625,12 +637,54 @@ def relu_bwd(dy, out):
     return dx
 
 
-def layernorm_bwd_params(x, dy, *, eps=1e-5):
-    """(d gamma, d beta) of nn.LayerNorm: d beta = column sums of dy; d gamma = diag(dy^T @ xhat) with xhat from me_layernorm(gamma 1, beta 0)."""
+def layernorm_bwd_params(x, dy, *, dgamma=None, dbeta=None, eps=1e-5):
+    """dgamma (fp32 [C]) += sum_m dy xhat, dbeta += sum_m dy (either may be None)."""
+    _chk2d(x, "layernorm_bwd_params.x")
+    _chk_grad(dy, "layernorm_bwd_params.dy")
     M, Cc = x.shape
-    one = torch.ones(Cc, dtype=F16, device=x.device)
-    xhat = layernorm(x, one, torch.zeros_like(one), eps)
-    dyT = _t_pad(dy, M, Cc)
-    xT = _t_pad(xhat, M, Cc)
-    d = gemm(dyT, xT.reshape(xT.shape[0], 1, xT.shape[1]), alpha=1.0 / _DW_SHIFT)
-    return torch.diagonal(d[:Cc, :Cc]).float() * _DW_SHIFT, colsum_grad(dy)
+    capi.check(capi.lib().me_layernorm_bwd_params(_p(dgamma), _p(dbeta), x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), M, Cc, eps, 1.0,
+                                                  _work(capi.lib().me_layernorm_bwd_params_work_bytes(M, Cc), x.device, "lnp").data_ptr(), _stream()), "me_layernorm_bwd_params")
+
+
+# -- loss, norms, optimiser (csrc/train.hip) --
+def sumsq_absmax(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 [2] device tensor {sum x^2, max |x|} of a contiguous fp32 tensor (no host sync)."""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("sumsq_absmax: contiguous fp32 input")
+    if out is None:
+        out = torch.empty(2, dtype=torch.float32, device=x.device)
+    capi.check(capi.lib().me_sumsq_absmax(out.data_ptr(), x.data_ptr(), x.numel(), _work(capi.lib().me_sumsq_work_bytes(), x.device, "sumsq").data_ptr(), _stream()),
+               "me_sumsq_absmax")
+    return out
+
+
+def adamw(p, m, v, g, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step: int, gnorm_sq: Optional[torch.Tensor] = None, max_grad_norm: float = 0.0,
+          grad_scale: float = 1.0) -> None:
+    """One AdamW step in place on contiguous fp32 p, m, v with gradient g (torch.optim.AdamW; weight_decay 0 = Adam); gnorm_sq (device scalar)
+    switches on clip_grad_norm_(max_grad_norm) over the bucket it was computed on."""
+    for t in (p, m, v, g):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
+            raise ValueError("adamw: contiguous fp32 tensors of equal size")
+    capi.check(capi.lib().me_adamw(p.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                   1.0 - beta1 ** step, 1.0 - beta2 ** step, _p(gnorm_sq), float(max_grad_norm), float(grad_scale), _stream()), "me_adamw")
+
+
+def cast_f16(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst fp16 = src fp32, contiguous and of equal size (packed weights from their fp32 masters)."""
+    if dst.dtype != F16 or src.dtype != torch.float32 or not dst.is_contiguous() or not src.is_contiguous() or dst.numel() != src.numel():
+        raise ValueError("cast_f16: contiguous fp16 <- fp32 of equal size")
+    capi.check(capi.lib().me_cast_f16(dst.data_ptr(), src.data_ptr(), src.numel(), _stream()), "me_cast_f16")
+    return dst
+
+
+def mse_seed(eps_u: torch.Tensor, target: torch.Tensor, *, eps_c: Optional[torch.Tensor] = None, x: Optional[torch.Tensor] = None, guidance: float = 1.0, ca: float = 0.0,
+             cb: float = 1.0, coef: float = 1.0):
+    """rec = ca x + cb (eps_u + guidance (eps_c - eps_u)), diff = rec - target (fp32 [nb, C, f, h, w]); returns (diff, d_eps rows fp32 [(nb f h w), C] = coef * diff)."""
+    nb, Cc, f, h, w = target.shape
+    if target.dtype != torch.float32 or not target.is_contiguous() or (x is not None and (x.dtype != torch.float32 or not x.is_contiguous())):
+        raise ValueError("mse_seed: contiguous fp32 latents")
+    diff = torch.empty_like(target)
+    d_eps = torch.empty((nb * f * h * w, Cc), dtype=torch.float32, device=target.device)
+    capi.check(capi.lib().me_mse_seed(diff.data_ptr(), d_eps.data_ptr(), d_eps.stride(0), eps_u.data_ptr(), eps_u.stride(0), _p(eps_c), 0 if eps_c is None else eps_c.stride(0),
+                                      _p(x), target.data_ptr(), nb, Cc, f, h * w, float(guidance), float(ca), float(cb), float(coef), _stream()), "me_mse_seed")
+    return diff, d_eps

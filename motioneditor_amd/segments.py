@@ -99,3 +99,35 @@ def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4, shard=
                 rows.append([gi(b - 1, max(g - 1, 0)), gi(b - 1, g), gi(b, g)])
                 modes.append([SEG_DUAL_BIN, SEG_DUAL_BIN, SEG_PLAIN] if binary_mask else [SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
     return _mk(("edited", f, binary_mask, B) + key, rows, modes, device)
+
+
+def has_dual(seg_mode: torch.Tensor) -> bool:
+    """True when the table holds any dual (masked / binary) segment.  Tables built here answer from the cache; a foreign table is inspected."""
+    gd, bd = GENERAL_DUAL.get(seg_mode.data_ptr()), BINARY_DUAL.get(seg_mode.data_ptr())
+    if gd is None or bd is None:
+        return bool((seg_mode != SEG_PLAIN).any().item())
+    return gd or bd
+
+
+_inverse: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+
+
+def inverse(seg_item: torch.Tensor, n_kv_items: int):
+    """CSR inverse of a segment table for the key-centric attention backward (me_attn_bwd): (inv_ptr int32 [n_kv_items + 1], inv_item int32)
+    with inv_item[inv_ptr[k] : inv_ptr[k + 1]] = the query items that list kv item k, once per listing, in ascending order."""
+    key = (seg_item.data_ptr(), tuple(seg_item.shape), n_kv_items, str(seg_item.device))
+    hit = _inverse.get(key)
+    if hit is None:
+        lists = [[] for _ in range(n_kv_items)]
+        for it, row in enumerate(seg_item.tolist()):
+            for kit in row:
+                if kit < 0:
+                    break
+                lists[kit].append(it)
+        ptr = [0]
+        for l_ in lists:
+            ptr.append(ptr[-1] + len(l_))
+        flat = [i for l_ in lists for i in l_] or [0]
+        hit = (torch.tensor(ptr, dtype=torch.int32, device=seg_item.device), torch.tensor(flat, dtype=torch.int32, device=seg_item.device), seg_item)   # seg_item kept alive: the key is its address
+        _inverse[key] = hit
+    return hit[0], hit[1]

@@ -338,3 +338,18 @@ def make_case_inputs(kind: str, B: int, f: int, h: int, w: int, seed: int = 33, 
         d["mid_res"] = T(mid)
         d["source_masks"] = T(synth_masks(f, 8 * h, 8 * w))
     return d
+
+
+def bench_inputs(f: int, h: int, w: int, seed: int = 33):
+    """Inputs of the benchmarked two-branch step (bench.py; SURVEY.md 8d "synthetic inputs"): latents [2,4,f,h,w] = [recon, edit],
+    50 unconditional embeddings, the two prompts' embeddings, the target skeleton video in [0, 1] and binary source masks.
+    CPU fp32 torch tensors; the same generator feeds bench.py, the config-3 golden (oracle/make_golden.py --only-config3) and its
+    GPU test, so all three see bit-identical data."""
+    import torch
+
+    T = torch.from_numpy
+    return dict(latents=T(synth_normal("bench.latents", (2, 4, f, h, w), seed)),
+                uncond=[T(synth_normal(f"bench.uncond{i}", (1, 77, 768), seed, 0.3)) for i in range(50)],
+                cond=T(synth_normal("bench.cond", (2, 77, 768), seed, 0.3)),
+                skeleton=T(np.clip(synth_normal("bench.skel", (1, f, 3, 8 * h, 8 * w), seed, 0.5) + 0.5, 0, 1).astype(np.float32)),
+                masks=T(synth_masks(f, 8 * h, 8 * w)))

@@ -48,11 +48,6 @@ class Packed:
         self.cache[key] = d
         return d
 
-    def vec(self, name: str) -> torch.Tensor:
-        """bias / norm parameter as fp16 [n]."""
-        k = "vec:" + name
-        return self.cache.get(k) if k in self.cache else self._put(k, self.raw(name).reshape(-1))
-
     @staticmethod
     def _as_taps(w: torch.Tensor) -> torch.Tensor:
         if w.dim() == 2:      # Linear
@@ -64,9 +59,45 @@ class Packed:
             return w.permute(0, 2, 1)
         raise ValueError(f"unsupported weight rank {w.dim()}")
 
+    @staticmethod
+    def _geglu_perm(n_out: int) -> torch.Tensor:
+        """packed row p = q*32 + r  <-  value row q*16 + r (r < 16) | gate row n_out + q*16 + (r-16)."""
+        q = torch.arange(n_out // 16)
+        val = (q[:, None] * 16 + torch.arange(16)[None]).reshape(-1, 16)
+        gate = val + n_out
+        return torch.cat([val, gate], dim=1).reshape(-1)
+
+    def packed_f32(self, key: str) -> torch.Tensor:
+        """The packed tensor of cache key `kind:name|name...` in fp32 on the host, built from the state dict (what _put then casts):
+        also the fp32 master copy of a trained parameter in the layout its kernels read."""
+        kind, _, names = key.partition(":")
+        ns = names.split("|")
+        if kind == "vec":
+            return self.raw(names).reshape(-1)
+        if kind == "mat":
+            return self._as_taps(self.raw(names)).contiguous()
+        if kind == "fused":
+            return torch.cat([self._as_taps(self.raw(n)) for n in ns], dim=0).contiguous()
+        if kind == "fvec":
+            return torch.cat([self.raw(n).reshape(-1) for n in ns])
+        if kind == "geglu":
+            w = self.raw(names)
+            return w[self._geglu_perm(w.shape[0] // 2)][:, None, :].contiguous()
+        if kind == "gegluv":
+            b = self.raw(names)
+            return b[self._geglu_perm(b.shape[0] // 2)].contiguous()
+        raise KeyError(key)
+
+    def _get(self, key: str) -> torch.Tensor:
+        hit = self.cache.get(key)
+        return hit if hit is not None else self._put(key, self.packed_f32(key))
+
+    def vec(self, name: str) -> torch.Tensor:
+        """bias / norm parameter as fp16 [n]."""
+        return self._get("vec:" + name)
+
     def mat(self, name: str) -> torch.Tensor:
-        k = "mat:" + name
-        return self.cache.get(k) if k in self.cache else self._put(k, self._as_taps(self.raw(name)))
+        return self._get("mat:" + name)
 
     def mat32(self, name: str) -> torch.Tensor:
         """fp32 [N, taps, K] (conv_small reads its tiny weights through the scalar cache)."""
@@ -83,40 +114,16 @@ class Packed:
 
     def fused(self, names: Iterable[str]) -> torch.Tensor:
         """Row-concatenation of several projections that share an input (q|k|v, k|v)."""
-        names = list(names)
-        k = "fused:" + "|".join(names)
-        if k in self.cache:
-            return self.cache[k]
-        return self._put(k, torch.cat([self._as_taps(self.raw(n)) for n in names], dim=0))
+        return self._get("fused:" + "|".join(names))
 
     def fused_vec(self, names: Iterable[str]) -> torch.Tensor:
-        names = list(names)
-        k = "fvec:" + "|".join(names)
-        if k in self.cache:
-            return self.cache[k]
-        return self._put(k, torch.cat([self.raw(n).reshape(-1) for n in names]))
-
-    @staticmethod
-    def _geglu_perm(n_out: int) -> torch.Tensor:
-        """packed row p = q*32 + r  <-  value row q*16 + r (r < 16) | gate row n_out + q*16 + (r-16)."""
-        q = torch.arange(n_out // 16)
-        val = (q[:, None] * 16 + torch.arange(16)[None]).reshape(-1, 16)
-        gate = val + n_out
-        return torch.cat([val, gate], dim=1).reshape(-1)
+        return self._get("fvec:" + "|".join(names))
 
     def geglu_mat(self, name: str) -> torch.Tensor:
-        k = "geglu:" + name
-        if k in self.cache:
-            return self.cache[k]
-        w = self.raw(name)
-        return self._put(k, w[self._geglu_perm(w.shape[0] // 2)][:, None, :])
+        return self._get("geglu:" + name)
 
     def geglu_vec(self, name: str) -> torch.Tensor:
-        k = "gegluv:" + name
-        if k in self.cache:
-            return self.cache[k]
-        b = self.raw(name)
-        return self._put(k, b[self._geglu_perm(b.shape[0] // 2)])
+        return self._get("gegluv:" + name)
 
     def is_zero(self, *names: str) -> bool:
         """True when every named tensor is exactly zero (the reference zero-initialises TemporalConv
@@ -138,13 +145,29 @@ class Packed:
 
     def update(self, name: str, value: torch.Tensor) -> None:
         """Replace a parameter (reference name, reference layout); every packed tensor built from it is dropped and re-packed on its
-        next use.  The state mapping must be mutable (a dict)."""
+        next use (and its cached transpose forgotten).  The state mapping must be mutable (a dict)."""
+        from . import ops
         self.state[self.prefix + name] = value.detach().cpu().clone()   # type: ignore[index]
-        for key in [k for k in self.cache if name in k.partition(":")[2].split("|")]:
+        stale = [k for k in self.cache if name in k.partition(":")[2].split("|")]
+        if self.device.type == "cuda":
+            ops.invalidate_transposed([self.cache[k] for k in stale if isinstance(self.cache[k], torch.Tensor) and self.cache[k].dim() == 3])
+        for key in stale:
             del self.cache[key]
 
+    def rehome(self, key: str, storage: torch.Tensor) -> torch.Tensor:
+        """Move packed tensor `key` into `storage` (a flat slice of a caller-owned bucket of the same dtype and size): the cache hands out the
+        bucket view from now on, so that one kernel can refresh every trained tensor from its fp32 master (util.AdapterTrainer)."""
+        t = self._get(key)
+        if storage.dtype != t.dtype or storage.numel() != t.numel() or not storage.is_contiguous():
+            raise ValueError("rehome: storage must be a contiguous slice of the packed tensor's dtype and size")
+        storage.copy_(t.reshape(-1))
+        v = storage.view(t.shape)
+        self.cache[key] = v
+        return v
+
     def unpack_grad(self, key: str, g: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """Gradient w.r.t. a packed tensor -> {reference parameter name: gradient in the reference's own layout}."""
+        """A tensor in the PACKED layout of `key` (a gradient, or an fp32 master copy) -> {reference parameter name: the same values in the
+        reference's own layout}: the inverse of packed_f32."""
         kind, _, names = key.partition(":")
         names_l = names.split("|")
         g = g.float().cpu()

@@ -29,6 +29,7 @@ import torch.nn.functional as F
 
 SD = Dict[str, torch.Tensor]
 HEADS = 8  # models/unet_2d_condition.py:206 passes attention_head_dim=8 as the head COUNT
+SDPA_SCORE_BYTES = 4 << 30  # largest score tensor one sdpa() call materialises (see sdpa)
 
 
 # --------------------------------------------------------------------------------------------
@@ -56,6 +57,11 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch
     This is both ``CrossAttention._attention`` (attention_2d.py:172-201, baddbmm/softmax/bmm) and the
     semantics of ``xformers.ops.memory_efficient_attention`` (attention_2d.py:246-253)."""
     scale = q.shape[-1] ** -0.5
+    # the score tensor of one call is bounded (SDPA_SCORE_BYTES): larger problems -- config 3's level-0 attention is 768 x 4096 x
+    # 8192 fp32 scores = 103 GB -- are walked in batch chunks; every batch entry sees exactly the same baddbmm / softmax / bmm
+    step = max(1, SDPA_SCORE_BYTES // max(1, q.shape[1] * k.shape[1] * 4))
+    if step < q.shape[0]:
+        return torch.cat([sdpa(q[i:i + step], k[i:i + step], v[i:i + step], bias) for i in range(0, q.shape[0], step)], dim=0)
     s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(1, 2), beta=0, alpha=scale)
     if bias is not None:
         s = s + bias

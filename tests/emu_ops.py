@@ -26,7 +26,7 @@ def empty(rows, cols, like):
 
 
 def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=None, res2=None, geglu=False, act=0, alpha=1.0,
-         conv=None, tconv=None):
+         conv=None, tconv=None, res_rows=0, res2_rows=0):
     N, taps, K = w.shape
     xf, wf = x.float()[:, :K], w.float()
     if conv is not None:
@@ -34,8 +34,12 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
         pad0 = conv[6] if len(conv) > 6 else 0
         n_img = x.shape[0] // (Hin * Win)
         img = xf.reshape(n_img, Hin, Win, K).permute(0, 3, 1, 2)
-        if ups:
+        if ups == 1:
             img = img.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        elif ups == 2:   # zero-stuffed 2x: virtual pixel (2y, 2x) = input pixel (y, x), the rest zeros
+            z = torch.zeros(n_img, K, 2 * Hin, 2 * Win, dtype=img.dtype)
+            z[:, :, ::2, ::2] = img
+            img = z
         wk = wf.reshape(N, 3, 3, K).permute(0, 3, 1, 2)
         y = F.conv2d(F.pad(img, (0, 1, 0, 1)), wk, None, stride=stride) if pad0 else F.conv2d(img, wk, None, stride=stride, padding=1)
         assert y.shape[2] == Hout and y.shape[3] == Wout
@@ -90,9 +94,9 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
         elif act == 2:
             y = F.silu(y)
         if res is not None:
-            y = y + res.float()[:M, :N]
+            y = y + res.float()[(torch.arange(M) % res_rows) if res_rows else slice(0, M), :N]
         if res2 is not None:
-            y = y + res2.float()[:M, :N]
+            y = y + res2.float()[(torch.arange(M) % res2_rows) if res2_rows else slice(0, M), :N]
     y = y.to(x.dtype)
     if out is not None:
         out[:M, :y.shape[1]] = y
@@ -114,7 +118,7 @@ def conv_small(inp, w, bias, *, n_img, Cin, H, Wd, img_stride, ch_stride, frames
     return y.permute(0, 2, 3, 1).reshape(-1, Cout).to(_EMU_DTYPE if w.dtype == torch.float32 else w.dtype)
 
 
-def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, out=None):
+def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, out=None, q_items=0, lse=None):
     scale = dh ** -0.5 if scale is None else scale
     C = heads * dh
     qf, kf, vf = q.float()[:, :C], k.float()[:, :C], v.float()[:, :C]
@@ -122,7 +126,8 @@ def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=N
     si, sm = seg_item.tolist(), seg_mode.tolist()
     mk = _f(mask)
     for it in range(n_items):
-        qi = qf[it * nq:(it + 1) * nq].reshape(nq, heads, dh).permute(1, 0, 2)   # [H, nq, dh]
+        iq = it % q_items if q_items else it
+        qi = qf[iq * nq:(iq + 1) * nq].reshape(nq, heads, dh).permute(1, 0, 2)   # [H, nq, dh]
         logits, vals = [], []
         for s, kit in enumerate(si[it]):
             if kit < 0:
@@ -142,7 +147,10 @@ def attention(q, k, v, *, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=N
                 m = mk[planes][:, None, :]                     # [H, 1, nk]
                 logits += [sc * m, sc * (1 - m)]
                 vals += [vs, vs]
-        p = torch.cat(logits, dim=-1).softmax(dim=-1)
+        lg = torch.cat(logits, dim=-1)
+        if lse is not None:   # log2-domain log-sum-exp [nq, heads], what the HIP forward stashes for its backward
+            lse[it * nq:(it + 1) * nq] = (torch.logsumexp(lg.detach(), dim=-1) * 1.4426950408889634).t()
+        p = lg.softmax(dim=-1)
         o = torch.einsum("hqk,hkd->hqd", p, torch.cat(vals, dim=1))
         res[it * nq:(it + 1) * nq] = o.permute(1, 0, 2).reshape(nq, C)
     res = res.to(q.dtype)
@@ -277,18 +285,36 @@ def nchw_to_rows(x, n_img, C, npix, img_stride, ch_stride):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # backward primitives (motioneditor_amd/autodiff.py): each is the vector-Jacobian product of its forward emulation above,
-# taken with torch autograd -- the CPU statement of what the backward kernels have to compute.
+# taken with torch autograd -- the CPU statement of what the backward kernels have to compute.  Same contract as ops.py:
+# entries with `dst` / `dq, dk, dv` ACCUMULATE into those fp32 views.
 # ---------------------------------------------------------------------------------------------------------------------
 def _leaf(t):
     return t.detach().float().clone().requires_grad_(True)
 
 
-def gemm_dx(dy, w, *, x_rows, M, alpha=1.0, conv=None, tconv=None):
-    """dX [x_rows, K] of y = alpha * gather(x) @ w^T (any gather mode): linear in x, so the point of linearisation is irrelevant."""
+def grad_acc(dst, src, alpha=1.0, pool=None):
+    s_ = src.float()
+    if pool is not None:
+        H, W = pool
+        s_ = s_.reshape(-1, H, 2, W, 2, s_.shape[-1]).sum(dim=(2, 4)).reshape(-1, s_.shape[-1])
+    if dst.dim() == 2:
+        dst.add_(alpha * s_[:dst.shape[0], :dst.shape[1]])
+    else:
+        dst.add_(alpha * s_.reshape(dst.shape))
+    return dst
+
+
+def invalidate_transposed(tensors=None):
+    pass
+
+
+def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None):
+    """dst += dX of y = alpha * gather(x) @ w^T (any gather mode): linear in x, so the point of linearisation is irrelevant."""
     K = w.shape[2]
-    x0 = torch.zeros((x_rows, K), dtype=torch.float32, requires_grad=True)
+    x0 = torch.zeros((dst.shape[0], K), dtype=torch.float32, requires_grad=True)
     y = gemm(x0, w.float(), M=M, alpha=alpha, conv=conv, tconv=tconv)
-    return torch.autograd.grad(y, x0, dy.float()[:y.shape[0], :y.shape[1]])[0]
+    dst.add_(torch.autograd.grad(y, x0, dy.float()[:y.shape[0], :y.shape[1]])[0])
+    return dst
 
 
 def geglu_bwd(pre, dy):
@@ -300,10 +326,13 @@ def geglu_bwd(pre, dy):
     return torch.autograd.grad(y, p0, dy.float())[0]
 
 
-def attention_bwd(q, k, v, out, dout, **kw):
+def attention_bwd(q, k, v, out, dout, *, dq, dk, dv, lse=None, **kw):
     q0, k0, v0 = _leaf(q), _leaf(k), _leaf(v)
     y = attention(q0, k0, v0, **kw)
-    return torch.autograd.grad(y, (q0, k0, v0), dout.float())
+    gq, gk, gv = torch.autograd.grad(y, (q0, k0, v0), dout.float())
+    dq.add_(gq[:, :dq.shape[1]])
+    dk.add_(gk[:, :dk.shape[1]])
+    dv.add_(gv[:, :dv.shape[1]])
 
 
 def temporal_attention_bwd(q, k, v, out, dout, **kw):
@@ -324,24 +353,68 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
     return torch.autograd.grad(y, x0, dy.float())[0]
 
 
-def gemm_dw(dy, x, *, taps, K, M, alpha=1.0, conv=None, tconv=None):
-    """dW [N, taps, K] of y = alpha * gather(x) @ w^T: linear in w."""
+def gemm_dw(dy, x, *, dst, taps, K, M, alpha=1.0, conv=None, tconv=None):
+    """dst += dW [N, taps, K] of y = alpha * gather(x) @ w^T: linear in w."""
     N = dy.shape[1]
     w0 = torch.zeros((N, taps, K), dtype=torch.float32, requires_grad=True)
     y = gemm(x.float(), w0, M=M, alpha=alpha, conv=conv, tconv=tconv)
-    return torch.autograd.grad(y, w0, dy.float()[:y.shape[0], :y.shape[1]])[0]
+    dst.add_(torch.autograd.grad(y, w0, dy.float()[:y.shape[0], :y.shape[1]])[0])
+    return dst
 
 
-def colsum_grad(dy):
-    return dy.float().sum(dim=0)
+def colsum_grad(dy, *, dst, alpha=1.0):
+    dst.add_(alpha * dy.float().sum(dim=0))
+    return dst
 
 
 def relu_bwd(dy, out):
     return dy.float() * (out.float() > 0).float()
 
 
-def layernorm_bwd_params(x, dy, *, eps=1e-5):
+def layernorm_bwd_params(x, dy, *, dgamma=None, dbeta=None, eps=1e-5):
     g0 = torch.ones(x.shape[1], requires_grad=True)
     b0 = torch.zeros(x.shape[1], requires_grad=True)
     y = layernorm(x.float(), g0, b0, eps)
-    return torch.autograd.grad(y, (g0, b0), dy.float())
+    dg, db = torch.autograd.grad(y, (g0, b0), dy.float())
+    if dgamma is not None:
+        dgamma.add_(dg)
+    if dbeta is not None:
+        dbeta.add_(db)
+
+
+def sumsq_absmax(x, out=None):
+    r = torch.stack([(x.double() ** 2).sum().float(), x.abs().max().float()])
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
+def adamw(p, m, v, g, *, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, step, gnorm_sq=None, max_grad_norm=0.0, grad_scale=1.0):
+    """torch.optim.AdamW's update written out (weight_decay 0 = Adam), with clip_grad_norm_ folded in as in me_adamw."""
+    gs = grad_scale
+    if gnorm_sq is not None:
+        total = float(gnorm_sq.reshape(-1)[0]) ** 0.5 * grad_scale
+        gs *= min(1.0, max_grad_norm / (total + 1e-6))
+    gi = g * gs
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(beta1).add_(gi, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1.0 - beta2)
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    p.addcdiv_(m, v.sqrt() / bc2 ** 0.5 + eps, value=-lr / bc1)
+
+
+def cast_f16(dst, src):
+    dst.copy_(src.to(dst.dtype))
+    return dst
+
+
+def mse_seed(eps_u, target, *, eps_c=None, x=None, guidance=1.0, ca=0.0, cb=1.0, coef=1.0):
+    nb, C, f, h, w = target.shape
+    to5 = lambda r: r.float()[:, :C].reshape(nb, f, h * w, C).permute(0, 3, 1, 2).reshape(nb, C, f, h, w)   # noqa: E731
+    e = to5(eps_u)
+    if eps_c is not None:
+        e = e + guidance * (to5(eps_c) - e)
+    rec = cb * e + (ca * x if x is not None else 0.0)
+    diff = rec - target
+    return diff, (coef * diff).permute(0, 2, 3, 4, 1).reshape(-1, C).contiguous()

@@ -1,5 +1,5 @@
 """Adapter training step (train_adaptor.py:364-385) on the emulated ABI, two data-parallel ranks on gloo:
-util.AdapterTrainer (tape gradients -> one all-reduced bucket -> clip_grad_norm -> AdamW -> weights written back) against the same
+util.AdapterTrainer (tape gradients accumulated into one flat bucket -> one all-reduce -> clip_grad_norm -> AdamW on packed fp32 masters -> packed weights refreshed in place) against the same
 step taken with torch autograd through the oracle on both clips in one process."""
 import os
 import sys
@@ -62,9 +62,11 @@ def _worker(rank, world, port, out_path):
             params[k].grad = g
         torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
         opt.step()
-        worst = max(float((unet.P.raw(k) - params[k].detach()).abs().max() / (params[k].detach() - sd[k]).abs().max().clamp_min(1e-12)) for k in names)
+        got = tr.export_state_dict()       # the trained parameters under the reference's names, in the reference's layouts
+        assert sorted(got) == names and all(got[k].shape == sd[k].shape for k in names)
+        worst = max(float((got[k] - params[k].detach()).abs().max() / (params[k].detach() - sd[k]).abs().max().clamp_min(1e-12)) for k in names)
         moved = max(float((params[k].detach() - sd[k]).abs().max()) for k in names)
-        num = sum(float((unet.P.raw(k) - params[k].detach()).pow(2).sum()) for k in names)
+        num = sum(float((got[k] - params[k].detach()).pow(2).sum()) for k in names)
         den = sum(float((params[k].detach() - sd[k]).pow(2).sum()) for k in names)
         torch.save({"worst": worst, "moved": moved, "update_rel_l2": (num / den) ** 0.5, "loss": loss, "want_loss": sum(losses) / world,
                     "repacked": float((unet.P.mat(names_w(names)) .float().reshape(-1)[:8] - params[names_w(names)].detach().reshape(-1)[:8]).abs().max())}, out_path)
@@ -115,7 +117,7 @@ def test_training_sequence_of_the_example_matches_the_oracle_loss(monkeypatch, u
     f, H = 8, 64
     b = ex.training_batch(f, H, H)
     t = 401
-    before = unet.P.raw("controlnet_adapter.body.0.block2.weight").clone()
+    before = tr.export_state_dict()["controlnet_adapter.body.0.block2.weight"].clone()
     loss = ex.step(tr, vae, cn, b, t)
     # oracle: the same sequence in torch
     T = torch.from_numpy
@@ -131,4 +133,4 @@ def test_training_sequence_of_the_example_matches_the_oracle_loss(monkeypatch, u
     with torch.no_grad():
         want = float(torch.nn.functional.mse_loss(ref_cpu.unet_forward(usd, noisy, t, b["ehs"], down, mid), b["noise"]))
     assert abs(loss - want) < 1e-3 * want, (loss, want)
-    assert float((unet.P.raw("controlnet_adapter.body.0.block2.weight") - before).abs().max()) > 1e-4
+    assert float((tr.export_state_dict()["controlnet_adapter.body.0.block2.weight"] - before).abs().max()) > 1e-4

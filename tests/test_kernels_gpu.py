@@ -485,10 +485,17 @@ def test_groupnorm_with_cross_rank_statistic_reduction_hook(ops):
 
 
 # ------------------------------------------------------------------ backward primitives (motioneditor_amd/autodiff.py)
+# Contract: entries that take `dst` / `dq, dk, dv` ACCUMULATE into those fp32 views -- every test starts them from a non-zero tensor.
+def _acc0(shape, seed=99, scale=0.5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
 @pytest.mark.parametrize("mode", ["dense", "dense_n4", "conv", "conv_s2", "conv_ups", "tconv", "geglu_w"])
 def test_gemm_dx_matches_the_vjp_of_the_forward_emulation(ops, mode):
     """Input gradient of me_gemm in every gather mode the UNet uses, computed by me_gemm itself on transposed / tap-reversed weights
-    (the stride-2 case over a zero-upsampled dy, the upsampled case with a 2 x 2 sum) vs torch autograd through the forward emulation."""
+    (the stride-2 case through the zero-stuffed gather mode ups = 2, the upsampled case with me_grad_acc's 2 x 2 pooling) vs torch autograd
+    through the forward emulation; accumulated into a strided view of a wider gradient buffer."""
     g = torch.Generator().manual_seed(5)
     conv = tconv = None
     if mode in ("dense", "geglu_w"):
@@ -505,10 +512,38 @@ def test_gemm_dx_matches_the_vjp_of_the_forward_emulation(ops, mode):
         M, N, K, taps, xr, tconv = 2 * 8 * 12, 128, 64, 3, 2 * 8 * 12, (8, 12, 8)
     w = (torch.randn(N, taps, K, generator=g) * (taps * K) ** -0.5).half()
     dy = torch.randn(M, N, generator=g)
-    want = emu.gemm_dx(dy.half().float(), w, x_rows=xr, M=M, conv=conv, tconv=tconv)
-    got = ops.gemm_dx(cu(dy), cu(w), x_rows=xr, M=M, conv=conv, tconv=tconv)
-    assert tuple(got.shape) == tuple(want.shape)
+    base = _acc0((xr, K + 8))
+    want = base.clone()
+    emu.gemm_dx(dy.half().float(), w, dst=want[:, 4:4 + K], M=M, conv=conv, tconv=tconv)
+    got = cu(base)
+    ops.gemm_dx(cu(dy), cu(w), dst=got[:, 4:4 + K], M=M, conv=conv, tconv=tconv)
     check(got, want, f"gemm_dx {mode}")
+    assert torch.equal(got[:, :4].cpu(), base[:, :4]) and torch.equal(got[:, 4 + K:].cpu(), base[:, 4 + K:])   # columns outside the view untouched
+
+
+@pytest.mark.parametrize("geom", [(16, 16, 1), (8, 12, 2), (20, 8, 3)])
+def test_gemm_conv_zero_stuffed_gather(ops, geom):
+    """Gather mode ups = 2 on its own: a 3x3 stride-1 convolution over the zero-stuffed 2x upsample of the input."""
+    H, W, n_img = geom
+    K, N = 64, 128
+    x, w = rnd(n_img * H * W, K, seed=1), rnd(N, 9, K, seed=2, scale=(9 * K) ** -0.5)
+    conv = (H, W, 2 * H, 2 * W, 1, 2)
+    check(ops.gemm(cu(x), cu(w), M=n_img * 4 * H * W, conv=conv), emu.gemm(x, w, M=n_img * 4 * H * W, conv=conv), f"conv zero-stuffed {geom}")
+
+
+@pytest.mark.parametrize("M,N,K", [(3 * 200, 320, 64), (2 * 256 * 260, 320, 64), (4 * 96, 128, 128)])
+def test_gemm_shared_residual_rows(ops, M, N, K):
+    """res_rows / res2_rows: residuals that hold one batch entry's rows and are read by every entry (row m reads row m % rows), on the
+    specialised and the generic epilogues, 256x320 and 128-wide tiles."""
+    nb = 3 if M == 600 else (2 if M > 1000 else 4)
+    rr = M // nb
+    x, w, bias = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    res, res2 = rnd(rr, N, seed=4), rnd(rr, N, seed=5)
+    full = rnd(M, N, seed=6)
+    for kw_gpu, kw_emu, name in ((dict(res=cu(res), res_rows=rr), dict(res=res, res_rows=rr), "res shared"),
+                                 (dict(res=cu(full), res2=cu(res2), res2_rows=rr), dict(res=full, res2=res2, res2_rows=rr), "res full + res2 shared"),
+                                 (dict(res=cu(res), res_rows=rr, act=1), dict(res=res, res_rows=rr, act=1), "generic epilogue")):
+        check(ops.gemm(cu(x), cu(w), bias=cu(bias), **kw_gpu), emu.gemm(x, w, bias=bias, **kw_emu), f"gemm {name} M={M}")
 
 
 def test_geglu_bwd(ops):
@@ -555,61 +590,206 @@ def test_temporal_attention_bwd(ops, F, dh, npix):
         check(a, b, f"tattn_bwd d{n} F={F} dh={dh}")
 
 
-@pytest.mark.parametrize("kind,dh,nq,nk", [("pc", 40, 128, 128), ("pc", 80, 96, 96), ("cross", 40, 64, 77), ("self", 160, 64, 64)])
-def test_attention_bwd_plain_segments(ops, kind, dh, nq, nk):
-    """(dq, dk, dv) of the fused attention for the tables the un-edited UNet uses -- [prev | cur] (a kv item is named by two query
-    items: its gradients add up), self, text -- vs the vjp of the forward emulation."""
+def _attn_case(kind, f, device="cpu"):
     from motioneditor_amd import segments
-    g = torch.Generator().manual_seed(10)
-    C, f = 8 * dh, 3
     if kind == "pc":
-        si, sm = segments.prev_cur(1, f, "cpu")
-        n_items, n_kv = f, f
-    elif kind == "self":
-        si, sm = segments.self_items(2, "cpu")
-        n_items, n_kv = 2, 2
-    else:
-        si, sm = segments.cross_text(1, f, "cpu")
-        n_items, n_kv = f, 1
+        si, sm = segments.prev_cur(1, f, device)
+        return si, sm, f, f
+    if kind == "self":
+        si, sm = segments.self_items(2, device)
+        return si, sm, 2, 2
+    if kind == "fp":      # adapter [first | prev] inside chunks of 8 frames: the first frame of a chunk is listed by up to nine query items
+        si, sm = segments.first_prev_chunked(1, f, 8, device)
+        return si, sm, f, f
+    si, sm = segments.cross_text(1, f, device)
+    return si, sm, f, 1
+
+
+@pytest.mark.parametrize("kind,dh,nq,nk,f", [("pc", 40, 128, 128, 3), ("pc", 80, 96, 96, 3), ("cross", 40, 64, 77, 3), ("self", 160, 64, 64, 2), ("fp", 40, 100, 100, 10),
+                                             ("pc", 40, 1024, 1024, 3), ("pc", 80, 1024, 1024, 2), ("self", 160, 256, 256, 2), ("cross", 80, 1000, 77, 4),
+                                             ("pc", 160, 40, 40, 3)])
+def test_attention_bwd_plain_segments(ops, kind, dh, nq, nk, f):
+    """me_attn_bwd (flash-style, two kernels) for the tables the un-edited UNet and the adapter use -- [prev | cur] (a kv item is named by
+    two query items: its gradients add up), self, text (one kv item named by every frame), [first | prev] -- vs the vjp of the forward
+    emulation.  P is rebuilt from the log-sum-exp the HIP forward stashes; q | k | v and their gradients are column slices of fused
+    [rows, 3C] tensors (strided views), every output accumulates onto what the buffer held; nq / nk with tails (77, 100, 40 keys)."""
+    g = torch.Generator().manual_seed(10)
+    C = 8 * dh
+    si, sm, n_items, n_kv = _attn_case(kind, f)
+    fused = kind in ("pc", "self", "fp") and nq == nk
     q = (torch.randn(n_items * nq, C, generator=g) * 0.7).half()
     k = (torch.randn(n_kv * nk, C, generator=g) * 0.7).half()
     v = torch.randn(n_kv * nk, C, generator=g).half()
     dout = torch.randn(n_items * nq, C, generator=g)
     args = dict(heads=8, dh=dh, n_items=n_items, nq=nq, nk=nk)
-    want = emu.attention_bwd(q, k, v, None, dout, seg_item=si, seg_mode=sm, **args)
-    got = ops.attention_bwd(cu(q), cu(k), cu(v), None, cu(dout), seg_item=cu(si), seg_mode=cu(sm), **args)
-    for a, b, n in zip(got, want, "qkv"):
-        check(a, b, f"attention_bwd d{n} {kind} dh={dh}", rel=4e-3, mx=6e-2)
+    if fused:      # one [rows, 3C] allocation as the q|k|v GEMM writes it, gradients likewise
+        qkv = cu(torch.cat([q, k, v], dim=1))
+        qc, kc, vc = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        g0 = _acc0((n_items * nq, 3 * C))
+        gg = cu(g0)
+        dq, dk, dv = gg[:, :C], gg[:, C:2 * C], gg[:, 2 * C:]
+        w0 = (g0[:, :C].clone(), g0[:, C:2 * C].clone(), g0[:, 2 * C:].clone())
+    else:
+        qc, kc, vc = cu(q), cu(k), cu(v)
+        w0 = (_acc0((n_items * nq, C), 1), _acc0((n_kv * nk, C), 2), _acc0((n_kv * nk, C), 3))
+        dq, dk, dv = cu(w0[0]), cu(w0[1]), cu(w0[2])
+    sic, smc = _attn_case(kind, f, "cuda")[:2]
+    lse = torch.empty((n_items * nq, 8), dtype=torch.float32, device="cuda")
+    out = ops.attention(qc, kc, vc, seg_item=sic, seg_mode=smc, lse=lse, **args)
+    lse_want = torch.empty((n_items * nq, 8))
+    emu.attention(q, k, v, seg_item=si, seg_mode=sm, lse=lse_want, **args)
+    assert float((lse.cpu() - lse_want).abs().max()) < 2e-2, "log-sum-exp stashed by the forward"
+    want = [w.clone() for w in w0]
+    emu.attention_bwd(q, k, v, None, dout, dq=want[0], dk=want[1], dv=want[2], seg_item=si, seg_mode=sm, **args)
+    ops.attention_bwd(qc, kc, vc, out, cu(dout), dq=dq, dk=dk, dv=dv, lse=lse, seg_item=sic, seg_mode=smc, **args)
+    for a, b, z, n in zip((dq, dk, dv), want, w0, "qkv"):
+        check(a - cu(z), b - z, f"attention_bwd d{n} {kind} dh={dh} nq={nq} nk={nk}", rel=4e-3, mx=6e-2)
 
 
-@pytest.mark.parametrize("mode", ["dense", "tconv", "geglu_n"])
+def test_attention_shared_query_items(ops):
+    """q_items: the adapter's pose queries computed once and read by every batch entry (item i reads query item i % q_items)."""
+    from motioneditor_amd import segments
+    g = torch.Generator().manual_seed(11)
+    dh, nq, f, nb = 40, 256, 3, 2
+    C = 8 * dh
+    q = (torch.randn(f * nq, C, generator=g) * 0.7).half()
+    kv = (torch.randn(nb * f * nq, 2 * C, generator=g) * 0.7).half()
+    si, sm = segments.self_items(nb * f, "cpu")
+    sic, smc = segments.self_items(nb * f, "cuda")
+    args = dict(heads=8, dh=dh, n_items=nb * f, nq=nq, nk=nq, q_items=f)
+    got = ops.attention(cu(q), cu(kv)[:, :C], cu(kv)[:, C:], seg_item=sic, seg_mode=smc, **args)
+    check(got, emu.attention(q, kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, **args), "attention q_items")
+    check(got, emu.attention(torch.cat([q] * nb), kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, heads=8, dh=dh, n_items=nb * f, nq=nq, nk=nq), "attention q_items == replicated q")
+
+
+@pytest.mark.parametrize("mode", ["dense", "tconv", "geglu_n", "dense_f16", "big"])
 def test_gemm_dw_and_bias_gradients(ops, mode):
-    """Weight / bias gradients of the adapter's Linear and TemporalConv layers (GEMMs over the token axis through me_gemm itself)
-    vs the vjp of the forward emulation."""
+    """me_gemm_dw / me_colsum: fp32-accumulating, fp32-output weight and bias gradients of the adapter's Linear and TemporalConv layers (the
+    token axis is the MFMA contraction; fixed-order split partials) vs the vjp of the forward emulation; accumulated onto existing content."""
     g = torch.Generator().manual_seed(12)
     tconv = None
-    if mode == "dense":
+    if mode in ("dense", "dense_f16"):
         M, N, K, taps = 300, 320, 192, 1
     elif mode == "geglu_n":
         M, N, K, taps = 200, 2560, 320, 1
+    elif mode == "big":
+        M, N, K, taps = 24 * 1024, 640, 640, 1
     else:
         M, N, K, taps, tconv = 2 * 16 * 12, 128, 64, 3, (16, 12, 8)
     x = (torch.randn(M, K, generator=g)).half()
     dy = torch.randn(M, N, generator=g)
-    want = emu.gemm_dw(dy.half().float(), x, taps=taps, K=K, M=M, tconv=tconv)
-    got = ops.gemm_dw(cu(dy), cu(x), taps=taps, K=K, M=M, tconv=tconv)
-    check(got, want, f"gemm_dw {mode}", rel=4e-3, mx=6e-2)
-    check(ops.colsum_grad(cu(dy)), emu.colsum_grad(dy.half().float()), f"colsum_grad {mode}", rel=4e-3, mx=6e-2)
+    dyq = dy.half().float()
+    base = _acc0((N, taps, K))
+    want = emu.gemm_dw(dyq, x, dst=base.clone(), taps=taps, K=K, M=M, tconv=tconv)
+    got = ops.gemm_dw(cu(dy.half()) if mode == "dense_f16" else cu(dy), cu(x), dst=cu(base), taps=taps, K=K, M=M, tconv=tconv)
+    check(got - cu(base), want - base, f"gemm_dw {mode}", rel=4e-3, mx=6e-2)
+    b0 = _acc0((N,))
+    check(ops.colsum_grad(cu(dy), dst=cu(b0)) - cu(b0), emu.colsum_grad(dy, dst=b0.clone()) - b0, f"colsum_grad {mode}", rel=1e-4, mx=1e-3)
 
 
 def test_relu_bwd_and_layernorm_param_gradients(ops):
     g = torch.Generator().manual_seed(13)
-    rows, C = 257, 320
+    rows, C = 1000, 320
     out = torch.randn(rows, C, generator=g).half()
     dy = torch.randn(rows, C, generator=g)
     assert torch.equal(ops.relu_bwd(cu(dy), cu(out)).cpu(), emu.relu_bwd(dy, out))
-    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
-    dg, db = ops.layernorm_bwd_params(cu(x), cu(dy), eps=1e-5)
-    wg, wb = emu.layernorm_bwd_params(x, dy.half().float(), eps=1e-5)
-    check(dg, wg, "layernorm d gamma", rel=4e-3, mx=6e-2)
-    check(db, wb, "layernorm d beta", rel=4e-3, mx=6e-2)
+    for C in (320, 1280):
+        x = (torch.randn(rows, C, generator=g) * 2 + 0.3).half()
+        dy = torch.randn(rows, C, generator=g)
+        g0, b0 = _acc0((C,), 1), _acc0((C,), 2)
+        dg, db = cu(g0), cu(b0)
+        ops.layernorm_bwd_params(cu(x), cu(dy), dgamma=dg, dbeta=db, eps=1e-5)
+        wg, wb = g0.clone(), b0.clone()
+        emu.layernorm_bwd_params(x, dy, dgamma=wg, dbeta=wb, eps=1e-5)
+        check(dg - cu(g0), wg - g0, f"layernorm d gamma C={C}", rel=1e-3, mx=2e-2)
+        check(db - cu(b0), wb - b0, f"layernorm d beta C={C}", rel=1e-4, mx=1e-3)
+
+
+def test_grad_acc_plain_strided_fp16_and_pooled(ops):
+    g = torch.Generator().manual_seed(14)
+    rows, cols = 300, 64
+    dst0 = _acc0((rows, cols + 16))
+    src = torch.randn(rows + 5, cols + 8, generator=g)
+    for s_, name in ((src, "fp32"), (src.half(), "fp16")):
+        got = cu(dst0)
+        ops.grad_acc(got[:, 8:8 + cols], cu(s_)[:, :cols], 0.5)
+        want = dst0.clone()
+        emu.grad_acc(want[:, 8:8 + cols], s_[:, :cols], 0.5)
+        check(got, want, f"grad_acc {name}", rel=1e-6 if name == "fp32" else 1e-3, mx=1e-2)
+    n_img, H, W = 3, 6, 10
+    big = torch.randn(n_img * 4 * H * W, cols, generator=g).half()
+    d0 = _acc0((n_img * H * W, cols))
+    got = cu(d0)
+    ops.grad_acc(got, cu(big), 1.0, pool=(H, W))
+    check(got, emu.grad_acc(d0.clone(), big, 1.0, pool=(H, W)), "grad_acc 2x2 pooling", rel=1e-3, mx=1e-2)
+    flat = _acc0((77 * 768,))
+    got = cu(flat)
+    ops.grad_acc(got, cu(src.reshape(-1)[:77 * 768].contiguous()), 2.0)
+    check(got, flat + 2.0 * src.reshape(-1)[:77 * 768], "grad_acc 1-D", rel=1e-6, mx=1e-5)
+
+
+def test_sumsq_absmax_is_deterministic_and_exact_enough(ops):
+    g = torch.Generator().manual_seed(15)
+    for n in (5, 1000, 3_000_001):
+        x = torch.randn(n, generator=g) * 3
+        x[n // 2] = -40.0
+        a, b = ops.sumsq_absmax(cu(x)).cpu(), ops.sumsq_absmax(cu(x)).cpu()
+        assert torch.equal(a, b)
+        assert abs(float(a[0]) / float((x.double() ** 2).sum()) - 1) < 1e-5 and float(a[1]) == 40.0
+
+
+@pytest.mark.parametrize("wd,clip", [(1e-2, True), (0.0, False)])
+def test_adamw_kernel_matches_torch_optim(ops, wd, clip):
+    """me_adamw over three steps vs torch.optim.AdamW (weight decay, bias correction) with torch.nn.utils.clip_grad_norm_ in front: the clip
+    factor comes from the device-side sum of squares, the loss scale is divided out by grad_scale."""
+    g = torch.Generator().manual_seed(16)
+    n, ls = 10_000, 256.0
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    p, m, v = cu(p0.clone()), cu(torch.zeros(n)), cu(torch.zeros(n))
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (0.05 if step == 2 else 3.0)     # step 2 stays below the clipping norm
+        ref.grad = gr.clone()
+        if clip:
+            torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gs = cu(gr * ls)
+        ops.adamw(p, m, v, gs, lr=1e-3, weight_decay=wd, step=step, gnorm_sq=ops.sumsq_absmax(gs) if clip else None, max_grad_norm=1.0, grad_scale=1.0 / ls)
+    check(p, ref.detach(), f"adamw wd={wd} clip={clip}", rel=1e-5, mx=1e-4)
+
+
+def test_cast_kernels_and_mse_seed(ops):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1003, generator=g) * 10
+    out = torch.empty(1003, dtype=torch.float16, device="cuda")
+    assert torch.equal(ops.cast_f16(out, cu(x)).cpu(), x.half())
+    wide = torch.randn(50, 40, generator=g)
+    got = ops._f16(cu(wide)[:, 4:24], 24)                      # a strided fp32 view, 20 columns padded to 24
+    assert torch.equal(got[:, :20].cpu(), wide[:, 4:24].half()) and float(got[:, 20:].abs().max()) == 0.0
+    nb, C, f, h, w = 1, 4, 3, 4, 5
+    eu, ec = (torch.randn(nb * f * h * w, 8, generator=g)).half(), (torch.randn(nb * f * h * w, 8, generator=g)).half()
+    xl, tg = torch.randn(nb, C, f, h, w, generator=g), torch.randn(nb, C, f, h, w, generator=g)
+    for kw in (dict(guidance=7.5, ca=1.01, cb=-0.2, coef=0.3), dict(coef=2.0 / tg.numel())):
+        full = "guidance" in kw
+        d1, r1 = ops.mse_seed(cu(eu), cu(tg), eps_c=cu(ec) if full else None, x=cu(xl) if full else None, **kw)
+        d0, r0 = emu.mse_seed(eu, tg, eps_c=ec if full else None, x=xl if full else None, **kw)
+        check(d1, d0, "mse_seed diff", rel=1e-6, mx=1e-5)
+        check(r1, r0, "mse_seed seed rows", rel=1e-6, mx=1e-5)
+
+
+@pytest.mark.parametrize("Cin,Cout,n_img,H,W,frames", [(4, 320, 4, 16, 16, 2), (3, 128, 2, 24, 40, 0), (4, 320, 3, 7, 9, 0)])
+def test_conv_small_wide_outputs_tile_kernel(ops, Cin, Cout, n_img, H, W, frames):
+    """conv_in (4 -> 320, 5-D latents) and the VAE encoder's 3 -> 128 through the 64-pixel tile kernel (row-contiguous stores), incl. a
+    pixel count that is not a multiple of 64."""
+    g = torch.Generator().manual_seed(18)
+    wt = torch.randn(Cout, 9, Cin, generator=g) * 0.2
+    bias = torch.randn(Cout, generator=g) * 0.1
+    if frames:
+        B = n_img // frames
+        x = torch.randn(B, Cin, frames, H, W, generator=g)
+        kw = dict(n_img=n_img, Cin=Cin, H=H, Wd=W, img_stride=Cin * frames * H * W, ch_stride=frames * H * W, frames=frames, frame_stride=H * W)
+    else:
+        x = torch.randn(n_img, Cin, H, W, generator=g)
+        kw = dict(n_img=n_img, Cin=Cin, H=H, Wd=W, img_stride=Cin * H * W, ch_stride=H * W)
+    check(ops.conv_small(cu(x), cu(wt), cu(bias), **kw), emu.conv_small(x, wt, bias, **kw), f"conv_small tile {Cin}->{Cout}")
