@@ -68,8 +68,9 @@ def parse_args():
                     help="secondary measurement: inner iterations of the null-text optimisation (UNet forward on a tape + backward + Adam, batch 1)")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
     ap.add_argument("--graph", action="store_true",
-                    help="A/B: replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from "
-                         "Python; measured neutral at config 3 and at the 8-frame 256^2 shape (the GPU, not the host, paces both), so it is off by default")
+                    help="replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from Python -- "
+                         "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
+                         "measured neutral (the GPU, not the host, paces the step); across GPUs it could only be validated on a world-1 RCCL group")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     ap.add_argument("--emulate", action="store_true", help="test plumbing: torch-CPU emulation of the C ABI (tests/emu_ops.py), gloo backend")
@@ -156,6 +157,8 @@ def resolve_mode(args, world):
     """-> (mode, n_cfg, n_shards, n_clips)"""
     m = args.parallel
     if world == 1:
+        if m == "frames":     # the frame-sharded code path on ONE rank (a world-1 RCCL group): launch-overhead / graph-capture measurements
+            return "frames", 1, 1, 1
         return "single", 1, 1, 1
     if m == "auto":
         m = "cfg" if world == 2 else ("cfg-frames" if world % 2 == 0 else "frames")
@@ -183,7 +186,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or (args.parallel == "frames" and not args.emulate)
     if args.emulate:
         device = "cpu"
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
@@ -194,6 +197,7 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
         if args.emulate:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -247,7 +251,8 @@ def main():
                           "value": round(args.steps / dt, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "dtype": "f16 (fp32 gradient buffers, loss-scaled fp16 between layers)",
                           "data": "synthetic", "config": {"workload": f"{f} frames x {8*h}x{8*h}, single-branch UNet3D, sparse-causal attn1 (normal_infer=False as the reference hard-codes)",
-                                                          "attention_backward": "matrix-materialising first form (me_gemm + me_softmax_rows + me_softmax_bwd_rows)"}}))
+                                                          "attention_backward": "fused flash-style me_attn_bwd (P rebuilt from the stashed log-sum-exp; key-centric dK / dV + query-centric dQ kernels)",
+                                                          "loss_and_optimiser": "device kernels (me_mse_seed, me_sumsq_absmax, me_adamw); two floats read by the host per iteration"}}))
         return
 
     if args.vae_decode:
@@ -307,7 +312,7 @@ def main():
                     if rank in ranks:
                         shard_group = g
     shard = None
-    if n_shards > 1:
+    if n_shards > 1 or mode == "frames":
         from motioneditor_amd import parallel
         lean = args.shard_exchange == "lean"
         shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather")   # f / n_shards frames per rank
@@ -330,7 +335,7 @@ def main():
         pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
         lat = lat[:1].contiguous()
 
-    use_graph = args.graph and not (args.emulate or args.inversion or dist_on)
+    use_graph = args.graph and not (args.emulate or args.inversion)
 
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
@@ -338,11 +343,16 @@ def main():
         if args.editors == "inactive":
             sed.cur_step = ted.cur_step = 0      # the editors count steps themselves: hold them before start_step
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
+        graphed = use_graph and ops.PROFILE is None
         if shard is not None:
+            if graphed:
+                return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5, shard=shard, cfg_group=cfg_group)
             return pipe.denoise_step_frame_sharded(lat, ts[i], emb, images, 7.5, shard, cfg_group=cfg_group)
         if n_cfg == 2:
+            if graphed:
+                return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5, cfg_parallel_group=cfg_group)
             return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=cfg_group)
-        if use_graph and ops.PROFILE is None:
+        if graphed:
             return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
@@ -410,12 +420,14 @@ def main():
         out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
                           f"denoise-steps/sec, {f}f x {8 * h}^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
-               "higher_is_better": True, "scaling": "weak" if (n_clips > 1 or world == 1) else "strong", "vs_baseline": None,
+               "higher_is_better": True, "scaling": "weak" if n_clips > 1 else "strong", "vs_baseline": None,
                "dtype": "f32 (CPU emulation of the C ABI: plumbing test, not a measurement)" if args.emulate else "f16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
                           "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
                           "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
+                          "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
+                                                  "text K|V of all transformer blocks projected by one GEMM per model",
                           "hip_graph_replay": bool(use_graph), "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; the ControlNet restatement (diffusers, not in the reference tree) is unpinned"},
                "step_tflop_reference_semantics": round(tf_ref, 2), "step_tflop_is_baseline_md_figure": tf_exact,
@@ -450,13 +462,21 @@ def main():
             out["mfma_frac_executed"] = round(exec_tf * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4)
             dom = max(kern, key=lambda k: kern[k][0])
             tsec, fl, by, n, xfl = kern[dom]
-            traffic = None   # HBM bytes per launch from the separate rocprofv3 --pmc passes (tools/pmc_summary.py), same workload only
+            # HBM bytes per launch of the dominant kernel: NOT measured in this run -- PMC counters need their own rocprofv3 --pmc passes
+            # (tools/collect_profiles.sh -> tools/pmc_summary.py -> profiles/pmc_traffic.json, same workload).  The file names the kernels it was
+            # collected for; if the dominant kernel of THIS run is not among them (the kernel set changed since), no figure is reported.
+            traffic, traffic_src = None, None
             pmc = ROOT / "profiles" / "pmc_traffic.json"
             if pmc.exists() and (f, h, w) == (24, 64, 64) and world == 1:
                 pt = json.loads(pmc.read_text())
-                traffic = (pt.get(dom) or pt.get(dom.split("<")[0]) or {}).get("hbm_bytes_per_launch")
+                ent = pt.get(dom)
+                if ent is not None and all(k in pt for k in list(sorted(kern, key=lambda k: -kern[k][0]))[:3] if not k.startswith(("groupnorm", "layernorm"))):
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not this run"
+                else:
+                    traffic_src = "profiles/pmc_traffic.json does not cover this run's dominant kernels (kernel set changed since it was collected): not reported"
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None if traffic is None else round(traffic),
+                               "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                                "achieved_executed": round(xfl / tsec / 1e12, 1), "frac_executed": round(xfl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                "flops_counted": "achieved = reference-semantics FLOPs of the launches (SURVEY 8d: a binary dual segment counts its 2 nk materialised keys); "
                                                 "achieved_executed = FLOPs the kernel multiplies (without MFMA tile padding)",

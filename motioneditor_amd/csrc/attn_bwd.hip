@@ -27,7 +27,9 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-// delta[row][h] = sum_d dO[row][h dh + d] * O[row][h dh + d]
+// delta[row][h] = sum_d dO[row][h dh + d] * O[row][h dh + d], with dO rounded to fp16 first -- the value the MFMAs multiply: dP - delta is
+// then a difference of sums over the SAME rounded factors, so a query whose softmax is a single 1 (one key: the 1x1-pixel level) gets
+// dS = 0 up to fp32 summation order instead of up to the fp16 rounding of dO (its q / k gradients are exactly zero under autograd)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const f16* __restrict__ O, int ldo, const float* __restrict__ dO, int lddo, float* __restrict__ delta,
                                                          long rows, int heads, int dh) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;   // (row, head)
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const f16* __restrict__
     U128 u;
     u.u = ldg128(o + c);
     const float4 a = *reinterpret_cast<const float4*>(d + c), b = *reinterpret_cast<const float4*>(d + c + 4);
-    acc += (float)u.e[0] * a.x + (float)u.e[1] * a.y + (float)u.e[2] * a.z + (float)u.e[3] * a.w;
-    acc += (float)u.e[4] * b.x + (float)u.e[5] * b.y + (float)u.e[6] * b.z + (float)u.e[7] * b.w;
+    acc += (float)u.e[0] * (float)(f16)a.x + (float)u.e[1] * (float)(f16)a.y + (float)u.e[2] * (float)(f16)a.z + (float)u.e[3] * (float)(f16)a.w;
+    acc += (float)u.e[4] * (float)(f16)b.x + (float)u.e[5] * (float)(f16)b.y + (float)u.e[6] * (float)(f16)b.z + (float)u.e[7] * (float)(f16)b.w;
   }
   delta[idx] = acc;
 }

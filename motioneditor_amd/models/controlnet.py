@@ -9,9 +9,10 @@ import torch
 from .. import ops, synth
 from ..weights import Packed
 from . import graph
+from .compat import ModuleShims
 
 
-class ControlNetModel:
+class ControlNetModel(ModuleShims):
     def __init__(self, state_dict: Mapping[str, object], device="cuda", dtype=torch.float16):
         self.P = Packed(state_dict, device, dtype=dtype)
         self.device = torch.device(device)
@@ -21,7 +22,7 @@ class ControlNetModel:
             raise KeyError(f"state dict lacks {len(missing)} ControlNet keys, e.g. {missing[:3]}")
 
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", **kwargs):
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", torch_dtype=None, **kwargs):
         from .. import checkpoint
         return cls(checkpoint.load_controlnet_state_dict(pretrained_model_name_or_path, subfolder), device)
 

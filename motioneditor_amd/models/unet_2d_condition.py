@@ -11,6 +11,7 @@ import torch
 from .. import ops, synth
 from ..weights import Packed
 from . import graph
+from .compat import ModuleShims, _SubModule
 
 
 @dataclass
@@ -25,7 +26,7 @@ class _Cfg(dict):
     __getattr__ = dict.__getitem__
 
 
-class UNet2DConditionModel:
+class UNet2DConditionModel(ModuleShims):
     num_spatial_attention_layers = 32   # 16 transformer blocks x {attn1, attn2} (fully_control_utils.py:220-229)
     num_temporal_attention_layers = 16  # (temporal_control_utils.py:134-144)
 
@@ -38,6 +39,7 @@ class UNet2DConditionModel:
                            block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, use_sc_attn=True, use_st_attn=False)
         self.spatial_editor = None
         self.temporal_editor = None
+        self.controlnet_adapter = _SubModule(self, "controlnet_adapter.")   # inference.py:240: unet.controlnet_adapter.load_state_dict(...)
         missing = [k for k in synth.unet_schema() if k not in state_dict]
         if missing:
             raise KeyError(f"state dict lacks {len(missing)} UNet keys, e.g. {missing[:3]}")

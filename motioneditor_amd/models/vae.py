@@ -23,6 +23,7 @@ import torch
 
 from .. import ops
 from ..weights import Packed
+from .compat import ModuleShims
 from .graph import Act, conv3x3
 
 UP_CH = (512, 512, 256, 128)
@@ -156,7 +157,7 @@ class AutoencoderKLOutput:
     latent_dist: DiagonalGaussianDistribution
 
 
-class AutoencoderKL:
+class AutoencoderKL(ModuleShims):
     """SD-1.5 VAE: `encode(x).latent_dist.sample()` and `decode(z).sample` like diffusers' class.  A state dict may hold either
     half (or both): the missing half raises on use."""
 
@@ -166,6 +167,18 @@ class AutoencoderKL:
         self.P = Packed(state_dict, device, dtype=dtype)
         self.device = torch.device(device)
         self.dtype = dtype
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", **kwargs) -> "AutoencoderKL":
+        """diffusers signature for a local directory (inference.py:154: AutoencoderKL.from_pretrained(path, subfolder="vae"))."""
+        from .. import checkpoint
+        return cls(checkpoint.load_file(checkpoint.find_weights(pretrained_model_name_or_path, subfolder)), device)
+
+    def enable_slicing(self):        # diffusers: decode one image at a time to bound memory; every decode here is per image already
+        return self
+
+    def disable_slicing(self):
+        return self
 
     @classmethod
     def from_synthetic(cls, device: str = "cuda", seed: int = 33) -> "AutoencoderKL":

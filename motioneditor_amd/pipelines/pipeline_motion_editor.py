@@ -61,6 +61,23 @@ class MotionEditorPipeline:
     def _execution_device(self):
         return self.device
 
+    def enable_vae_slicing(self):        # reference pipeline :93-94 (inference.py:197); the VAE here decodes per image already
+        if self.vae is not None and hasattr(self.vae, "enable_slicing"):
+            self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):       # reference pipeline :96-97
+        if self.vae is not None and hasattr(self.vae, "disable_slicing"):
+            self.vae.disable_slicing()
+
+    def to(self, device=None, *a, **k):
+        """diffusers DiffusionPipeline.to: move every component that can move."""
+        for m in (self.unet, self.controlnet, self.vae, self.text_encoder):
+            if m is not None and hasattr(m, "to") and device is not None:
+                m.to(device)
+        if device is not None:
+            self.device = torch.device(device)
+        return self
+
     # ---- reference :374-387 ----
     def check_inputs(self, prompt, height, width, callback_steps):
         if not isinstance(prompt, str) and not isinstance(prompt, list):
@@ -278,42 +295,68 @@ class MotionEditorPipeline:
 
     @torch.no_grad()
     def denoise_step_graphed(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
-                             guidance_scale: float, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
-        """denoise_step with its ~1100 kernel launches (both HIP streams) captured ONCE into a hipGraph and replayed: shapes and
-        key-segment tables are static, the editors' gating is a function of the step index, and the per-step scalars
-        (timestep, guidance, DDIM coefficients) live in device memory (ops.STEP_PARAMS), so a replay needs four host writes
-        and one launch.  The first call per (shape, gating) runs the step eagerly (warm-up: allocations, tables, function
-        attributes) and captures it; editors' counters advance exactly as in the eager step."""
+                             guidance_scale: float, controlnet_conditioning_scale: float = 1.0, *, shard=None, cfg_group=None, cfg_parallel_group=None) -> torch.Tensor:
+        """A denoising step with its ~1100 kernel launches (both HIP streams, and -- in the sharded modes -- every RCCL exchange) captured ONCE
+        into a hipGraph and replayed: shapes and key-segment tables are static, the editors' gating is a function of the step index, and the
+        per-step scalars (timestep, guidance, DDIM coefficients) live in device memory (ops.STEP_PARAMS), so a replay needs four host writes
+        and one launch.  The first call per (mode, shape, gating) runs the step eagerly (warm-up: allocations, tables, function attributes,
+        communicator set-up) and captures it; editors' counters advance exactly as in the eager step.
+
+        Which step is captured:  plain `denoise_step` by default; `shard=` (+ optional `cfg_group=`) -> `denoise_step_frame_sharded`;
+        `cfg_parallel_group=` -> `denoise_step_cfg_parallel`.  Collectives are captured as graph nodes (torch.distributed's NCCL/RCCL
+        process group enqueues on its streams, which fork from and join the capturing stream); every rank of the groups involved must
+        capture and replay in step."""
+        from .. import parallel
         sed, ted = self.unet.spatial_editor, self.unet.temporal_editor
-        key = (tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr()),
+        if shard is not None:
+            mode = ("frames", id(shard), None if cfg_group is None else id(cfg_group))
+            step = lambda lat, emb: self.denoise_step_frame_sharded(lat, t, emb, images, guidance_scale, shard, controlnet_conditioning_scale, cfg_group=cfg_group)   # noqa: E731
+        elif cfg_parallel_group is not None:
+            mode = ("cfg", id(cfg_parallel_group))
+            step = lambda lat, emb: self.denoise_step_cfg_parallel(lat, t, emb, images, guidance_scale, group=cfg_parallel_group,   # noqa: E731
+                                                                   controlnet_conditioning_scale=controlnet_conditioning_scale)
+        else:
+            mode = ("single",)
+            step = lambda lat, emb: self.denoise_step(lat, t, emb, images, guidance_scale, controlnet_conditioning_scale)   # noqa: E731
+        key = (mode, tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr()),
                self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.overlap_controlnet, self.overlap_adapter)
         ca, cb = self.scheduler.coeffs(int(t))
         host = torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32)
         ent = self._graphs.get(key)
         if ent is None:
-            counters = [(e.cur_step, e.cur_att_layer) for e in (sed, ted) if e is not None]
+            editors = [e for e in (sed, ted) if e is not None]
+            counters = [(e.cur_step, e.cur_att_layer) for e in editors]
             st = dict(lat=latents.clone(), emb=text_embeddings_input.clone(), params=host.to(latents.device))
-            self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)   # warm-up, eager
+            step(st["lat"], st["emb"])                      # warm-up, eager
             torch.cuda.synchronize()
-            for e, (cs, cl) in zip([e for e in (sed, ted) if e is not None], counters):
+            for e, (cs, cl) in zip(editors, counters):
                 e.cur_step, e.cur_att_layer = cs, cl
+            before = {k: list(v) for k, v in parallel.STATS.items()}
             g = torch.cuda.CUDAGraph()
             ops.STEP_PARAMS = st["params"]
             try:
-                with torch.cuda.graph(g):
-                    st["out"] = self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    st["out"] = step(st["lat"], st["emb"])
             finally:
                 ops.STEP_PARAMS = None
+            # the exchanges of the captured step, for bench.py's `comm` accounting: added again at every replay
+            st["comm"] = {k: [v[0] - before.get(k, [0, 0])[0], v[1] - before.get(k, [0, 0])[1]] for k, v in parallel.STATS.items()}
+            for k, v in st["comm"].items():     # the capture pass itself moved nothing
+                parallel.STATS[k][0] -= v[0]
+                parallel.STATS[k][1] -= v[1]
             st["graph"] = g
             st["images"] = images      # keep the captured conditioning tensor alive
-            st["counters"] = [(e.cur_step, e.cur_att_layer) for e in (sed, ted) if e is not None]   # state after one step
-            for e, (cs, cl) in zip([e for e in (sed, ted) if e is not None], counters):
+            for e, (cs, cl) in zip(editors, counters):
                 e.cur_step, e.cur_att_layer = cs, cl
             ent = self._graphs[key] = st
         ent["lat"].copy_(latents)
         ent["emb"].copy_(text_embeddings_input)
         ent["params"].copy_(host, non_blocking=False)
         ent["graph"].replay()
+        for k, v in ent["comm"].items():
+            c = parallel.STATS.setdefault(k, [0, 0])
+            c[0] += v[0]
+            c[1] += v[1]
         for e in (sed, ted):
             if e is not None:      # what MutualAttentionBase.__call__ does over the step's attention layers
                 e.cur_att_layer = 0

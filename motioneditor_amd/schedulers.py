@@ -43,13 +43,35 @@ class DDIMScheduler:
     @classmethod
     def from_config(cls, config) -> "DDIMScheduler":
         """Adopt a foreign scheduler's configuration (diffusers' DDIMScheduler as inference.py:187-197 builds it: `.config` is a
-        FrozenDict): only the scaled-linear, eta = 0 DDIM the reference runs is supported; anything else raises."""
+        FrozenDict).  Keys the configuration does not carry take DIFFUSERS' OWN defaults (steps_offset 0, set_alpha_to_one True, linear
+        betas 1e-4 .. 2e-2 -- not the SD-1.5 values this class's constructor defaults to), so that a foreign config means here what it means
+        there; what this path cannot reproduce (anything but the epsilon-prediction, leading-spaced, eta = 0 DDIM with scaled-linear betas
+        the reference runs) raises instead of being ignored."""
         get = (lambda k, d: config.get(k, d)) if hasattr(config, "get") else (lambda k, d: getattr(config, k, d))
         if get("prediction_type", "epsilon") != "epsilon":
             raise NotImplementedError(f"prediction_type {get('prediction_type', None)!r}")
-        return cls(num_train_timesteps=get("num_train_timesteps", 1000), beta_start=get("beta_start", 0.00085), beta_end=get("beta_end", 0.012),
-                   beta_schedule=get("beta_schedule", "scaled_linear"), clip_sample=False, set_alpha_to_one=get("set_alpha_to_one", False),
-                   steps_offset=get("steps_offset", 1))
+        if get("trained_betas", None) is not None:
+            raise NotImplementedError("trained_betas")
+        for flag in ("thresholding", "rescale_betas_zero_snr"):
+            if get(flag, False):
+                raise NotImplementedError(f"{flag}=True")
+        if get("timestep_spacing", "leading") != "leading":
+            raise NotImplementedError(f"timestep_spacing {get('timestep_spacing', None)!r} (the reference's SD-1.5 scheduler is 'leading')")
+        return cls(num_train_timesteps=get("num_train_timesteps", 1000), beta_start=get("beta_start", 0.0001), beta_end=get("beta_end", 0.02),
+                   beta_schedule=get("beta_schedule", "linear"), clip_sample=False, set_alpha_to_one=get("set_alpha_to_one", True),
+                   steps_offset=get("steps_offset", 0))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, **kwargs) -> "DDIMScheduler":
+        """diffusers signature for a local directory (inference.py:192,198: DDIMScheduler.from_pretrained(path, subfolder="scheduler")):
+        reads `scheduler_config.json`."""
+        import json
+        from pathlib import Path
+        d = Path(pretrained_model_name_or_path) / subfolder if subfolder else Path(pretrained_model_name_or_path)
+        f = d / "scheduler_config.json"
+        if not f.exists():
+            raise FileNotFoundError(f"{f} not found")
+        return cls.from_config(json.loads(f.read_text()))
 
     def set_timesteps(self, num_inference_steps: int, device=None):
         self.num_inference_steps = num_inference_steps

@@ -200,7 +200,7 @@ class AdapterTrainer:
         self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         self.steps = 0
         P = unet.P
-        P.state = dict(P.state)          # a private, mutable weight store
+        P.make_private()                 # a private, mutable weight store
         self.names = sorted(k[len(P.prefix):] for k in P.state if k.startswith(P.prefix + prefix))
         self.keys = graph.adapter_pack(P, prefix)
         covered = sorted(n for k in self.keys for n in k.partition(":")[2].split("|"))
@@ -233,16 +233,17 @@ class AdapterTrainer:
         from .models import graph
         B_ = graph.ops
         world = self._world()
+        dist_on = dist.is_available() and dist.is_initialized()
         self.grad.zero_()
         sync = None
-        if world > 1:
+        if dist_on:
             sync = lambda a: dist.all_reduce(a, op=dist.ReduceOp.MAX, group=self.group)   # noqa: E731  (one loss scale for every rank's bucket)
         loss, ls, G = _adapter_backward(self.unet, noisy_latents, timestep, encoder_hidden_states, down_block_res_samples, mid_block_res_sample, target, self.prefix,
                                         param_buffers=self.param_buffers, sync_amax=sync)
         stray = [k for k in G.params if k not in self.param_buffers]
         if stray:
             raise RuntimeError(f"a gradient reached packed tensors the trainer does not own: {stray[:3]}")
-        if world > 1:
+        if dist_on:
             dist.all_reduce(self.grad, group=self.group)                 # DP gradient sum: ONE bucket of every adapter gradient (averaged by grad_scale below)
             lt = torch.tensor([loss], dtype=torch.float32, device=self.grad.device)
             dist.all_reduce(lt, group=self.group)                        # train_adaptor.py:377 (accelerator.gather(loss).mean())

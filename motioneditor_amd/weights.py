@@ -37,6 +37,13 @@ class Packed:
         self.prefix = prefix
         self.cache: Dict[str, torch.Tensor] = {}
 
+    def make_private(self) -> None:
+        """Give this store its own (mutable) name -> tensor mapping before the first parameter is replaced: the caller's state dict -- often
+        shared by several models -- must not change under it."""
+        if not getattr(self, "_private", False):
+            self.state = dict(self.state)
+            self._private = True
+
     def has(self, name: str) -> bool:
         return (self.prefix + name) in self.state
 
@@ -145,8 +152,9 @@ class Packed:
 
     def update(self, name: str, value: torch.Tensor) -> None:
         """Replace a parameter (reference name, reference layout); every packed tensor built from it is dropped and re-packed on its
-        next use (and its cached transpose forgotten).  The state mapping must be mutable (a dict)."""
+        next use (and its cached transpose forgotten).  The store takes a private copy of the mapping first (make_private)."""
         from . import ops
+        self.make_private()
         self.state[self.prefix + name] = value.detach().cpu().clone()   # type: ignore[index]
         stale = [k for k in self.cache if name in k.partition(":")[2].split("|")]
         if self.device.type == "cuda":

@@ -62,7 +62,7 @@ def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, bias: Optional[torch
     step = max(1, SDPA_SCORE_BYTES // max(1, q.shape[1] * k.shape[1] * 4))
     if step < q.shape[0]:
         return torch.cat([sdpa(q[i:i + step], k[i:i + step], v[i:i + step], bias) for i in range(0, q.shape[0], step)], dim=0)
-    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype), q, k.transpose(1, 2), beta=0, alpha=scale)
+    s = torch.baddbmm(torch.empty(q.shape[0], q.shape[1], k.shape[1], dtype=q.dtype, device=q.device), q, k.transpose(1, 2), beta=0, alpha=scale)
     if bias is not None:
         s = s + bias
     return torch.bmm(s.softmax(dim=-1), v)
@@ -80,7 +80,8 @@ def timestep_sinusoid(t: torch.Tensor, dim: int = 320) -> torch.Tensor:
 
 
 def time_embed(sd: SD, p: str, t: torch.Tensor) -> torch.Tensor:
-    e = timestep_sinusoid(t)
+    w = sd[p + "time_embedding.linear_1.weight"]
+    e = timestep_sinusoid(t).to(w.device, w.dtype)    # (fp32 everywhere in the pinned runs; the cast serves the fp16 calibration run)
     return _lin(sd, p + "time_embedding.linear_2", F.silu(_lin(sd, p + "time_embedding.linear_1", e)))
 
 
@@ -172,7 +173,7 @@ class SpatialEditor(_EditorBase):
         nf = 8
         Hs = int(math.isqrt(N))
         assert Hs * Hs == N and k.shape[0] % nf == 0
-        m = F.interpolate(self.source_masks, (nf, Hs, Hs), mode="nearest")  # [1,1,8,Hs,Hs]
+        m = F.interpolate(self.source_masks, (nf, Hs, Hs), mode="nearest").to(k.device, k.dtype)  # [1,1,8,Hs,Hs]
         prev_idx = torch.arange(nf) - 1
         prev_idx[0] = 0
         m_prev, m_cur = m[:, :, prev_idx], m
@@ -258,9 +259,10 @@ def feed_forward(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return _lin(sd, p + ".net.2", a * F.gelu(g))
 
 
-def causal_bias(f: int) -> torch.Tensor:
+def causal_bias(f: int, like: Optional[torch.Tensor] = None) -> torch.Tensor:
     """(1 - tril) * -10000, shape [1,f,f] (attention_2d.py:542-543)."""
-    return (1.0 - torch.tril(torch.ones(f, f)))[None] * -10000.0
+    b = (1.0 - torch.tril(torch.ones(f, f)))[None] * -10000.0
+    return b if like is None else b.to(like.device, like.dtype)
 
 
 def basic_block(sd: SD, p: str, x: torch.Tensor, ehs: Optional[torch.Tensor], f: int,
@@ -295,7 +297,7 @@ def basic_block(sd: SD, p: str, x: torch.Tensor, ehs: Optional[torch.Tensor], f:
         q = _split_heads(_lin(sd, p + ".attn_temp.to_q", nt), HEADS)
         k = _split_heads(_lin(sd, p + ".attn_temp.to_k", nt), HEADS)
         v = _split_heads(_lin(sd, p + ".attn_temp.to_v", nt), HEADS)
-        a = temporal(q, k, v, causal_bias(f)) if temporal is not None else _merge_heads(sdpa(q, k, v, causal_bias(f)), HEADS)
+        a = temporal(q, k, v, causal_bias(f, q)) if temporal is not None else _merge_heads(sdpa(q, k, v, causal_bias(f, q)), HEADS)
         xt = _lin(sd, p + ".attn_temp.to_out.0", a) + xt
         x = xt.reshape(bf // f, n, f, c).permute(0, 2, 1, 3).reshape(bf, n, c)
     return x
@@ -352,7 +354,7 @@ def adapter_block(sd: SD, p: str, x: torch.Tensor, src: torch.Tensor) -> torch.T
     q = _split_heads(_lin(sd, p + ".attn_self_temp.to_q", nt), HEADS)
     k = _split_heads(_lin(sd, p + ".attn_self_temp.to_k", nt), HEADS)
     v = _split_heads(_lin(sd, p + ".attn_self_temp.to_v", nt), HEADS)
-    at = _lin(sd, p + ".attn_self_temp.to_out.0", _merge_heads(sdpa(q, k, v, causal_bias(t)), HEADS)) + at
+    at = _lin(sd, p + ".attn_self_temp.to_out.0", _merge_heads(sdpa(q, k, v, causal_bias(t, q)), HEADS)) + at
     a = at.reshape(b, n, t, c).permute(0, 2, 1, 3)  # b t n c
     a = a.reshape(b, t, hh, ww, c).permute(0, 4, 1, 2, 3)
     return a + hc

@@ -3,6 +3,7 @@ tests/golden/harness_inputs.npz (shapes + checksums), the tensor conventions by 
 import sys
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLD, ROOT
@@ -103,3 +104,68 @@ def test_prepare_image_matches_the_reference_function_golden():
     t = T(g["tensor_in"])
     assert torch.equal(pipe.prepare_image(t, 32, 24, 2, 1, "cpu", torch.float32, True), T(g["tensor_cfg"]))
     assert torch.equal(pipe.prepare_image([t[:1], t[1:]], 32, 24, 2, 1, "cpu", torch.float32, False), T(g["tensor_list"]))
+
+
+def test_reference_harness_setup_calls_run_on_the_drop_in_classes(tmp_path, unet_sd_np, cn_sd_np):
+    """The calls inference.py:152-248 makes on its models between loading them and the first batch -- requires_grad_(False),
+    enable_xformers_memory_efficient_attention, the pipeline constructor with DDIMScheduler.from_pretrained(..., subfolder="scheduler"),
+    enable_vae_slicing, .to(device, dtype=...), unet.controlnet_adapter.load_state_dict(adapter checkpoint), named_modules /
+    named_parameters, eval() -- replayed on motioneditor_amd's classes (weights from state dicts; from_pretrained itself is covered by
+    test_checkpoint_cpu.py and the GPU round trip)."""
+    import json
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from motioneditor_amd.schedulers import DDIMScheduler
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(dict(   # SD-1.5's scheduler_config.json (SURVEY Appendix B)
+        _class_name="PNDMScheduler", num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+        set_alpha_to_one=False, steps_offset=1, skip_prk_steps=True, trained_betas=None)))
+    vae = AutoencoderKL(synth.synth_state_dict(synth.vae_decoder_schema(), salt="vae."), device="cpu", dtype=torch.float32)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    controlnet = ControlNetModel(cn_sd_np, device="cpu", dtype=torch.float32)
+    for m in (vae, unet, controlnet):
+        assert m.requires_grad_(False) is m                                     # :159-162
+    unet.enable_xformers_memory_efficient_attention()                           # :166
+    unet.enable_gradient_checkpointing()                                        # :171
+    pipe = MotionEditorPipeline(vae=vae, text_encoder=None, tokenizer=None, unet=unet, scheduler=DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler"),
+                                safety_checker=None, feature_extractor=None, controlnet=controlnet)          # :187-196
+    pipe.enable_vae_slicing()                                                   # :197
+    inv = DDIMScheduler.from_pretrained(str(tmp_path), subfolder="scheduler")   # :198-199
+    inv.set_timesteps(50)
+    assert inv.timesteps[0] == 981 and inv.timesteps[-1] == 1 and pipe.scheduler.config.steps_offset == 1
+    vae.to("cpu", dtype=torch.float32)                                          # :215-217
+    controlnet.to(torch.device("cpu"), dtype=torch.float16)
+    with pytest.raises(NotImplementedError):
+        controlnet.to("cpu", dtype=torch.bfloat16)
+    # :237-240 -- the stage-2 adapter checkpoint: a state dict without the "controlnet_adapter." prefix
+    g = torch.Generator().manual_seed(4)
+    adapter = {k[len("controlnet_adapter."):]: torch.randn(v.shape, generator=g) for k, v in unet_sd_np.items() if k.startswith("controlnet_adapter.")}
+    torch.save(adapter, tmp_path / "adapter.pth")
+    packed_before = unet.P.mat("controlnet_adapter.body.0.block2.weight")
+    unet.controlnet_adapter.load_state_dict(torch.load(tmp_path / "adapter.pth"))
+    k0 = "body.0.block2.weight"
+    assert torch.equal(unet.P.raw("controlnet_adapter." + k0), adapter[k0])
+    assert unet.P.mat("controlnet_adapter." + k0) is not packed_before and torch.equal(unet.P.mat("controlnet_adapter." + k0)[:, 0, :], adapter[k0][:, :, 0])   # re-packed
+    with pytest.raises(RuntimeError):
+        unet.controlnet_adapter.load_state_dict({k0: adapter[k0]})               # strict: the rest is missing
+    with pytest.raises(RuntimeError):
+        unet.controlnet_adapter.load_state_dict({**adapter, k0: torch.zeros(3)})   # size mismatch
+    mods = [n for n, _ in pipe.unet.named_modules()]                            # :242-246
+    params = [n for n, _ in pipe.unet.named_parameters()]
+    assert mods[0] == "" and "controlnet_adapter.body.11.attn_self_temp" in mods and "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q" in mods
+    assert params == list(synth.unet_schema()) and len(set(mods)) == len(mods)
+    assert unet.eval() is unet and unet.training is False                       # :248
+    assert unet.dtype == torch.float16 and unet.device == torch.device("cpu")   # :268 source_masks.to(device=unet.device, dtype=unet.dtype)
+    # a foreign config that lacks the SD-1.5 keys means diffusers' defaults (linear betas): refused, not silently replaced
+    (tmp_path / "bare").mkdir()
+    (tmp_path / "bare" / "scheduler_config.json").write_text(json.dumps(dict(num_train_timesteps=1000)))
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler.from_pretrained(str(tmp_path / "bare"))
+    for bad in (dict(timestep_spacing="trailing"), dict(thresholding=True), dict(rescale_betas_zero_snr=True), dict(trained_betas=[0.1])):
+        with pytest.raises(NotImplementedError):
+            DDIMScheduler.from_config(dict(beta_schedule="scaled_linear", **bad))
+    d = DDIMScheduler.from_config(dict(beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012))
+    assert d.config.steps_offset == 0 and d.config.set_alpha_to_one is True     # diffusers' defaults for absent keys

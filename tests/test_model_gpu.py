@@ -22,6 +22,11 @@ pytestmark = pytest.mark.gpu
 
 UNET_TOL = 1e-2
 STEP_TOL = 5e-3
+# The CFG-amplified noise prediction (uncond + 7.5 (cond - uncond)): SURVEY 8c asked for this bound to be calibrated against an fp16 eager run of
+# the restatement.  tools/calibrate_fp16.py (profiles/r03_fp16_calibration.txt): the oracle itself in fp16 sits at 0.99 - 1.0e-2 from its own fp32 run
+# (8 f x 8 x 8, 24 f x 16 x 16 and 8 f x 32 x 32 latents alike; updated latents 8.2 - 8.4e-4); the HIP path (fp32 accumulation / statistics)
+# measures 9.4e-3 / 5 - 6e-4 -- the bound is 1.5 x the fp16-eager level instead of the former, uncalibrated 2e-2.
+NOISE_PRED_TOL = 1.5e-2
 
 
 def record(name, value):
@@ -148,7 +153,7 @@ def test_denoise_step_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch
     record(f"step{step}_noise_pred", e_np)
     e = rel_l2(got, want)
     record(f"step{step}_latents", e)
-    assert e_np <= 2 * UNET_TOL, e_np   # CFG amplifies (cond - uncond) by 7.5
+    assert e_np <= NOISE_PRED_TOL, e_np   # CFG amplifies (cond - uncond) by 7.5
     assert e <= STEP_TOL, e
 
 
@@ -464,9 +469,11 @@ def test_properties_at_larger_size(unet):
 
 
 def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
-    """World-size-1 RCCL process group: exercises the frame-sharded code path (K|V all-gather, sharded tconv / temporal
-    attention arguments, GroupNorm split) through the real kernels; must equal the ordinary step to the noise floor.
-    Multi-rank correctness of the exchanges is covered by tests/test_frame_shard_cpu.py (gloo, world 2)."""
+    """World-size-1 RCCL process group: exercises the frame-sharded code path (K|V exchange buffers, sharded tconv / temporal
+    attention arguments, GroupNorm split with its all-reduce) through the real kernels; must equal the ordinary step to the noise floor.
+    Then the same sharded step CAPTURED into a hipGraph (RCCL calls as graph nodes, denoise_step_graphed(shard=...)) and replayed over
+    two steps with different timesteps / embeddings: bitwise equal to the eager sharded steps.
+    Multi-rank correctness of the exchanges is covered by tests/test_frame_shard_cpu.py (gloo, world 2-8)."""
     import torch.distributed as dist
     from motioneditor_amd import parallel
     from motioneditor_amd.pipelines import MotionEditorPipeline
@@ -487,13 +494,104 @@ def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
         want = pipe.denoise_step(x["latents"].cuda(), t, emb, torch.cat([images] * 2), 7.5)
         sed.reset(); ted.reset()
         sed.cur_step = ted.cur_step = 4
-        got = pipe.denoise_step_frame_sharded(x["latents"].cuda(), t, emb, images, 7.5, parallel.FrameShard(f))
+        shard = parallel.FrameShard(f)
+        got = pipe.denoise_step_frame_sharded(x["latents"].cuda(), t, emb, images, 7.5, shard)
         e = rel_l2(got, want)
         record("frame_shard_world1", e)
         assert e < 3e-3, e
+        # captured sharded step == eager sharded step, bit for bit, over two consecutive steps (editors active in both)
+        outs = {}
+        for mode in ("eager", "graph"):
+            sed.reset(); ted.reset()
+            sed.cur_step = ted.cur_step = 4
+            lat = x["latents"].cuda()
+            for i in (4, 5):
+                emb_i = torch.cat([(x["uncond"] * (1.0 + 0.1 * i)).expand(2, 77, 768), x["cond"]]).cuda()
+                ti = pipe.scheduler.timesteps[i]
+                if mode == "eager":
+                    lat = pipe.denoise_step_frame_sharded(lat, ti, emb_i, images, 7.5, shard)
+                else:
+                    lat = pipe.denoise_step_graphed(lat, ti, emb_i, images, 7.5, shard=shard)
+            outs[mode] = lat.clone()
+            assert sed.cur_step == ted.cur_step == 6
+        eg = rel_l2(outs["graph"], outs["eager"])
+        record("frame_shard_graph_vs_eager", eg)
+        assert eg == 0.0, eg
     finally:
         unet.spatial_editor = unet.temporal_editor = None
         dist.destroy_process_group()
+
+
+def test_step_config3_full_size_vs_golden():
+    """BASELINE configs[2] at FULL size -- the benchmarked workload itself (24 frames x 64x64 latents, batch 4, ControlNet + adapter, both editors
+    active, bench.py's inputs and weights) -- against tests/golden/step_config3.npz, which oracle/make_golden.py --only-config3 generated in the
+    build container (one oracle step, 707 s on 8 cores): a strided sub-sample of the updated latents and of the guided noise prediction plus
+    the abs-mean of every skip, motion residual and ControlNet residual."""
+    from motioneditor_amd import synth
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    g = np.load(GOLD / "step_config3.npz")
+    f, h, step = int(g["frames"]), int(g["latent"]), int(g["step"])
+    x = synth.bench_inputs(f, h, h)
+    u = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cuda")
+    c = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
+    pipe = MotionEditorPipeline(unet=u, controlnet=c)
+    sed, ted = editors(u, x["masks"])
+    sed.cur_step = ted.cur_step = step
+    pipe.scheduler.set_timesteps(50)
+    t = pipe.scheduler.timesteps[step]
+    assert int(t) == int(g["t"])
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * h).cuda()
+    emb = torch.cat([x["uncond"][step].expand(2, 77, 768), x["cond"]]).cuda()
+    taps = {}
+    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images, 7.5, taps=taps)
+    am = lambda t_: float(t_.float().abs().mean())   # noqa: E731
+    for i, d in enumerate(taps["cn_down"]):           # one ControlNet entry (the reference's two are identical)
+        assert abs(am(d) - g["cn_down_stats"][i, 1]) < 2e-2 * g["cn_down_stats"][i, 1], f"ControlNet residual {i}"
+    assert abs(0.5 * am(taps["cn_mid"]) - g["cn_mid_stats"][1]) < 2e-2 * g["cn_mid_stats"][1]        # golden: [0, m, 0, m]
+    for i, s_ in enumerate(taps["skips"]):
+        assert abs(am(s_) - g["skip_stats"][i, 1]) < 2e-2 * g["skip_stats"][i, 1], f"skip {i}"
+    for i, m in enumerate(taps["motion"]):            # edit rows only here; the golden statistics are over [0, m0, 0, m1]
+        assert abs(0.5 * am(m) - g["motion_stats"][i, 1]) < 3e-2 * g["motion_stats"][i, 1], f"motion residual {i}"
+    assert abs(am(taps["mid"]) - g["mid_stats"][1]) < 2e-2 * g["mid_stats"][1]
+    N = h * h
+    eps = taps["eps_rows"].float().reshape(4, f, N, 4).permute(0, 3, 1, 2).reshape(4, 4, f, h, h)
+    npred = (eps[:2] + 7.5 * (eps[2:] - eps[:2]))[:, :, ::2, ::4, ::4].cpu()
+    e_np = rel_l2(npred, torch.from_numpy(g["noise_pred_sub"]))
+    e = rel_l2(got[:, :, :, ::2, ::2].cpu(), torch.from_numpy(g["latents_sub"]))
+    record("config3_full_size_noise_pred", e_np)
+    record("config3_full_size_latents", e)
+    u.spatial_editor = u.temporal_editor = None
+    assert torch.isfinite(got).all() and e_np <= NOISE_PRED_TOL and e <= STEP_TOL, (e_np, e)
+
+
+@pytest.mark.parametrize("f,hw", [(8, 32), (48, 16)])
+def test_denoise_step_baseline_config0_and_48_frames_vs_cpu_oracle(unet, controlnet, unet_sd_torch, cn_sd_torch, f, hw):
+    """(8, 32): BASELINE configs[0]'s shape -- 8 frames x 256^2 -- one full two-branch step, editors active, vs the CPU oracle run on the box.
+    (48, 16): BASELINE configs[4]'s frame count through the whole graph (six adapter chunks, 48-frame temporal attention in every block)."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from oracle import ref_cpu
+    from test_step_cpu import step_inputs
+    x = step_inputs(f=f, h=hw, w=hw)
+    step = 4
+    ddim = ref_cpu.DDIM()
+    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+    sp.cur_step = tp.cur_step = step
+    t = ddim.timesteps[step]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * hw, 8 * hw)
+    with torch.no_grad():
+        want = ref_cpu.denoise_step(unet_sd_torch, cn_sd_torch, ddim, x["latents"], t, x["uncond"], x["cond"], images, sp, tp, 7.5)
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    sed, ted = editors(unet, x["masks"])
+    sed.cur_step = ted.cur_step = step
+    pipe.scheduler.set_timesteps(50)
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images.cuda(), 7.5)
+    unet.spatial_editor = unet.temporal_editor = None
+    e = rel_l2(got, want)
+    record(f"step4_f{f}_{hw}x{hw}_latents", e)
+    assert e <= STEP_TOL, e
 
 
 def test_null_text_optimization_on_the_gpu_vs_reference_golden(unet_sd_np):
@@ -556,3 +654,93 @@ def test_adapter_training_gradients_on_the_gpu_vs_reference_golden(unet_sd_np):
     print("adapter training on GPU: loss", loss, "vs", float(g["loss"]), " total grad norm ratio", tot, " median / max per-parameter norm error", float(np.median(rel)), float(rel.max()),
           " full tensors rel-L2", fulls)
     assert abs(loss - float(g["loss"])) < 5e-3 * float(g["loss"]) and abs(tot - 1) < 2e-2 and float(np.median(rel)) < 2e-2 and max(fulls) < 5e-2, (loss, tot, fulls)
+
+
+def test_adapter_trainer_step_on_the_gpu_vs_oracle_autograd_adamw(unet_sd_np):
+    """util.AdapterTrainer.step entirely on the device, on a world-1 RCCL group (the gradient bucket and the loss go through dist.all_reduce on
+    device tensors): tape gradients accumulated into one flat fp32 bucket, global-norm clip from the device reduction, me_adamw on the packed
+    fp32 masters, packed fp16 weights refreshed in place -- against the oracle's UNet under torch autograd + clip_grad_norm_ +
+    torch.optim.AdamW on the same clip (train_adaptor.py:364-385).  Then a second step: the forward must read the UPDATED weights (the
+    transposed-weight cache of the backward is invalidated), i.e. its loss equals the oracle's loss at the updated parameters."""
+    import torch.distributed as dist
+    from conftest import GOLD
+    from motioneditor_amd import ops, util
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from oracle import ref_cpu
+    g = np.load(GOLD / "adapter_train.npz")
+    T = torch.from_numpy
+    F32 = lambda k: T(g[k].astype(np.float32))   # noqa: E731
+    clip = dict(noisy=F32("noisy"), t=int(g["t"]), ehs=F32("ehs"), down=[F32(f"down{i}") for i in range(12)], mid=F32("mid"), noise=F32("noise"))
+    lr = 1e-3                                            # a visible step (the reference's 3e-5 moves fp32 weights by 1e-5)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        unet = UNet2DConditionModel(unet_sd_np, device="cuda")
+        tr = util.AdapterTrainer(unet, lr=lr)
+        loss = tr.step(clip["noisy"], clip["t"], clip["ehs"], clip["down"], clip["mid"], clip["noise"])
+        cache1 = len(ops._wT_cache)     # transposes of the FROZEN weights the backward walked through; the trained ones were dropped again
+        # oracle: the same step with torch autograd
+        sd = {k: T(v) for k, v in unet_sd_np.items()}
+        names = tr.names
+        params = {k: torch.nn.Parameter(sd[k].clone()) for k in names}
+        opt = torch.optim.AdamW(list(params.values()), lr=lr, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+        sd2 = dict(sd)
+        sd2.update(params)
+        l0 = torch.nn.functional.mse_loss(ref_cpu.unet_forward(sd2, clip["noisy"], clip["t"], clip["ehs"], clip["down"], clip["mid"]), clip["noise"])
+        for k, gr in zip(names, torch.autograd.grad(l0, [params[k] for k in names])):
+            params[k].grad = gr
+        torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+        opt.step()
+        got = tr.export_state_dict()
+        num = sum(float((got[k] - params[k].detach()).pow(2).sum()) for k in names)
+        den = sum(float((params[k].detach() - sd[k]).pow(2).sum()) for k in names)
+        upd = (num / den) ** 0.5
+        record("adapter_trainer_update_rel_l2", upd)
+        print("adapter trainer on GPU: loss", loss, "vs", float(l0), " update rel-L2", upd)
+        assert abs(loss - float(l0)) < 5e-3 * float(l0) and upd < 1e-2, (loss, float(l0), upd)
+        # second step: forward on the updated weights
+        with torch.no_grad():
+            sd3 = dict(sd)
+            sd3.update({k: v.detach() for k, v in params.items()})
+            l1 = float(torch.nn.functional.mse_loss(ref_cpu.unet_forward(sd3, clip["noisy"], clip["t"], clip["ehs"], clip["down"], clip["mid"]), clip["noise"]))
+        loss2 = tr.step(clip["noisy"], clip["t"], clip["ehs"], clip["down"], clip["mid"], clip["noise"])
+        assert abs(loss2 - l1) < 5e-3 * l1 and abs(l1 - float(l0)) > 1e-5, (loss2, l1, float(l0))
+        tr.step(clip["noisy"], clip["t"], clip["ehs"], clip["down"], clip["mid"], clip["noise"])
+        assert len(ops._wT_cache) <= cache1, "transposed-weight cache grows with the training steps"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_example_sequence_on_the_gpu_matches_the_oracle_loss(unet_sd_np, cn_sd_np):
+    """examples/train_adapter.py::step on the GPU -- VAE encode, add_noise, ControlNet, UNet + adapter on the tape, backward, clip, AdamW -- reports
+    the oracle's loss for the same tensors and moves the adapter."""
+    import sys
+    sys.path.insert(0, str(ROOT / "examples"))
+    import train_adapter as ex
+    from motioneditor_amd import synth, util
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.models.vae import AutoencoderKL
+    from oracle import ref_cpu
+    vsd = synth.synth_state_dict(synth.vae_encoder_schema(), 33, salt="vae.")
+    vae, unet, cn = AutoencoderKL(vsd, device="cuda"), UNet2DConditionModel(unet_sd_np, device="cuda"), ControlNetModel(cn_sd_np, device="cuda")
+    tr = util.AdapterTrainer(unet, lr=1e-3)
+    f, H, t = 8, 64, 401
+    b = ex.training_batch(f, H, H)
+    before = tr.export_state_dict()["controlnet_adapter.body.0.block2.weight"].clone()
+    loss = ex.step(tr, vae, cn, b, t)
+    T = torch.from_numpy
+    usd, csd = {k: T(x) for k, x in unet_sd_np.items()}, {k: T(x) for k, x in cn_sd_np.items()}
+    with torch.no_grad():
+        lat = ref_cpu.vae_encode_sample({k: T(x) for k, x in vsd.items()}, b["pixel_values"].reshape(f, 3, H, H), b["encode_noise"])
+        lat = lat.reshape(1, f, 4, 8, 8).permute(0, 2, 1, 3, 4) * 0.18215
+        a = float(ex.alphas_cumprod()[t])
+        noisy = a ** 0.5 * lat + (1 - a) ** 0.5 * b["noise"]
+        down, mid = ref_cpu.controlnet_forward(csd, noisy.permute(0, 2, 1, 3, 4).reshape(f, 4, 8, 8), t, b["ehs"].repeat(f, 1, 1), b["skeleton"].reshape(f, 3, H, H))
+        down = [d.reshape(1, f, *d.shape[1:]).permute(0, 2, 1, 3, 4) for d in down]
+        mid = mid.reshape(1, f, *mid.shape[1:]).permute(0, 2, 1, 3, 4)
+        want = float(torch.nn.functional.mse_loss(ref_cpu.unet_forward(usd, noisy, t, b["ehs"], down, mid), b["noise"]))
+    record("train_example_loss_rel", abs(loss - want) / want)
+    assert abs(loss - want) < 1e-2 * want, (loss, want)
+    assert float((tr.export_state_dict()["controlnet_adapter.body.0.block2.weight"] - before).abs().max()) > 1e-4
