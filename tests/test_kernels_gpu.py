@@ -722,10 +722,10 @@ def test_grad_acc_plain_strided_fp16_and_pooled(ops):
     got = cu(d0)
     ops.grad_acc(got, cu(big), 1.0, pool=(H, W))
     check(got, emu.grad_acc(d0.clone(), big, 1.0, pool=(H, W)), "grad_acc 2x2 pooling", rel=1e-3, mx=1e-2)
-    flat = _acc0((77 * 768,))
+    flat, add = _acc0((77 * 768,)), _acc0((77 * 768,), 5)
     got = cu(flat)
-    ops.grad_acc(got, cu(src.reshape(-1)[:77 * 768].contiguous()), 2.0)
-    check(got, flat + 2.0 * src.reshape(-1)[:77 * 768], "grad_acc 1-D", rel=1e-6, mx=1e-5)
+    ops.grad_acc(got, cu(add), 2.0)
+    check(got, flat + 2.0 * add, "grad_acc 1-D", rel=1e-6, mx=1e-5)
 
 
 def test_sumsq_absmax_is_deterministic_and_exact_enough(ops):
