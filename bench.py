@@ -71,6 +71,9 @@ def parse_args():
                     help="replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from Python -- "
                          "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
                          "measured neutral (the GPU, not the host, paces the step); across GPUs it could only be validated on a world-1 RCCL group")
+    ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
+                    help="who issues the data-path exchanges of the sharded modes: 'torch' = torch.distributed's nccl (= RCCL) process group; 'rccl' = RCCL called "
+                         "directly on our own communicators (motioneditor_amd/rccl.py: no watchdog, capturable); auto = rccl with --graph, else torch")
     ap.add_argument("--zero-tconv", action="store_true",
                     help="secondary measurement: UNet TemporalConv weights exactly zero, as in real checkpoints (resnet_2d.py:15-16) -> the launch is skipped")
     ap.add_argument("--emulate", action="store_true", help="test plumbing: torch-CPU emulation of the C ABI (tests/emu_ops.py), gloo backend")
@@ -312,10 +315,15 @@ def main():
                     if rank in ranks:
                         shard_group = g
     shard = None
+    comm = "torch" if args.emulate else (args.comm if args.comm != "auto" else ("rccl" if args.graph else "torch"))
+    if dist_on and comm == "rccl":   # our own communicators (every rank of a group creates it together); the pipeline takes the adapter in place of the group
+        from motioneditor_amd import parallel
+        if cfg_group is not None:
+            cfg_group = parallel.exchange(cfg_group, "rccl")
     if n_shards > 1 or mode == "frames":
         from motioneditor_amd import parallel
         lean = args.shard_exchange == "lean"
-        shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather")   # f / n_shards frames per rank
+        shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather", comm=comm)   # f / n_shards frames per rank
         assert shard.rank == shard_i
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (cfg), or for all ranks
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"], emu_dtype)
@@ -428,7 +436,7 @@ def main():
                           "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
-                          "hip_graph_replay": bool(use_graph), "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; the ControlNet restatement (diffusers, not in the reference tree) is unpinned"},
                "step_tflop_reference_semantics": round(tf_ref, 2), "step_tflop_is_baseline_md_figure": tf_exact,
                "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1)}

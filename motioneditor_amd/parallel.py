@@ -42,32 +42,116 @@ def stats_summary(steps: int = 1) -> dict:
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Exchange backends.  Every data-path exchange of this module goes through one of these two adapters (same interface):
+#   TorchExchange -- torch.distributed's process group ("gloo" in the CPU tests, "nccl" = RCCL for eager multi-GPU runs): collectives run on the
+#                    group's own stream under its watchdog; asynchronous forms return the Work objects.
+#   RcclExchange  -- RCCL called directly (motioneditor_amd/rccl.py): no watchdog, enqueued on the caller's stream or on the communicator's
+#                    side stream behind an event -- the form a captured hipGraph can hold (MotionEditorPipeline.denoise_step_graphed).
+# p2p peers are ranks INSIDE the group.
+# ---------------------------------------------------------------------------------------------------------------------
+class TorchExchange:
+    kind = "torch"
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
+
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_gather_start(self, out: torch.Tensor, inp: torch.Tensor):
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)   # in place: inp = this rank's slot of out
+
+    def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        dist.all_to_all_single(recv, send, group=self.group)
+
+    def p2p_start(self, ops_):
+        if not ops_:
+            return None
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._ranks[peer], self.group) for k, t, peer in ops_])
+
+    def finish(self, handle) -> None:
+        if handle is None:
+            return
+        for r in (handle if isinstance(handle, (list, tuple)) else [handle]):
+            r.wait()
+
+
+class RcclExchange:
+    kind = "rccl"
+
+    def __init__(self, group=None):
+        from . import rccl
+        self.group = group
+        self.comm = rccl.RcclComm.from_group(group)
+        self.rank, self.world = self.comm.rank, self.comm.world
+
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> None:
+        self.comm.all_reduce_(t, op)
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        self.comm.all_gather_into(out, inp)
+
+    def all_gather_start(self, out: torch.Tensor, inp: torch.Tensor):
+        return (self.comm.side(lambda: self.comm.all_gather_into(out, inp)), out, inp)     # tensors kept alive until finish()
+
+    def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        self.comm.all_to_all_single(recv, send)
+
+    def p2p_start(self, ops_):
+        if not ops_:
+            return None
+        return (self.comm.side(lambda: self.comm.batch_p2p(ops_)), ops_)
+
+    def finish(self, handle) -> None:
+        if handle is not None:
+            self.comm.join(handle[0])
+
+
+_exchanges = {}
+
+
+def exchange(group=None, kind: str = "torch"):
+    """The exchange adapter of a process group (one per (group, kind); creating an RcclExchange is a collective over the group)."""
+    if isinstance(group, (TorchExchange, RcclExchange)):
+        return group
+    key = (id(group) if group is not None else None, kind)
+    x = _exchanges.get(key)
+    if x is None:
+        x = _exchanges[key] = (RcclExchange if kind == "rccl" else TorchExchange)(group)
+    return x
+
+
 class FrameShard:
-    def __init__(self, f_total: int, group=None, temporal: str = "a2a", adapter: str = "halo"):
+    def __init__(self, f_total: int, group=None, temporal: str = "a2a", adapter: str = "halo", comm: str = "torch"):
         if temporal not in ("a2a", "gather") or adapter not in ("halo", "gather"):
             raise ValueError("temporal must be 'a2a' or 'gather', adapter 'halo' or 'gather'")
         self.temporal, self.adapter = temporal, adapter
         self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
+        self.x = exchange(group, comm)          # every exchange below goes through it
+        self.rank, self.world = self.x.rank, self.x.world
         if f_total % self.world:
             raise ValueError(f"{f_total} frames do not split evenly over {self.world} ranks")
         self.f_total = f_total
         self.f_loc = f_total // self.world
         self.frame0 = self.rank * self.f_loc
-        self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
 
     # ---- GroupNorm statistics -------------------------------------------------------------------------
     def allreduce_(self, t: torch.Tensor) -> None:
         _count("all_reduce(groupnorm stats)", t)
-        dist.all_reduce(t, group=self.group)
+        self.x.all_reduce_(t)
 
     # ---- K|V rows of all frame shards, part-major -----------------------------------------------------
     def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         _count("all_gather(K|V rows)", t)
-        dist.all_gather(list(out.unbind(0)), t, group=self.group)
+        self.x.all_gather_into(out.reshape(self.world * t.shape[0], *t.shape[1:]), t)
         return out.reshape(self.world * t.shape[0], *t.shape[1:])
 
     def kv_buffer(self, rows: int, cols: int, B: int, npix: int, like: torch.Tensor):
@@ -81,12 +165,12 @@ class FrameShard:
         projection, so the caller's next launches (the query projection) overlap the transfer; finish_kv() joins."""
         loc = ext[self.rank]
         _count("all_gather(K|V rows)", loc)
-        work = dist.all_gather_into_tensor(ext.reshape(-1, ext.shape[-1]), loc, group=self.group, async_op=True)   # in place: input = this rank's slot
+        work = self.x.all_gather_start(ext.reshape(-1, ext.shape[-1]), loc)   # in place: input = this rank's slot
         return (work, ext)
 
     def finish_kv(self, handle) -> torch.Tensor:
         work, ext = handle
-        work.wait()
+        self.x.finish(work)
         return ext.reshape(self.world * ext.shape[1], ext.shape[2])
 
     def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows=None) -> torch.Tensor:
@@ -104,7 +188,7 @@ class FrameShard:
         copy_blocks(send, x, R, BF, Ns, ys0=BF * Ns, ys1=Ns, xs0=Ns, xs1=npix)      # (bf, j, pl) -> (j, bf, pl)
         recv = torch.empty_like(send)
         _count("all_to_all(temporal in)", send, (R - 1) / R)
-        dist.all_to_all_single(recv, send, group=self.group)
+        self.x.all_to_all(recv, send)
         return recv
 
     def to_frame_shards(self, o: torch.Tensor, BF: int, npix: int, copy_blocks) -> torch.Tensor:
@@ -112,7 +196,7 @@ class FrameShard:
         R, Ns = self.world, npix // self.world
         recv = torch.empty_like(o)
         _count("all_to_all(temporal out)", o, (R - 1) / R)
-        dist.all_to_all_single(recv, o.contiguous(), group=self.group)
+        self.x.all_to_all(recv, o.contiguous())
         out = torch.empty((BF * npix, o.shape[1]), dtype=o.dtype, device=o.device)
         copy_blocks(out, recv, R, BF, Ns, ys0=Ns, ys1=npix, xs0=BF * Ns, xs1=Ns)       # (j, bf, pl) -> (bf, j, pl)
         return out
@@ -150,16 +234,14 @@ class FrameShard:
             for b in range(B):
                 copy_rows(first[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc) * npix:(b * self.f_loc + 1) * npix])
             _count("p2p(TemporalConv halo)", first)
-            ops_ += [dist.P2POp(dist.isend, first, self._ranks[self.rank - 1], self.group), dist.P2POp(dist.irecv, prev_blk, self._ranks[self.rank - 1], self.group)]
+            ops_ += [("send", first, self.rank - 1), ("recv", prev_blk, self.rank - 1)]
         if self.rank < self.world - 1:
             last = torch.empty_like(next_blk)
             for b in range(B):
                 copy_rows(last[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
             _count("p2p(TemporalConv halo)", last)
-            ops_ += [dist.P2POp(dist.isend, last, self._ranks[self.rank + 1], self.group), dist.P2POp(dist.irecv, next_blk, self._ranks[self.rank + 1], self.group)]
-        if ops_:
-            for r in dist.batch_isend_irecv(ops_):
-                r.wait()
+            ops_ += [("send", last, self.rank + 1), ("recv", next_blk, self.rank + 1)]
+        self.x.finish(self.x.p2p_start(ops_))      # nothing independent sits between this layer's producer and its consumer: joined at once
         return (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)
 
 
@@ -197,18 +279,16 @@ class PrevFrameHalo:
             for b in range(B):
                 copy_rows(last[b * npix:(b + 1) * npix], kv[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
             _count("p2p(attn1 K|V halo)", last)
-            ops_.append(dist.P2POp(dist.isend, last, s._ranks[self.rank + 1], s.group))
+            ops_.append(("send", last, self.rank + 1))
         if self.rank > 0:
-            ops_.append(dist.P2POp(dist.irecv, ext[:B * npix], s._ranks[self.rank - 1], s.group))
+            ops_.append(("recv", ext[:B * npix], self.rank - 1))
         else:
             copy_rows(ext[:B * npix], kv[:B * npix])      # never addressed (frame 0 has no predecessor); keep it finite
-        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
-        return (reqs, ext, keep)
+        return (s.x.p2p_start(ops_), ext, keep)
 
     def finish_kv(self, handle) -> torch.Tensor:
         reqs, ext, _keep = handle
-        for r in reqs:
-            r.wait()
+        self.s.x.finish(reqs)
         return ext
 
     def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:
@@ -276,27 +356,25 @@ class ChunkHalo:
                 frame_rows(buf[i * hb:(i + 1) * hb], g - self.frame0)
             keep.append(buf)
             _count("p2p(adapter K|V halo)", buf)
-            ops_.append(dist.P2POp(dist.isend, buf, s._ranks[r], s.group))
+            ops_.append(("send", buf, r))
         of = self.first // fl if self.first is not None else None
         op = self.prev // fl if self.prev is not None else None
         if of is not None and of == op:      # both frames from the same rank: one message [first | prev]
-            ops_.append(dist.P2POp(dist.irecv, ext[:2 * hb], s._ranks[of], s.group))
+            ops_.append(("recv", ext[:2 * hb], of))
         else:
             if of is not None:
-                ops_.append(dist.P2POp(dist.irecv, ext[:hb], s._ranks[of], s.group))
+                ops_.append(("recv", ext[:hb], of))
             if op is not None:
-                ops_.append(dist.P2POp(dist.irecv, ext[hb:2 * hb], s._ranks[op], s.group))
+                ops_.append(("recv", ext[hb:2 * hb], op))
         if of is None:
             copy_rows(ext[:hb], kv[:hb])          # never addressed; keep it finite
         if op is None:
             copy_rows(ext[hb:2 * hb], kv[:hb])
-        reqs = dist.batch_isend_irecv(ops_) if ops_ else []
-        return (reqs, ext, keep)
+        return (s.x.p2p_start(ops_), ext, keep)
 
     def finish_kv(self, handle) -> torch.Tensor:
         reqs, ext, _keep = handle
-        for r in reqs:
-            r.wait()
+        self.s.x.finish(reqs)
         return ext
 
     def complete_kv(self, ext: torch.Tensor, B: int, npix: int, copy_rows) -> torch.Tensor:

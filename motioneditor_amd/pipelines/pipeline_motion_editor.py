@@ -191,9 +191,10 @@ class MotionEditorPipeline:
             x = torch.cat([latents] * 2)
             emb = text_embeddings_input
         else:
-            import torch.distributed as dist
-            assert dist.get_world_size(cfg_group) == 2, "CFG parallelism is a 2-way split"
-            r = dist.get_rank(cfg_group)
+            from .. import parallel
+            cx = parallel.exchange(cfg_group)             # a torch process group, or an exchange adapter (direct RCCL for graph capture)
+            assert cx.world == 2, "CFG parallelism is a 2-way split"
+            r = cx.rank
             x = latents                                   # both CFG halves see the same [recon, edit] latents (:605)
             emb = text_embeddings_input[2 * r:2 * r + 2]
         down = mid = None
@@ -207,12 +208,10 @@ class MotionEditorPipeline:
             two = True
         eps = self.unet.forward_rows(x, t, emb, down, mid, two, shard=shard).t
         if cfg_group is not None:
-            import torch.distributed as dist
-            from .. import parallel
-            both = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
+            both = torch.empty((2 * eps.shape[0], eps.shape[1]), dtype=eps.dtype, device=eps.device)
             parallel._count("all_gather(noise prediction, CFG pair)", eps)
-            dist.all_gather(list(both.unbind(0)), eps.contiguous(), group=cfg_group)   # rows: [uncond (rec, edit) | cond (rec, edit)]
-            eps = both.reshape(-1, eps.shape[1])
+            cx.all_gather_into(both, eps.contiguous())   # rows: [uncond (rec, edit) | cond (rec, edit)]
+            eps = both
         ca, cb = self.scheduler.coeffs(int(t))
         return ops.cfg_ddim(latents, eps, guidance=guidance_scale, ca=ca, cb=cb)
 
@@ -224,9 +223,10 @@ class MotionEditorPipeline:
         UNet / adapter / editors (GroupNorm statistics, K/V injection and the adapter all stay inside a pair), so the only
         exchange is ONE all-gather of the 4-channel noise prediction (RCCL over xGMI on MI355X; 2 x [2,4,f,h,w] fp16) before
         the fused CFG + DDIM update, which every rank then applies to its own copy of the latents."""
-        import torch.distributed as dist
-        r = dist.get_rank(group)
-        assert dist.get_world_size(group) == 2, "CFG parallelism is a 2-way split"
+        from .. import parallel
+        cx = parallel.exchange(group)                      # a torch process group, or an exchange adapter (direct RCCL for graph capture)
+        r = cx.rank
+        assert cx.world == 2, "CFG parallelism is a 2-way split"
         f = latents.shape[2]
         x2 = latents                                                       # both CFG halves see the same [recon, edit] latents (:605)
         emb = text_embeddings_input[2 * r:2 * r + 2]
@@ -238,12 +238,11 @@ class MotionEditorPipeline:
             down, mid = self.controlnet.forward_rows(x2, [1], t, prompt, images[r * nimg:(r + 1) * nimg], controlnet_conditioning_scale, row_offset=r * f)
             two = True
         eps = self.unet.forward_rows(x2, t, emb, down, mid, two).t       # [(2 f N), 4]
-        both = torch.empty((2,) + tuple(eps.shape), dtype=eps.dtype, device=eps.device)
-        from .. import parallel
+        both = torch.empty((2 * eps.shape[0], eps.shape[1]), dtype=eps.dtype, device=eps.device)
         parallel._count("all_gather(noise prediction, CFG pair)", eps)
-        dist.all_gather(list(both.unbind(0)), eps.contiguous(), group=group)   # rows: [uncond (rec, edit) | cond (rec, edit)]
+        cx.all_gather_into(both, eps.contiguous())   # rows: [uncond (rec, edit) | cond (rec, edit)]
         ca, cb = self.scheduler.coeffs(int(t))
-        return ops.cfg_ddim(latents, both.reshape(-1, eps.shape[1]), guidance=guidance_scale, ca=ca, cb=cb)
+        return ops.cfg_ddim(latents, both, guidance=guidance_scale, ca=ca, cb=cb)
 
     @torch.no_grad()
     def denoise_step(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],

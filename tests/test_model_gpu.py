@@ -471,8 +471,8 @@ def test_properties_at_larger_size(unet):
 def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
     """World-size-1 RCCL process group: exercises the frame-sharded code path (K|V exchange buffers, sharded tconv / temporal
     attention arguments, GroupNorm split with its all-reduce) through the real kernels; must equal the ordinary step to the noise floor.
-    Then the same sharded step CAPTURED into a hipGraph (RCCL calls as graph nodes, denoise_step_graphed(shard=...)) and replayed over
-    two steps with different timesteps / embeddings: bitwise equal to the eager sharded steps.
+    Then the same sharded step with its exchanges issued by RCCL directly, eager (== the process-group run, bitwise) and CAPTURED into a
+    hipGraph (denoise_step_graphed(shard=...), RCCL calls as graph nodes) replayed over two steps: bitwise equal to the eager sharded steps.
     Multi-rank correctness of the exchanges is covered by tests/test_frame_shard_cpu.py (gloo, world 2-8)."""
     import torch.distributed as dist
     from motioneditor_amd import parallel
@@ -499,7 +499,14 @@ def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
         e = rel_l2(got, want)
         record("frame_shard_world1", e)
         assert e < 3e-3, e
-        # captured sharded step == eager sharded step, bit for bit, over two consecutive steps (editors active in both)
+        # The same exchanges issued by RCCL directly (motioneditor_amd/rccl.py; no process-group watchdog, so capturable): eager must equal the
+        # process-group run bit for bit, and the step CAPTURED into a hipGraph (RCCL calls as graph nodes) must equal the eager steps bit for
+        # bit over two consecutive steps with different timesteps / embeddings (editors active in both).
+        shard_r = parallel.FrameShard(f, comm="rccl")
+        sed.reset(); ted.reset()
+        sed.cur_step = ted.cur_step = 4
+        got_r = pipe.denoise_step_frame_sharded(x["latents"].cuda(), t, emb, images, 7.5, shard_r)
+        assert torch.equal(got_r, got), rel_l2(got_r, got)
         outs = {}
         for mode in ("eager", "graph"):
             sed.reset(); ted.reset()
@@ -509,9 +516,9 @@ def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
                 emb_i = torch.cat([(x["uncond"] * (1.0 + 0.1 * i)).expand(2, 77, 768), x["cond"]]).cuda()
                 ti = pipe.scheduler.timesteps[i]
                 if mode == "eager":
-                    lat = pipe.denoise_step_frame_sharded(lat, ti, emb_i, images, 7.5, shard)
+                    lat = pipe.denoise_step_frame_sharded(lat, ti, emb_i, images, 7.5, shard_r)
                 else:
-                    lat = pipe.denoise_step_graphed(lat, ti, emb_i, images, 7.5, shard=shard)
+                    lat = pipe.denoise_step_graphed(lat, ti, emb_i, images, 7.5, shard=shard_r)
             outs[mode] = lat.clone()
             assert sed.cur_step == ted.cur_step == 6
         eg = rel_l2(outs["graph"], outs["eager"])
