@@ -81,8 +81,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
 }
 
 // stats[sg][g] = (sum, sum of squares) in fp64 from the chunks' shifted partial sums: chunk mean = K + S1 / n, chunk
-// M2 = S2 - S1^2 / n, merged with Chan's update of (n, mean, M2) in a FIXED tree: slice s of the block merges chunks
-// s, s + S, s + 2S, ... in order, then slice 0 merges the S slice results in order (bitwise reproducible).
+// M2 = S2 - S1^2 / n, merged with Chan's update of (n, mean, M2) in a FIXED tree (bitwise reproducible).
 struct Moments { double n, mean, M2; };
 __device__ __forceinline__ void merge(Moments& a, double nb, double mb, double M2b) {
   const double delta = mb - a.mean, nt = a.n + nb;
@@ -92,24 +91,34 @@ __device__ __forceinline__ void merge(Moments& a, double nb, double mb, double M
 }
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float4* __restrict__ part, double* __restrict__ stats, int chunks, int chunk_rows,
                                                           int rows_per_group, int nsg, int groups, int cg) {
+  // one block per (sample-group, channel group): thread t folds chunks t, t + 256, ... in index order, then a fixed binary tree over the 256
+  // threads (the serial walk of the first version -- 8 slices x chunks / 8 dependent fp64 updates with two divisions each -- took 10 us per
+  // launch, 88 launches per step)
   __shared__ Moments sm[256];
-  const int sg = blockIdx.x, g = threadIdx.x % groups, slice = threadIdx.x / groups, S = 256 / groups;
+  const int sg = blockIdx.x / groups, g = blockIdx.x - sg * groups, t = threadIdx.x;
   Moments m{0.0, 0.0, 0.0};
-  if (slice < S) {
-    for (int c = slice; c < chunks; c += S) {
-      const float4 p = part[((long)c * nsg + sg) * groups + g];
-      const int rows_c = min((c + 1) * chunk_rows, rows_per_group) - c * chunk_rows;
-      const double nb = (double)rows_c * (double)cg;
-      merge(m, nb, (double)p.z + (double)p.x / nb, fmax((double)p.y - (double)p.x * (double)p.x / nb, 0.0));
-    }
+  for (int c = t; c < chunks; c += 256) {
+    const float4 p = part[((long)c * nsg + sg) * groups + g];
+    const int rows_c = min((c + 1) * chunk_rows, rows_per_group) - c * chunk_rows;
+    const double nb = (double)rows_c * (double)cg;
+    const double mb = (double)p.z + (double)p.x / nb, M2b = fmax((double)p.y - (double)p.x * (double)p.x / nb, 0.0);
+    if (m.n == 0.0) m = Moments{nb, mb, M2b};
+    else merge(m, nb, mb, M2b);
   }
-  sm[threadIdx.x] = m;
+  sm[t] = m;
   __syncthreads();
-  if (slice == 0) {
-    for (int s2 = 1; s2 < S; ++s2) {
-      const Moments o = sm[s2 * groups + g];
-      if (o.n > 0.0) merge(m, o.n, o.mean, o.M2);
+  for (int off = 128; off > 0; off >>= 1) {
+    if (t < off) {
+      const Moments o = sm[t + off];
+      if (o.n > 0.0) {
+        if (m.n == 0.0) m = o;
+        else merge(m, o.n, o.mean, o.M2);
+      }
+      sm[t] = m;
     }
+    __syncthreads();
+  }
+  if (t == 0) {
     stats[((long)sg * groups + g) * 2 + 0] = m.n * m.mean;
     stats[((long)sg * groups + g) * 2 + 1] = m.M2 + m.n * m.mean * m.mean;
   }
@@ -374,7 +383,7 @@ extern "C" int me_groupnorm_stats(const me_groupnorm_args* a, void* stream) {
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   hipLaunchKernelGGL(gn_stats_kernel, dim3(chunks, nsg), dim3(256), lds, st, reinterpret_cast<const f16*>(a->X), part, a->rows_per_group,
                      chunk_rows, a->C, a->ldx, a->groups);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg), dim3(256), 0, st, part, stats, chunks, chunk_rows, a->rows_per_group, nsg, a->groups, a->C / a->groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(nsg * a->groups), dim3(256), 0, st, part, stats, chunks, chunk_rows, a->rows_per_group, nsg, a->groups, a->C / a->groups);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_groupnorm_stats: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }

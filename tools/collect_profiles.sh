@@ -7,7 +7,7 @@ cd $R
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/parity.jsonl
-timeout 1500 python -m pytest tests -m gpu -q -x -p no:cacheprovider > gpurun_out/${tag}_pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/${tag}_pytest_gpu.log 2>&1
 echo "pytest exit $?" > gpurun_out/${tag}_summary.txt
 cp gpurun_out/parity.jsonl gpurun_out/${tag}_parity.jsonl 2>/dev/null
 timeout 900 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/${tag}_smoke.log 2>&1
@@ -22,8 +22,18 @@ python tools/rocpd_summary.py $(find gpurun_out/${tag}_prof -name "*.db" | head 
 ( cd /tmp && timeout 1200 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${tag}_pmc_f -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap > $R/gpurun_out/${tag}_pmc_f.log 2>&1 )
 ( cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap > $R/gpurun_out/${tag}_pmc_w.log 2>&1 )
 python tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*.db" | head -1) $(find gpurun_out/${tag}_pmc_w -name "*.db" | head -1) gpurun_out/${tag}_pmc_hbm.csv gpurun_out/${tag}_pmc_traffic.json 3 >> gpurun_out/${tag}_summary.txt 2>&1
-timeout 600 python tools/kbench.py gemm attn misc > gpurun_out/${tag}_kbench.txt 2>&1
-timeout 300 tools/_bin/ubench > gpurun_out/${tag}_ubench.txt 2>&1
-timeout 600 bash tools/exp_pmc_attn.sh 0 > /dev/null 2>&1; cp gpurun_out/r2c/pmc_attn.txt gpurun_out/${tag}_attn_dh40_sq_counters.txt 2>/dev/null
+timeout 600 python tools/kbench.py gemm attn misc bwd > gpurun_out/${tag}_kbench.txt 2>&1
+# secondary measurements: null-text inner iteration, other shapes, the frame-sharded path on one rank (eager / captured)
+timeout 400 python bench.py --null-text --steps 3 --warmup 1 > gpurun_out/${tag}_nulltext.log 2>&1; tail -1 gpurun_out/${tag}_nulltext.log > gpurun_out/${tag}_bench_nulltext.json
+timeout 300 python bench.py --frames 8 --latent 32 --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_8f_256.json
+timeout 600 python bench.py --frames 48 --latent 96 --steps 2 --warmup 1 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_48f_768.json
+timeout 300 python bench.py --parallel frames --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_frames1_graph.json
+timeout 300 python bench.py --parallel frames --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_frames1_eager.json
+timeout 300 python bench.py --no-overlap --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_no_overlap.json
+timeout 300 python bench.py --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_graph.json
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_nt -o r -- python $R/bench.py --null-text --steps 1 --warmup 1 > $R/gpurun_out/${tag}_rocprof_nt.log 2>&1 )
+python tools/rocpd_summary.py $(find gpurun_out/${tag}_prof_nt -name "*.db" | head -1) gpurun_out/${tag}_nulltext_kernel_stats.csv 1 >> gpurun_out/${tag}_summary.txt 2>&1
+rm -rf gpurun_out/${tag}_prof_nt
+# (instruction-rate micro-benchmarks and the attention kernel's SQ counters: tools/ubench.hip, tools/exp_pmc_attn.sh -- unchanged since round 2, profiles/r02_*)
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w
 cat gpurun_out/${tag}_summary.txt; tail -c 600 gpurun_out/${tag}_bench_c3.json

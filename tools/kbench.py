@@ -188,6 +188,44 @@ def bench_misc():
         del x, y
 
 
+def bench_bwd():
+    """Backward kernels at the null-text / adapter-training geometry (batch 1, 24 frames x 512^2)."""
+    f = 24
+    print(f"{'backward':40s} {'ms':>8s} {'TF/s':>8s}")
+    for name, dh, N in [("attn_bwd L0 prev|cur", 40, 4096), ("attn_bwd L1 prev|cur", 80, 1024), ("attn_bwd L2 prev|cur", 160, 256)]:
+        C = 8 * dh
+        qkv = rnd(f * N, 3 * C)
+        si, sm = segments.prev_cur(1, f, dev)
+        lse = torch.empty((f * N, 8), dtype=torch.float32, device=dev)
+        out = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads=8, dh=dh, n_items=f, nq=N, nk=N, seg_item=si, seg_mode=sm, lse=lse)
+        dout = torch.randn(f * N, C, device=dev)
+        g = torch.zeros(f * N, 3 * C, device=dev)
+        fn = lambda: ops.attention_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], out, dout, dq=g[:, :C], dk=g[:, C:2 * C], dv=g[:, 2 * C:], lse=lse, heads=8, dh=dh,  # noqa: E731
+                                       n_items=f, nq=N, nk=N, seg_item=si, seg_mode=sm)
+        ms = timeit(fn)
+        units = segments.KEY_UNITS[si.data_ptr()]
+        print(f"{name:40s} {ms:8.3f} {10.0 * 8 * N * N * units * dh / ms / 1e9:8.1f}   (5 matrix products of the flash backward; 7 executed)")
+        ms_f = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], heads=8, dh=dh, n_items=f, nq=N, nk=N, seg_item=si, seg_mode=sm))
+        print(f"{'   forward of the same launch':40s} {ms_f:8.3f} {4.0 * 8 * N * N * units * dh / ms_f / 1e9:8.1f}")
+    for name, M, N, K in [("gemm_dw L0 qkv", f * 4096, 960, 320), ("gemm_dw L0 ff1", f * 4096, 2560, 320), ("gemm_dw L2 ff2", f * 256, 1280, 5120)]:
+        x, dy = rnd(M, K), torch.randn(M, N, device=dev)
+        dst = torch.zeros(N, 1, K, device=dev)
+        ms = timeit(lambda: ops.gemm_dw(dy, x, dst=dst, taps=1, K=K, M=M))
+        print(f"{name:40s} {ms:8.3f} {2.0 * M * N * K / ms / 1e9:8.1f}")
+    for C, hw in [(320, 64), (1280, 16)]:
+        M = f * hw * hw
+        x = rnd(M, 3 * C)
+        dout = torch.randn(M, C, device=dev)
+        ms = timeit(lambda: ops.temporal_attention_bwd(x[:, :C], x[:, C:2 * C], x[:, 2 * C:], None, dout, heads=8, dh=C // 8, batch=1, frames=f, npix=hw * hw))
+        print(f"{'tattn_bwd C=' + str(C):40s} {ms:8.3f}")
+        y, gm, bt = rnd(M, C), rnd(C), rnd(C)
+        dy = torch.randn(M, C, device=dev)
+        ms = timeit(lambda: ops.groupnorm_bwd(y, gm, bt, dy, rows_per_group=f * hw * hw, eps=1e-5, silu=True))
+        print(f"{'groupnorm_bwd C=' + str(C):40s} {ms:8.3f}")
+        ms = timeit(lambda: ops.layernorm_bwd(y, gm, dy))
+        print(f"{'layernorm_bwd C=' + str(C):40s} {ms:8.3f}")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "attn", "misc"]
     if "gemm" in what:
@@ -210,3 +248,5 @@ if __name__ == "__main__":
         bench_attn(True)
     if "misc" in what:
         bench_misc()
+    if "bwd" in what:
+        bench_bwd()
