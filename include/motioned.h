@@ -285,9 +285,11 @@ int me_geglu_bwd(void* dpre, int32_t ldd, const void* pre, int32_t ldp, const vo
 /* nn.LayerNorm: dx fp32 [rows, C] from x fp16, gamma fp16, dy fp32 */
 int me_layernorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* dy, int32_t lddy, int64_t rows, int32_t C, float eps,
                      void* stream);
-/* GroupNorm (+ SiLU when silu != 0; statistics over rows_per_group rows x C/groups channels, as me_groupnorm): dx fp32 */
+/* GroupNorm (+ SiLU when silu != 0; statistics over rows_per_group rows x C/groups channels, as me_groupnorm): dx fp32.  Row-parallel passes
+ * (statistics, per-chunk gradient sums in a fixed order, apply); scratch: me_groupnorm_bwd_scratch_bytes(rows, rows_per_group, groups) bytes, 16-byte aligned */
 int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* beta, const void* dy, int32_t lddy, int64_t rows,
-                     int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* stream);
+                     int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* scratch, void* stream);
+int64_t me_groupnorm_bwd_scratch_bytes(int32_t rows, int32_t rows_per_group, int32_t groups);
 
 /* Temporal causal attention (me_tattn, plain row order, identity kv_map): dq, dk, dv fp32 [batch*frames*npix, ld] from q, k, v fp16
  * and dout fp32; frames <= 64 */

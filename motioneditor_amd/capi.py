@@ -116,7 +116,8 @@ SYMBOLS = {
     "me_attn_vsum_bytes": (_i64, [_i32, _i32]),
     "me_geglu_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_layernorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i64, _i32, C.c_float, _vp]),
-    "me_groupnorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, C.c_float, _i32, _vp]),
+    "me_groupnorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp]),
+    "me_groupnorm_bwd_scratch_bytes": (_i64, [_i32, _i32, _i32]),
     "me_tattn_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp]),
     "me_softmax_bwd_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, C.c_float, _vp]),
     "me_relu_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp]),

@@ -125,34 +125,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const me_attn_bwd_arg
   const float c = a.scale * LOG2E;
   __syncthreads();
 
+  // Stages = (query item that lists this kv item) x (32-query tile).  The global loads of stage s + 1 are issued into registers BEFORE the
+  // MFMAs of stage s (the first version loaded, waited, staged and computed in sequence: every stage paid a full memory latency and the
+  // kernel ran 18x off its MFMA time).
+  constexpr int NCHK = (QB * CH + 255) / 256;
   const int p0 = a.inv_ptr[kit], p1 = a.inv_ptr[kit + 1];
-  for (int p = p0; p < p1; ++p) {
-    const int qi = a.inv_item[p];
-    for (int q0 = 0; q0 < a.nq; q0 += QB) {
-      // ---- stage 32 queries: Q and dO row-major and transposed (query slot order), lse, delta ----
-      for (int ci = tid; ci < QB * CH; ci += 256) {
-        const int q = ci / CH, cc = ci - q * CH;
-        const bool ok = q0 + q < a.nq;
-        const long row = (long)qi * a.nq + q0 + q;
-        U128 uq, ud;
-        uq.u = ok ? ldg128(Q + row * a.ldq + h * DH + cc * 8) : zero128();
-        ud.u = ok ? f32x8_to_f16(dO + row * a.lddo + h * DH + cc * 8) : zero128();
-        *reinterpret_cast<uint4*>(sQ + q * RLD + cc * 8) = uq.u;
-        *reinterpret_cast<uint4*>(sdO + q * RLD + cc * 8) = ud.u;
-        const int pos = ((q >> 2) & 3) * 8 + (q >> 4) * 4 + (q & 3);   // query i * 16 + g * 4 + r sits at slot g * 8 + i * 4 + r
+  const int nqt = (a.nq + QB - 1) / QB;
+  const int nstage = (p1 - p0) * nqt;
+  U128 rq[NCHK], rd[NCHK];
+  float rl = 0.f, rdl = 0.f;
+  auto fetch = [&](int sidx) {
+    const int qi = a.inv_item[p0 + sidx / nqt];
+    const int q0 = (sidx % nqt) * QB;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          sQt[(cc * 8 + e) * TLD + pos] = uq.e[e];
-          sdOt[(cc * 8 + e) * TLD + pos] = ud.e[e];
+    for (int n = 0; n < NCHK; ++n) {
+      const int ci = tid + 256 * n;
+      const int q = ci / CH, cc = ci - q * CH;
+      const bool ok = ci < QB * CH && q0 + q < a.nq;
+      const long row = (long)qi * a.nq + q0 + q;
+      rq[n].u = ok ? ldg128(Q + row * a.ldq + h * DH + cc * 8) : zero128();
+      rd[n].u = ok ? f32x8_to_f16(dO + row * a.lddo + h * DH + cc * 8) : zero128();
+    }
+    if (tid < QB) {
+      const bool ok = q0 + tid < a.nq;
+      const long row = (long)qi * a.nq + q0 + tid;
+      rl = ok ? lse[row * a.heads + h] : 1.0e30f;   // rows past nq: P = 2^(-huge) = 0
+      rdl = ok ? delta[row * a.heads + h] : 0.f;
+    }
+  };
+  if (nstage > 0) fetch(0);
+  for (int sidx = 0; sidx < nstage; ++sidx) {
+    {
+      // ---- stage 32 queries: Q and dO row-major and transposed (query slot order), lse, delta ----
+#pragma unroll
+      for (int n = 0; n < NCHK; ++n) {
+        const int ci = tid + 256 * n;
+        if (ci < QB * CH) {
+          const int q = ci / CH, cc = ci - q * CH;
+          *reinterpret_cast<uint4*>(sQ + q * RLD + cc * 8) = rq[n].u;
+          *reinterpret_cast<uint4*>(sdO + q * RLD + cc * 8) = rd[n].u;
+          const int pos = ((q >> 2) & 3) * 8 + (q >> 4) * 4 + (q & 3);   // query i * 16 + g * 4 + r sits at slot g * 8 + i * 4 + r
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            sQt[(cc * 8 + e) * TLD + pos] = rq[n].e[e];
+            sdOt[(cc * 8 + e) * TLD + pos] = rd[n].e[e];
+          }
         }
       }
       if (tid < QB) {
-        const bool ok = q0 + tid < a.nq;
-        const long row = (long)qi * a.nq + q0 + tid;
-        slse[tid] = ok ? lse[row * a.heads + h] : 1.0e30f;   // rows past nq: P = 2^(-huge) = 0
-        sdel[tid] = ok ? delta[row * a.heads + h] : 0.f;
+        slse[tid] = rl;
+        sdel[tid] = rdl;
       }
       __syncthreads();
+      if (sidx + 1 < nstage) fetch(sidx + 1);
 
       // ---- S[q, key] = Q K^T, dP[q, key] = dO V^T: lane (key = l15, g), reg r <-> query i * 16 + g * 4 + r ----
       f32x4 s[NKT][2], dp[NKT][2];
@@ -292,26 +317,49 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const me_attn_bwd_args
   for (int dt = 0; dt < DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
+  // Stages = (segment) x (KT-key tile); the loads of stage s + 1 are in flight during the MFMAs of stage s (see attn_bwd_dkv_kernel).
+  constexpr int NCHK = (KT * CH + 255) / 256;
+  int nvalid = 0;
   for (int sgi = 0; sgi < a.nseg; ++sgi) {
-    const int kit = a.seg_item[item * a.nseg + sgi];
-    if (kit < 0) break;
-    for (int kt0 = 0; kt0 < a.nk; kt0 += KT) {
-      // ---- stage 64 keys: K row-major and transposed (key slot order), V row-major ----
-      for (int ci = tid; ci < KT * CH; ci += 256) {
-        const int key = ci / CH, cc = ci - key * CH;
-        const bool ok = kt0 + key < a.nk;
-        const long row = (long)kit * a.nk + kt0 + key;
-        U128 uk, uv;
-        uk.u = ok ? ldg128(K + row * a.ldk + h * DH + cc * 8) : zero128();
-        uv.u = ok ? ldg128(V + row * a.ldv + h * DH + cc * 8) : zero128();
-        *reinterpret_cast<uint4*>(sK + key * RLD + cc * 8) = uk.u;
-        *reinterpret_cast<uint4*>(sV + key * RLD + cc * 8) = uv.u;
-        // key kk * 32 + i * 16 + g * 4 + r sits at slot kk * 32 + g * 8 + i * 4 + r
-        const int pos = (key & 32) | ((key & 12) << 1) | ((key & 16) >> 2) | (key & 3);
+    if (a.seg_item[item * a.nseg + sgi] < 0) break;
+    ++nvalid;
+  }
+  const int nkt = (a.nk + KT - 1) / KT;
+  const int nstage = nvalid * nkt;
+  U128 rk[NCHK], rv[NCHK];
+  auto fetch = [&](int sidx) {
+    const int kit = a.seg_item[item * a.nseg + sidx / nkt];
+    const int kt0 = (sidx % nkt) * KT;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sKt[(cc * 8 + e) * TLD + pos] = uk.e[e];
+    for (int n = 0; n < NCHK; ++n) {
+      const int ci = tid + 256 * n;
+      const int key = ci / CH, cc = ci - key * CH;
+      const bool ok = ci < KT * CH && kt0 + key < a.nk;
+      const long row = (long)kit * a.nk + kt0 + key;
+      rk[n].u = ok ? ldg128(K + row * a.ldk + h * DH + cc * 8) : zero128();
+      rv[n].u = ok ? ldg128(V + row * a.ldv + h * DH + cc * 8) : zero128();
+    }
+  };
+  if (nstage > 0) fetch(0);
+  for (int sidx = 0; sidx < nstage; ++sidx) {
+    {
+      const int kt0 = (sidx % nkt) * KT;
+      // ---- stage KT keys: K row-major and transposed (key slot order), V row-major ----
+#pragma unroll
+      for (int n = 0; n < NCHK; ++n) {
+        const int ci = tid + 256 * n;
+        if (ci < KT * CH) {
+          const int key = ci / CH, cc = ci - key * CH;
+          *reinterpret_cast<uint4*>(sK + key * RLD + cc * 8) = rk[n].u;
+          *reinterpret_cast<uint4*>(sV + key * RLD + cc * 8) = rv[n].u;
+          // key kk * 32 + i * 16 + g * 4 + r sits at slot kk * 32 + g * 8 + i * 4 + r
+          const int pos = (key & 32) | ((key & 12) << 1) | ((key & 16) >> 2) | (key & 3);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sKt[(cc * 8 + e) * TLD + pos] = rk[n].e[e];
+        }
       }
       __syncthreads();
+      if (sidx + 1 < nstage) fetch(sidx + 1);
 
       // ---- S^T[key, q] = K Q^T, dP^T[key, q] = V dO^T: lane (q = l15, g), reg r <-> key t * 16 + g * 4 + r ----
       f32x4 st[NT], dpt[NT];

@@ -62,67 +62,154 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restric
   }
 }
 
-// GroupNorm (+ SiLU): one block per (sample group, channel group); three sweeps over the group's rows_per_group x cg elements
-// (statistics; the two gradient sums; apply), fp64 block reductions.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-  const int tid = threadIdx.x;
-  red[tid] = v;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
+// GroupNorm (+ SiLU) backward in three row-parallel passes (the first version gave a whole (sample group, channel group) to ONE block: 32
+// blocks for a batch-1 clip, 3.0 ms per call, a third of a null-text iteration):
+//   statistics   me_groupnorm_stats, the forward's deterministic fp64 (sum, sum of squares)
+//   sums         per row chunk and channel group: A = sum g, B = sum g xhat with g = dy (SiLU') gamma   (gn_bwd_sums_kernel, fixed order)
+//   fold + apply dx = rstd (g - A / n - xhat B / n)                                                      (gn_bwd_fold_kernel, gn_bwd_apply_kernel)
+// Thread layout as in norm.hip: a thread owns one 16-byte channel vector and walks down the rows of its chunk.
+struct GnCoef { float mean[8], rstd[8], gm[8], bt[8]; };
+
+__device__ __forceinline__ void gn_coef(GnCoef& k, const double* __restrict__ stats, const f16* __restrict__ gamma, const f16* __restrict__ beta, int sg, int vc, int cg,
+                                        int groups, double inv_cnt, float eps) {
+  U128 g8, b8;
+  g8.u = ldg128(gamma + vc * 8);
+  b8.u = ldg128(beta + vc * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ge = (vc * 8 + e) / cg;
+    const double mean_d = stats[((long)sg * groups + ge) * 2 + 0] * inv_cnt;
+    const float var = fmaxf((float)(stats[((long)sg * groups + ge) * 2 + 1] * inv_cnt - mean_d * mean_d), 0.f);
+    k.mean[e] = (float)mean_d;
+    k.rstd[e] = rsqrtf(var + eps);
+    k.gm[e] = (float)g8.e[e];
+    k.bt[e] = (float)b8.e[e];
   }
-  const double r = red[0];
-  __syncthreads();
-  return r;
 }
 
-__global__ __launch_bounds__(256) void groupnorm_bwd_kernel(const f16* __restrict__ X, int ldx, const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                            const float* __restrict__ dY, int lddy, float* __restrict__ dX, int lddx, int rows_per_group, int C,
-                                                            int groups, float eps, int silu) {
-  __shared__ double red[256];
-  const int sg = blockIdx.x / groups, g = blockIdx.x % groups;
-  const int cg = C / groups, c0 = g * cg;
-  const long r0 = (long)sg * rows_per_group;
-  const long n = (long)rows_per_group * cg;
-  double s = 0.0, q = 0.0;
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const long r = i / cg;
-    const int c = (int)(i - r * cg);
-    const double v = (double)(float)X[(r0 + r) * ldx + c0 + c];
-    s += v;
-    q += v * v;
+// g = dL/d(xhat) of one element: dy * gamma, through the SiLU of y = xhat gamma + beta when the forward applied it
+__device__ __forceinline__ float gn_g(float dy, float xh, float gm, float bt, int silu) {
+  if (silu) {
+    const float y = __builtin_fmaf(xh, gm, bt);
+    const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * y));
+    dy *= sig * (1.0f + y * (1.0f - sig));
   }
-  const double S = block_sum(s, red), Q = block_sum(q, red);
-  const double mean_d = S / (double)n;
-  const float mean = (float)mean_d, rstd = rsqrtf(fmaxf((float)(Q / (double)n - mean_d * mean_d), 0.f) + eps);
-  auto grad_in = [&](long r, int c, float& xh) {   // dL/d(gamma xhat + beta) * gamma
-    xh = ((float)X[(r0 + r) * ldx + c0 + c] - mean) * rstd;
-    const float gm = (float)gamma[c0 + c];
-    float d = dY[(r0 + r) * lddy + c0 + c];
-    if (silu) {
-      const float y = xh * gm + (float)beta[c0 + c];
-      const float sig = 1.0f / (1.0f + __expf(-y));
-      d *= sig * (1.0f + y * (1.0f - sig));
+  return dy * gm;
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_sums_kernel(const f16* __restrict__ X, int ldx, const float* __restrict__ dY, int lddy, const f16* __restrict__ gamma,
+                                                          const f16* __restrict__ beta, const double* __restrict__ stats, float2* __restrict__ part, int rows_per_group,
+                                                          int chunk_rows, int C, int groups, float eps, int silu) {
+  extern __shared__ __attribute__((aligned(16))) float2 red[];   // [row lane][channel of the pass]
+  __shared__ float2 chan[2560];
+  const int tid = threadIdx.x;
+  const int sg = blockIdx.y;
+  const int r0 = blockIdx.x * chunk_rows, r1 = min(r0 + chunk_rows, rows_per_group);
+  const int tpr = C / 8, tprc = tpr < 256 ? tpr : 256;
+  const int rl = tid / tprc, vc0 = tid - rl * tprc, RL = 256 / tprc;
+  const int cg = C / groups;
+  const double inv_cnt = 1.0 / ((double)rows_per_group * (double)cg);
+  const long base_row = (long)sg * rows_per_group;
+  for (int pass0 = 0; pass0 < tpr; pass0 += tprc) {
+    const int vc = pass0 + vc0;
+    if (rl < RL && vc < tpr) {
+      GnCoef k;
+      gn_coef(k, stats, gamma, beta, sg, vc, cg, groups, inv_cnt, eps);
+      float sa[8], sb[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+#pragma unroll 2
+      for (int r = r0 + rl; r < r1; r += RL) {
+        U128 u;
+        u.u = ldg128(X + (base_row + r) * ldx + vc * 8);
+        const float* dp = dY + (base_row + r) * lddy + vc * 8;
+        const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = ((float)u.e[e] - k.mean[e]) * k.rstd[e];
+          const float g = gn_g(dv[e], xh, k.gm[e], k.bt[e], silu);
+          sa[e] += g;
+          sb[e] += g * xh;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rl * (tprc * 8) + vc0 * 8 + e] = make_float2(sa[e], sb[e]);
     }
-    return d * gm;
-  };
-  double a = 0.0, b = 0.0;
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const long r = i / cg;
-    const int c = (int)(i - r * cg);
-    float xh;
-    const float gi = grad_in(r, c, xh);
-    a += gi;
-    b += (double)gi * xh;
+    __syncthreads();
+    for (int cidx = tid; cidx < tprc * 8 && pass0 * 8 + cidx < C; cidx += 256) {   // fixed order over the row lanes
+      float2 a = red[cidx];
+      for (int l = 1; l < RL; ++l) {
+        const float2 b = red[l * (tprc * 8) + cidx];
+        a.x += b.x;
+        a.y += b.y;
+      }
+      chan[pass0 * 8 + cidx] = a;
+    }
+    __syncthreads();
   }
-  const float ma = (float)(block_sum(a, red) / (double)n), mb = (float)(block_sum(b, red) / (double)n);
-  for (long i = threadIdx.x; i < n; i += 256) {
-    const long r = i / cg;
-    const int c = (int)(i - r * cg);
-    float xh;
-    const float gi = grad_in(r, c, xh);
-    dX[(r0 + r) * lddx + c0 + c] = rstd * (gi - ma - xh * mb);
+  if (tid < groups) {                                                               // fixed order over the group's channels
+    float2 a = chan[tid * cg];
+    for (int cc = 1; cc < cg; ++cc) {
+      const float2 b = chan[tid * cg + cc];
+      a.x += b.x;
+      a.y += b.y;
+    }
+    part[((long)blockIdx.x * gridDim.y + sg) * groups + tid] = a;
+  }
+}
+
+// sums[sg][g] = (A / n, B / n), chunks added in index order in fp64
+__global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const float2* __restrict__ part, float2* __restrict__ sums, int chunks, int nsg, int groups, double inv_cnt) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;   // (sg, g)
+  if (idx >= nsg * groups) return;
+  double a = 0.0, b = 0.0;
+  for (int c = 0; c < chunks; ++c) {
+    const float2 p = part[(long)c * nsg * groups + idx];
+    a += (double)p.x;
+    b += (double)p.y;
+  }
+  sums[idx] = make_float2((float)(a * inv_cnt), (float)(b * inv_cnt));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const f16* __restrict__ X, int ldx, const float* __restrict__ dY, int lddy, float* __restrict__ dX, int lddx,
+                                                           const f16* __restrict__ gamma, const f16* __restrict__ beta, const double* __restrict__ stats,
+                                                           const float2* __restrict__ sums, long rows, int rows_per_group, int C, int groups, float eps, int silu, int chunk) {
+  const int vc = blockIdx.y * blockDim.x + threadIdx.x;   // 16-byte vector column
+  const int cg = C / groups;
+  const double inv_cnt = 1.0 / ((double)rows_per_group * (double)cg);
+  const long r0 = (long)blockIdx.x * chunk;
+  const long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  long row = r0 + threadIdx.y;
+  while (row < r1) {
+    const int sg = (int)(row / rows_per_group);
+    const long seg_end = (long)(sg + 1) * rows_per_group < r1 ? (long)(sg + 1) * rows_per_group : r1;
+    GnCoef k;
+    gn_coef(k, stats, gamma, beta, sg, vc, cg, groups, inv_cnt, eps);
+    float ma[8], mb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 sm = sums[(long)sg * groups + (vc * 8 + e) / cg];
+      ma[e] = sm.x;
+      mb[e] = sm.y;
+    }
+    for (; row < seg_end; row += blockDim.y) {
+      U128 u;
+      u.u = ldg128(X + row * ldx + vc * 8);
+      const float* dp = dY + row * lddy + vc * 8;
+      const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
+      const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = ((float)u.e[e] - k.mean[e]) * k.rstd[e];
+        const float g = gn_g(dv[e], xh, k.gm[e], k.bt[e], silu);
+        o[e] = k.rstd[e] * (g - ma[e] - xh * mb[e]);
+      }
+      float* op = dX + row * lddx + vc * 8;
+      *reinterpret_cast<float4*>(op) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
   }
 }
 
@@ -272,16 +359,74 @@ extern "C" int me_layernorm_bwd(void* dx, int32_t lddx, const void* x, int32_t l
   ME_BWD_LAUNCH_CHECK("me_layernorm_bwd")
 }
 
+// chunk geometry of the row-parallel passes (same rule as norm.hip's statistics pass: ~1024 blocks in total)
+static void gn_bwd_chunks(int64_t rows, int rows_per_group, int* chunks_out, int* chunk_rows_out) {
+  const int nsg = (int)(rows / rows_per_group);
+  int chunks = 1024 / nsg;
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  int chunk_rows = (rows_per_group + chunks - 1) / chunks;
+  if (chunk_rows < 8) chunk_rows = 8;
+  *chunks_out = (rows_per_group + chunk_rows - 1) / chunk_rows;
+  *chunk_rows_out = chunk_rows;
+}
+
+extern "C" int64_t me_groupnorm_bwd_scratch_bytes(int32_t rows, int32_t rows_per_group, int32_t groups) {
+  if (rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || groups <= 0) return 0;
+  int chunks, chunk_rows;
+  gn_bwd_chunks(rows, rows_per_group, &chunks, &chunk_rows);
+  const int64_t nsg = rows / rows_per_group;
+  const int64_t fwd = (me_groupnorm_scratch_bytes(rows, rows_per_group, groups) + 15) / 16 * 16;
+  return fwd + ((int64_t)chunks + 1) * nsg * groups * (int64_t)sizeof(float2);
+}
+
 extern "C" int me_groupnorm_bwd(void* dx, int32_t lddx, const void* x, int32_t ldx, const void* gamma, const void* beta, const void* dy, int32_t lddy, int64_t rows,
-                                int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* stream) {
-  if (!dx || !x || !gamma || !beta || !dy || rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || groups <= 0 || C % groups) {
-    me_set_error("me_groupnorm_bwd: bad arguments");
+                                int32_t rows_per_group, int32_t C, int32_t groups, float eps, int32_t silu, void* scratch, void* stream) {
+  if (!dx || !x || !gamma || !beta || !dy || !scratch || rows <= 0 || rows_per_group <= 0 || rows % rows_per_group || groups <= 0 || groups > 64 || C % groups || C % 8 ||
+      C > 2560 || ldx % 8 || lddx % 4 || lddy % 4 || (((uintptr_t)dx | (uintptr_t)x | (uintptr_t)dy | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)scratch) & 15)) {
+    me_set_error("me_groupnorm_bwd: bad arguments (C % 8 == 0, C <= 2560, aligned pointers, strides multiples of 8 / 4)");
     return ME_EINVAL;
   }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int nsg = (int)(rows / rows_per_group);
+  // statistics: the forward's deterministic pass
+  me_groupnorm_args fa{};
+  fa.X = x;
+  fa.Y = const_cast<void*>(x);   // not written by the statistics pass
+  fa.gamma = gamma;
+  fa.beta = beta;
+  fa.stats = scratch;
+  fa.rows = (int32_t)rows;
+  fa.rows_per_group = rows_per_group;
+  fa.C = C;
+  fa.ldx = ldx;
+  fa.ldy = ldx;
+  fa.groups = groups;
+  fa.eps = eps;
+  if (int rc = me_groupnorm_stats(&fa, stream)) return rc;
+  const double* stats = reinterpret_cast<const double*>(scratch);
+  const int64_t fwd = (me_groupnorm_scratch_bytes((int32_t)rows, rows_per_group, groups) + 15) / 16 * 16;
+  float2* part = reinterpret_cast<float2*>(reinterpret_cast<char*>(scratch) + fwd);
+  int chunks, chunk_rows;
+  gn_bwd_chunks(rows, rows_per_group, &chunks, &chunk_rows);
+  float2* sums = part + (size_t)chunks * nsg * groups;
+  const int tpr = C / 8, tprc = tpr < 256 ? tpr : 256;
+  const size_t lds = (size_t)(256 / tprc) * tprc * 8 * sizeof(float2);
   (void)hipGetLastError();
-  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3((unsigned)((rows / rows_per_group) * groups)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(beta), reinterpret_cast<const float*>(dy), lddy,
-                     reinterpret_cast<float*>(dx), lddx, rows_per_group, C, groups, eps, silu);
+  hipLaunchKernelGGL(gn_bwd_sums_kernel, dim3(chunks, nsg), dim3(256), lds, st, reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const float*>(dy), lddy,
+                     reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(beta), stats, part, rows_per_group, chunk_rows, C, groups, eps, silu);
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3((nsg * groups + 255) / 256), dim3(256), 0, st, part, sums, chunks, nsg, groups,
+                     1.0 / ((double)rows_per_group * (double)(C / groups)));
+  int ny = 1;
+  while (tpr / ny > 256 || tpr % ny) ++ny;
+  const int bx = tpr / ny, by = 256 / bx > 0 ? 256 / bx : 1;
+  long chunk = (long)by * 16;
+  while (chunk > by && (rows + chunk - 1) / chunk * ny < 2048) chunk /= 2;
+  if (chunk < by) chunk = by;
+  const long nbx = (rows + chunk - 1) / chunk;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nbx, (unsigned)ny), dim3(bx, by), 0, st, reinterpret_cast<const f16*>(x), ldx, reinterpret_cast<const float*>(dy), lddy,
+                     reinterpret_cast<float*>(dx), lddx, reinterpret_cast<const f16*>(gamma), reinterpret_cast<const f16*>(beta), stats, sums, (long)rows, rows_per_group, C, groups,
+                     eps, silu, (int)chunk);
   ME_BWD_LAUNCH_CHECK("me_groupnorm_bwd")
 }
 

@@ -566,8 +566,9 @@ def groupnorm_bwd(x, gamma, beta, dy, *, rows_per_group, eps, silu, groups=32):
     _chk2d(x, "groupnorm_bwd.x")
     _chk_grad(dy, "groupnorm_bwd.dy")
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    scratch = _work(capi.lib().me_groupnorm_bwd_scratch_bytes(x.shape[0], rows_per_group, groups), x.device, "gnbwd")
     capi.check(capi.lib().me_groupnorm_bwd(dx.data_ptr(), dx.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), dy.data_ptr(), dy.stride(0),
-                                           x.shape[0], rows_per_group, x.shape[1], groups, eps, 1 if silu else 0, _stream()), "me_groupnorm_bwd")
+                                           x.shape[0], rows_per_group, x.shape[1], groups, eps, 1 if silu else 0, scratch.data_ptr(), _stream()), "me_groupnorm_bwd")
     return dx
 
 
