@@ -741,6 +741,260 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a
   epilogue<NT, MT, WN>(a, acc, rowfn, 0, n0, wn, lane, nullptr, 0);
 }
 
+// ---- 8-phase ping-pong gather-GEMM: 256 x BN x 64 tiles, waves 2 (M) x 4 (N), two wave groups half a phase apart ----
+// The one-barrier-per-slab loop of gemm_kernel keeps the two waves of a SIMD in lockstep: both read fragments, both run their
+// MFMAs, both wait for the slab's DMA at the barrier (vmcnt(0)).  Here the K tile is cut into four phases -- the quadrants
+// (A0,B0) (A0,B1) (A1,B1) (A1,B0) of the wave's 128 x WN output, A0/A1 = its two 64-row halves, B0/B1 = its first NT0 / last NT1
+// column tiles -- and every phase is  { read the quadrant's new fragments; issue ONE part of a later K tile's DMA }  barrier
+// { MFMAs }  barrier.  Waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so on each SIMD one wave's
+// MFMA cluster runs beside the other's LDS reads and DMA issue (s_setprio favours the cluster).  DMAs are never drained inside
+// the loop: ONE counted s_waitcnt vmcnt(2 + NT1) per K tile (in phase 3) leaves the two youngest parts in flight across barriers.
+//
+// Parts of K tile t live in LDS buffer t & 1 and are issued, in program order,
+//     phase 0 of tile t: A1(t+1)    phase 1: B0(t+1)    phase 2: A0(t+2)    phase 3: B1(t+2), then vmcnt(2 + NT1)
+// Read-after-DMA: a part is read at least one full phase (two barriers) after the counted wait that covers it -- the wait of
+// phase 3 of tile t retires everything up to B0(t+1); A0(t+1) / B0(t+1) are first read in phase 0 of t+1, B1(t+1) in phase 1,
+// A1(t+1) in phase 2 -- so the other wave group (half a phase behind with its own waits) has waited too.
+// DMA-after-read: a part's slot is re-issued two phases after its last read (A0: read phase 0, issued phase 2; B1: 1 -> 3;
+// A1: 2 -> 0; B0: 3 -> 1).  Tiles past the end are issued as out-of-range offsets (zero fill, no memory traffic) so that the
+// counts stay uniform; everything is drained before the epilogue.
+template <int BN, bool GATHER>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
+  constexpr int BM = 256, WN = BN / 4, NT = WN / 16, MT = 8, NT0 = (NT + 1) / 2, NT1 = NT / 2;
+  constexpr int ABYTES = BM * 128, BUFBYTES = (BM + BN) * 128;
+  static_assert(BN % 64 == 0 && NT1 >= 1, "wave tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 256 rows | B BN rows][128 B], then (GATHER) the source-row table [taps][256]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nbn = (a.N + BN - 1) / BN;
+  const int nbm = (a.M + BM - 1) / BM;
+  const int w = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tile_n = w % nbn, tile_m = w / nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
+  const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
+  const int taps = !GATHER ? 1 : (a.gather == ME_GATHER_CONV3 ? 9 : (a.gather == ME_GATHER_TCONV ? 3 : 1));
+  const int nkc = a.K / BK;
+  const int nit = taps * nkc;
+
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr unsigned OOB = 0x80000000u;
+  long brow = m0;
+  if (GATHER) {
+    if (a.gather == ME_GATHER_CONV3) brow = (long)(m0 / (a.Hout * a.Wout)) * a.Hin * a.Win;
+    else if (a.gather == ME_GATHER_TCONV) brow = m0 > a.npix ? m0 - a.npix : 0;
+  }
+  const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(X + brow * a.ldx), 0, OOB, 0x00020000);
+  const int wrows = min(a.N - n0, BN);
+  const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W + (long)n0 * taps * a.K), 0, (unsigned)((long)wrows * taps * a.K * 2), 0x00020000);
+
+  // DMA lane mapping as in gemm_kernel: one wave instruction = 8 LDS rows x 128 B, lane -> row + lane / 8, 16-byte slot lane % 8
+  // holding source chunk (lane % 8) ^ ((row >> 1) & 7); every piece of this wave starts on a row whose bit 3 is wave & 1
+  const int prow = lane >> 3;
+  const int scol = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 8;
+  // first LDS row of this wave's piece i of a part (wave-uniform; the DMA's LDS address travels in M0)
+  int rA[2][2], rB0[NT0], rB1[NT1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    rA[0][i] = __builtin_amdgcn_readfirstlane(i * 128 + 8 * wave);        // A0 / A1: 16 pieces each, 2 per wave
+    rA[1][i] = __builtin_amdgcn_readfirstlane(i * 128 + 64 + 8 * wave);
+  }
+#pragma unroll
+  for (int i = 0; i < NT0; ++i) {   // B0: 8 NT0 pieces
+    const int p = wave + 8 * i;
+    rB0[i] = __builtin_amdgcn_readfirstlane((p / (2 * NT0)) * WN + 8 * (p % (2 * NT0)));
+  }
+#pragma unroll
+  for (int i = 0; i < NT1; ++i) {   // B1: 8 NT1 pieces
+    const int p = wave + 8 * i;
+    rB1[i] = __builtin_amdgcn_readfirstlane((p / (2 * NT1)) * WN + 16 * NT0 + 8 * (p % (2 * NT1)));
+  }
+
+  // A-operand source offsets.  Dense: one byte offset per staged row, fixed.  Gathers: the offsets change with the tap, and a branch
+  // that recomputes them inside the K loop makes hipcc drain the DMA queue (vmcnt(0)) where the paths join -- so every (tap, row)
+  // offset of the tile is computed ONCE into an LDS table (9 KB for a 3x3 convolution) and each issue reads its two entries.
+  unsigned* tab = reinterpret_cast<unsigned*>(smem + 2 * BUFBYTES);   // [taps][256]: byte offset of the source row (chunk 0), or OOB
+  unsigned xo[2][2];
+  if constexpr (GATHER) {
+    const int r = tid & 255;
+    const RowInfo ri = make_row(a, m0 + r);
+    for (int tap = tid >> 8; tap < taps; tap += 2) {
+      const int sr = src_row(a, ri, tap);
+      tab[tap * 256 + r] = sr < 0 ? OOB : (unsigned)((long)(sr - brow) * a.ldx * 2);
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + rA[h][i] + prow;
+        xo[h][i] = m < a.M ? (unsigned)(((long)(m - brow) * a.ldx + scol) * 2) : OOB;
+      }
+  }
+  unsigned wo0[NT0], wo1[NT1];
+#pragma unroll
+  for (int i = 0; i < NT0; ++i) wo0[i] = (unsigned)(((long)(rB0[i] + prow) * taps * a.K + scol) * 2);
+#pragma unroll
+  for (int i = 0; i < NT1; ++i) wo1[i] = (unsigned)(((long)(rB1[i] + prow) * taps * a.K + scol) * 2);
+
+  // issue cursors, one per part: tl = K tile the next issue of the part belongs to.  The weight rows are [taps][K] contiguous and K is a
+  // multiple of 64, so a B part's scalar offset is simply tl * 128 bytes; the A parts of a gather also track (tap, k chunk).
+  struct Cur { int tap, kc, tl; };
+  Cur cA0 = {0, 0, 0}, cA1 = {0, 0, 0};
+  int tB0 = 0, tB1 = 0;
+  auto issueA = [&](Cur& c, int half) {
+    char* base = smem + (c.tl & 1) * BUFBYTES;
+    const int sx = __builtin_amdgcn_readfirstlane((GATHER ? c.kc : c.tl) * (BK * 2));
+    const bool live = c.tl < nit;
+    unsigned v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if constexpr (GATHER) v[i] = tab[__builtin_amdgcn_readfirstlane(min(c.tap, taps - 1)) * 256 + rA[half][i] + prow] + (unsigned)(scol * 2);
+      else v[i] = xo[half][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(base + rA[half][i] * 128), 16, (int)(live ? v[i] : OOB), sx, 0, 0);
+    ++c.tl;
+    if constexpr (GATHER) {
+      if (++c.kc == nkc) { c.kc = 0; ++c.tap; }
+    }
+  };
+  auto issueB0 = [&]() {
+    char* base = smem + (tB0 & 1) * BUFBYTES + ABYTES;
+    const int sw = __builtin_amdgcn_readfirstlane(tB0 * (BK * 2));
+    const bool live = tB0 < nit;
+#pragma unroll
+    for (int i = 0; i < NT0; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(base + rB0[i] * 128), 16, (int)(live ? wo0[i] : OOB), sw, 0, 0);
+    ++tB0;
+  };
+  auto issueB1 = [&]() {
+    char* base = smem + (tB1 & 1) * BUFBYTES + ABYTES;
+    const int sw = __builtin_amdgcn_readfirstlane(tB1 * (BK * 2));
+    const bool live = tB1 < nit;
+#pragma unroll
+    for (int i = 0; i < NT1; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(base + rB1[i] * 128), 16, (int)(live ? wo1[i] : OOB), sw, 0, 0);
+    ++tB1;
+  };
+
+  f32x4 acc[NT][MT];
+  init_acc<NT, MT, WN>(a, acc, n0, wc, lane);
+
+  // fragment reads: lane -> row (tile base + lane & 15), 16-byte chunk ((ks * 4 + lane >> 4) ^ ((row >> 1) & 7)); every tile base is a
+  // multiple of 16 rows, so the swizzle term depends on the lane alone and the two k-steps differ by an XOR with 64 bytes
+  const int frow = lane & 15, fg = lane >> 4;
+  const int c0 = (fg ^ ((frow >> 1) & 7)) << 4;
+  const int la0 = (wr * 128 + frow) * 128 + c0, la1 = la0 ^ 64;
+  const int lb0 = ABYTES + (wc * WN + frow) * 128 + c0, lb1 = lb0 ^ 64;
+  f16x8 fa[2][4], fb[2][NT0];
+  auto readA = [&](int buf, int half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[0][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la0 + (half * 4 + i) * 2048);
+      fa[1][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la1 + (half * 4 + i) * 2048);
+    }
+  };
+  auto readB = [&](int buf, int j0, int nj) {
+#pragma unroll
+    for (int j = 0; j < NT0; ++j) {
+      if (j < nj) {
+        fb[0][j] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + lb0 + (j0 + j) * 2048);
+        fb[1][j] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + lb1 + (j0 + j) * 2048);
+      }
+    }
+  };
+  auto cluster = [&](int half, int j0, int nj) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < NT0; ++j)
+        if (j < nj) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[j0 + j][half * 4 + i] = mfma16(fb[ks][j], fa[ks][i], acc[j0 + j][half * 4 + i]);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+#define ME_BAR()                               \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("" ::: "memory");             \
+    __builtin_amdgcn_s_barrier();              \
+    asm volatile("" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+#define ME_LGKM0()                                       \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+
+  // prologue: tile 0 whole, the first two parts of tile 1
+  issueA(cA0, 0);
+  issueB0();
+  issueB1();
+  issueA(cA1, 1);
+  issueA(cA0, 0);
+  issueB1();
+  if constexpr (NT1 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  ME_BAR();
+  if (wr == 1) ME_BAR();   // the second wave of every SIMD runs one barrier behind the first
+
+  for (int t = 0; t < nit; ++t) {
+    const int buf = t & 1;
+    // phase 0: quadrant (A0, B0)
+    readB(buf, 0, NT0);
+    readA(buf, 0);
+    issueA(cA1, 1);
+    ME_BAR();
+    ME_LGKM0();
+    cluster(0, 0, NT0);
+    ME_BAR();
+    // phase 1: (A0, B1)
+    readB(buf, NT0, NT1);
+    issueB0();
+    ME_BAR();
+    ME_LGKM0();
+    cluster(0, NT0, NT1);
+    ME_BAR();
+    // phase 2: (A1, B1)
+    readA(buf, 1);
+    issueA(cA0, 0);
+    ME_BAR();
+    ME_LGKM0();
+    cluster(1, NT0, NT1);
+    ME_BAR();
+    // phase 3: (A1, B0)
+    readB(buf, 0, NT0);
+    issueB1();
+    if constexpr (NT1 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    ME_BAR();
+    ME_LGKM0();
+    cluster(1, 0, NT0);
+    ME_BAR();
+  }
+  if (wr == 0) ME_BAR();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range tail DMAs still write (zeros) into this block's LDS
+#undef ME_BAR
+#undef ME_LGKM0
+
+  auto rowfn = [&](int i) {
+    const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+    return m < a.M ? m : -1;
+  };
+  epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wc, lane, nullptr, 0);
+}
+
 int stage_impl() {
   static int impl = -1;
   if (impl < 0) {
@@ -786,6 +1040,11 @@ bool buf_stage() {   // ME_GEMM_BUF=0: keep the global_load_lds staging for ever
   return on == 1;
 }
 
+int use_8p() {   // ME_GEMM_8P=0: every big-tile GEMM stays on the one-barrier-per-slab kernel (A/B); default: K tiles >= ME_GEMM_8P (2).
+  const char* e = getenv("ME_GEMM_8P");   // read at every call so that tests and tools/kbench.py can flip it inside one process
+  return e ? atoi(e) : 2;
+}
+
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -820,6 +1079,35 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>", BM, BN, STAGE == STAGE_REG ? ",reg" : "");
+    me_set_kernel(nm);
+  }
+  if (hipGetLastError() != hipSuccess) {
+    me_set_error("me_gemm: kernel launch failed");
+    return ME_EHIP;
+  }
+  return ME_OK;
+}
+
+template <int BN, bool GATHER>
+static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
+  const int lds = 2 * (256 + BN) * 128 + (GATHER ? 9 * 256 * 4 : 0);
+  static bool attr_set_dev[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  bool& attr_set = attr_set_dev[dev_id & 63];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+      me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return ME_EHIP;
+    }
+    attr_set = true;
+  }
+  const int nbm = (a->M + 255) / 256, nbn = (a->N + BN - 1) / BN;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((gemm8p_kernel<BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, *a);
+  {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "gemm8p_kernel<%d,%s>", BN, GATHER ? "true" : "false");
     me_set_kernel(nm);
   }
   if (hipGetLastError() != hipSuccess) {
@@ -886,8 +1174,17 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);
     const bool buf = a->K % 64 == 0 && buf_stage();   // scalar-offset buffer staging (no K tail, no packed-tap mode)
-    if (a->N % 320 == 0 && big_blocks >= big_min_blocks())
+    if (a->N % 320 == 0 && big_blocks >= big_min_blocks()) {
+      // the 8-phase kernel: K tiles of 64, at least use_8p() of them; GEGLU pairs (value, gate) column tiles inside a wave -> 256-wide
+      // tiles with 4 column tiles per wave (every GEGLU width of the model, 2560 ... 10240, is a multiple of 256)
+      const int nit8 = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
+      if (buf && use_8p() > 0 && nit8 >= use_8p()) {
+        const bool dense = a->gather == ME_GATHER_DENSE;
+        if (!a->geglu) return dense ? launch_gemm8p<320, false>(a, st) : launch_gemm8p<320, true>(a, st);
+        if (dense && a->N % 256 == 0 && (long)((a->M + 255) / 256) * (a->N / 256) >= big_min_blocks()) return launch_gemm8p<256, false>(a, st);
+      }
       return buf ? launch_gemm<256, 320, STAGE_BUF>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
+    }
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
     const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);

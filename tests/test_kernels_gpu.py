@@ -150,6 +150,59 @@ def test_gemm_tconv(ops, C, frames, npix, chunk, nb):
     check(got, emu.gemm(x, w, bias=bias, tconv=(frames, npix, chunk), res=res), f"tconv C={C} f={frames} chunk={chunk}")
 
 
+@pytest.mark.parametrize("case", ["dense k320 bias+res", "dense tail k128 res+res2", "dense generic epilogue", "dense one k tile", "geglu", "conv stride 2",
+                                  "conv upsampled", "tconv"])
+def test_gemm_8phase_kernel(ops, case, monkeypatch):
+    """The 8-phase ping-pong kernel (grids of >= 512 tiles of 256 rows): against the emulation, BITWISE against the one-barrier-per-slab
+    kernel (same MFMA order per accumulator, same epilogue code) and bitwise across repeated runs -- a staging race would show as a tile
+    that differs on some run."""
+    kw, ekw = {}, {}
+    geglu = False
+    if case.startswith("dense"):
+        M, N, K = {"dense k320 bias+res": (256 * 520, 320, 320), "dense tail k128 res+res2": (66000, 640, 128),
+                   "dense generic epilogue": (256 * 260, 640, 192), "dense one k tile": (256 * 520, 320, 64)}[case]
+        x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+        ekw["bias"] = rnd(N, seed=3)
+        ekw["res"] = rnd(M, N, seed=4)
+        if "res2" in case or "generic" in case:
+            ekw["res2"] = rnd(M, N, seed=5)
+        if "generic" in case:
+            ekw["rowvec"], ekw["rows_per_vec"], ekw["act"] = rnd(8, N, seed=6), (M + 7) // 8, 2
+    elif case == "geglu":
+        M, C = 33000, 320
+        from motioneditor_amd.weights import Packed
+        Pc = Packed({"w": torch.randn(8 * C, C, generator=torch.Generator().manual_seed(1)) * C ** -0.5,
+                     "b": torch.randn(8 * C, generator=torch.Generator().manual_seed(2)) * 0.1}, "cpu")
+        x, w = rnd(M, C, seed=3), Pc.geglu_mat("w")
+        ekw["bias"] = Pc.geglu_vec("b")
+        geglu = True
+    elif case.startswith("conv"):
+        Cin, Cout, H, W, stride, ups, nimg = (128, 320, 32, 32, 2, 0, 512) if "stride" in case else (64, 320, 8, 8, 1, 1, 512)
+        ho, wo = ((H << ups) - 1) // stride + 1, ((W << ups) - 1) // stride + 1
+        M = nimg * ho * wo
+        x, w = rnd(nimg * H * W, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
+        ekw.update(M=M, conv=(H, W, ho, wo, stride, ups), bias=rnd(Cout, seed=3), res=rnd(M, Cout, seed=4))
+    else:
+        C, frames, npix, chunk, nb = 320, 16, 64, 8, 128
+        M = nb * frames * npix
+        x, w = rnd(M, C, seed=1), rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
+        ekw.update(tconv=(frames, npix, chunk), bias=rnd(C, seed=3), rowvec=rnd(nb, C, seed=5), rows_per_vec=frames * npix, res=rnd(M, C, seed=4))
+    for k, v in ekw.items():
+        kw[k] = cu(v) if isinstance(v, torch.Tensor) else v
+    xg, wg = cu(x), cu(w)
+    monkeypatch.setenv("ME_GEMM_8P", "0")
+    ref = ops.gemm(xg, wg, geglu=geglu, **kw)
+    assert ops._last_kernel().startswith("gemm_kernel<256,320"), ops._last_kernel()
+    monkeypatch.setenv("ME_GEMM_8P", "1")
+    for rep in range(4):
+        got = ops.gemm(xg, wg, geglu=geglu, **kw)
+        assert ops._last_kernel().startswith("gemm8p_kernel"), ops._last_kernel()
+        assert torch.equal(got, ref), f"{case}: run {rep} differs from the one-barrier kernel in {int((got != ref).sum())} elements"
+    sub = slice(0, None, 7)   # every 7th row against the emulation (the bitwise check above covers the rest)
+    want = emu.gemm(x, w, geglu=geglu, **ekw)
+    check(got[sub], want[sub], f"8-phase gemm {case}")
+
+
 def test_gemm_rejects_bad_arguments(ops):
     x, w = cu(rnd(16, 12)), cu(rnd(8, 1, 12))
     with pytest.raises(ValueError):

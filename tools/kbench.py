@@ -63,6 +63,55 @@ def bench_gemm():
     print("sum ms", round(tot, 2))
 
 
+def bench_gemm_8p():
+    """8-phase ping-pong kernel vs the one-barrier-per-slab kernel on the shapes that take the 256-row tile (ME_GEMM_8P flips per call):
+    times both, and checks the 8-phase result BITWISE against the other kernel's (same MFMA order per accumulator, same epilogue) on
+    every one of several runs (a staging race shows up as a tile that differs on some run)."""
+    import os
+    B, f = 4, 24
+    cases = []
+    for li, (hw, C) in enumerate([(64, 320), (32, 640), (16, 1280)]):
+        M = B * f * hw * hw
+        cases += [(f"L{li} qkv", M, 3 * C, C, None, None, False, ""), (f"L{li} out +b+res", M, C, C, None, None, False, "br"),
+                  (f"L{li} ff1 geglu", M, 8 * C, C, None, None, True, "b"), (f"L{li} ff2 +b+res", M, C, 4 * C, None, None, False, "br")]
+        if li < 2:
+            cases += [(f"L{li} tconv +b+rv+res", M, C, C, None, (f, hw * hw, f), False, "bvr")]
+    cases += [("L1->L0 ups conv 640", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, False, "b"),
+              ("L2->L1 ups conv 1280", B * f * 1024, 1280, 1280, (16, 16, 32, 32, 1, 1), None, False, "b"),
+              ("L0->L1 s2 conv 320", B * f * 1024, 320, 320, (64, 64, 32, 32, 2, 0), None, False, "b"),
+              ("L2 conv 2560->1280 @32", B * f * 1024, 1280, 2560, (32, 32, 32, 32, 1, 0), None, False, "b"),
+              ("big 8192 x 8320 K4096", 8192, 8320, 4096, None, None, False, ""),
+              ("big 8192 x 8192 K4096 geglu", 8192, 8192, 4096, None, None, True, "b"),
+              ("tail M=100000 N=960 K=320", 100000, 960, 320, None, None, False, "br")]
+    print(f"{'gemm':30s} {'M':>8s} {'N':>6s} {'K':>6s} {'old ms':>8s} {'TF/s':>7s} {'8p ms':>8s} {'TF/s':>7s} {'x':>5s}  bitwise", flush=True)
+    for name, M, N, K, conv, tconv, geglu, terms in cases:
+        taps = 9 if conv else (3 if tconv else 1)
+        rows_in = M if not conv else (M // (conv[2] * conv[3])) * conv[0] * conv[1]
+        x, w = rnd(rows_in, K), rnd(N, taps, K) * (0.05 if K * taps > 2000 else 0.2)
+        kw = dict(M=M, conv=conv, tconv=tconv, geglu=geglu)
+        if "b" in terms:
+            kw["bias"] = rnd(N)
+        if "v" in terms:
+            kw["rowvec"], kw["rows_per_vec"] = rnd(B, N), M // B
+        if "r" in terms:
+            kw["res"] = rnd(M, N)
+        os.environ["ME_GEMM_8P"] = "0"
+        ref = ops.gemm(x, w, **kw)
+        k_old = ops._last_kernel()
+        t_old = timeit(lambda: ops.gemm(x, w, **kw))
+        os.environ["ME_GEMM_8P"] = "1"
+        ok = True
+        for _ in range(6):
+            y = ops.gemm(x, w, **kw)
+            ok = ok and torch.equal(y, ref)
+        k_new = ops._last_kernel()
+        t_new = timeit(lambda: ops.gemm(x, w, **kw))
+        fl = 2.0 * M * N * K * taps
+        print(f"{name:30s} {M:8d} {N:6d} {K*taps:6d} {t_old:8.3f} {fl/t_old/1e9:7.1f} {t_new:8.3f} {fl/t_new/1e9:7.1f} {t_old/t_new:5.2f}  {'equal' if ok else 'DIFFERENT'}  {k_old} -> {k_new}", flush=True)
+        del x, w, ref, y, kw
+    os.environ.pop("ME_GEMM_8P", None)
+
+
 def bench_gemm_cached():
     """Same dense shapes with every X row aliased to row 0 (stride-0 view): X comes from L2, only the output streams.
     The gap to the normal run = what HBM latency / bandwidth on the activation stream costs."""
@@ -238,6 +287,8 @@ if __name__ == "__main__":
         bench_gemm_epi()
     if "gemmk" in what:
         bench_gemm_ksweep()
+    if "gemm8p" in what:
+        bench_gemm_8p()
     if "gemmabl" in what:
         bench_gemm_abl()
     if "gemmc" in what:
