@@ -3,9 +3,10 @@
 rows, one batch-4 UNet3D forward with the content-aware motion adapter and both attention editors,
 classifier-free guidance and the DDIM update -- runs entirely on libmotioned HIP kernels.
 
-Out of scope here: CLIP text encoding, VAE encode/decode, null-text inversion.  With
-no ``text_encoder`` the prompt embeddings are passed as ``text_embeddings=[2,77,768]`` (an extension
-keyword swallowed by the reference's ``**kwargs``); with no ``vae`` use ``output_type="latent"``.
+CLIP text encoding is out of scope: with no ``text_encoder`` the prompt embeddings are
+passed as ``text_embeddings=[2,77,768]`` (an extension keyword swallowed by the reference's ``**kwargs``).
+The VAE (``models/vae.py``) is optional: with no ``vae`` use ``output_type="latent"``.  DDIM inversion and
+null-text optimisation live in ``motioneditor_amd/util.py``.
 """
 from __future__ import annotations
 
@@ -162,7 +163,7 @@ class MotionEditorPipeline:
 
     def decode_latents(self, latents):
         if self.vae is None:
-            raise ValueError("no vae: call with output_type='latent' (VAE decode is out of scope)")
+            raise ValueError("no vae: call with output_type='latent', or construct the pipeline with motioneditor_amd.models.vae.AutoencoderKL")
         b, c, f, h, w = latents.shape
         x = (1 / 0.18215) * latents.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
         video = self.vae.decode(x).sample
