@@ -1045,6 +1045,11 @@ int use_8p() {   // ME_GEMM_8P=0: every big-tile GEMM stays on the one-barrier-p
   return e ? atoi(e) : 2;
 }
 
+long n64_below() {   // ME_GEMM_N64_BELOW: grids of fewer 128 x 128 tiles than this take 128 x 64 tiles (M = 1536 convolutions: 0.136 -> 0.117 ms)
+  const char* e = getenv("ME_GEMM_N64_BELOW");
+  return e ? atol(e) : 200;
+}
+
 bool tile160() {
   static int on = -1;
   if (on < 0) {
@@ -1188,6 +1193,10 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
     const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);
+    {   // grids that leave more than half of the 256 CUs without a 128 x 128 tile (the M = 1536 level: 120 tiles): 64-wide tiles double the block count
+      const long blocks128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+      if (a->N % 64 == 0 && blocks128 < n64_below()) return buf ? launch_gemm<128, 64, STAGE_BUF>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
+    }
     if (a->N % 128 == 0 && blocks160 < 512) return buf ? launch_gemm<128, 128, STAGE_BUF>(a, st) : launch_gemm<128, 128, STAGE_GLDS>(a, st);
     if (!a->geglu && a->N % 160 == 0 && tile160()) return buf ? launch_gemm<128, 160, STAGE_BUF>(a, st) : launch_gemm<128, 160, STAGE_GLDS>(a, st);
     if (wide) return buf ? launch_gemm<128, 128, STAGE_BUF>(a, st) : launch_gemm<128, 128, STAGE_GLDS>(a, st);
