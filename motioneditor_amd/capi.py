@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "libmotioned.so"
+LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
 ABI_VERSION = 4
