@@ -156,6 +156,11 @@ typedef struct me_attn_args {
 
 int me_attn(const me_attn_args* a, void* stream);
 int64_t me_attn_vsum_bytes(int32_t n_kv_items, int32_t channels);
+/* Diagnostic of the fixed-offset softmax (the dh = 40 / 80 kernels for segments of >= 256 keys): the number of thread blocks, on the current
+ * device since the last reset, whose speculative pass met a probability beyond fp16's range and that therefore re-ran with the classic
+ * running maximum (correct either way; each such block costs about twice).  Synchronises with the device.  reset != 0 zeroes the counter.
+ * Returns -1 on a HIP error.  With trained checkpoints this says whether the per-stage re-basing keeps the fast path. */
+int64_t me_attn_fallback_blocks(int32_t reset);
 
 /* ---- temporal (per-pixel, over frames) causal attention ------------------------------------- *
  * rows (b*frames + fr)*npix + p.  For batch b, K/V are read from batch kv_map[b] (the temporal

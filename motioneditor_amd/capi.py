@@ -114,6 +114,7 @@ SYMBOLS = {
     "me_softmax_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "me_attn_vsum_bytes": (_i64, [_i32, _i32]),
+    "me_attn_fallback_blocks": (_i64, [_i32]),
     "me_geglu_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_layernorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _i32, _i64, _i32, C.c_float, _vp]),
     "me_groupnorm_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, C.c_float, _i32, _vp, _vp]),

@@ -31,6 +31,9 @@ extern "C" void me_set_kernel(const char* name);
 
 namespace {
 
+__device__ unsigned long long g_fallback_blocks;   // blocks of the fixed-offset kernels that re-ran with the running maximum (phase B)
+
+
 constexpr float NEG_BIG = -1.0e30f;
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: 16 rows x 16 B hit 64 distinct banks)
@@ -859,6 +862,38 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's K fragment reads below this tile's PV: 8 x 4 registers the kernel does not have
   };
 
+  // FOLD hedge: once per stage, a query whose denominator has grown past 2^9 -- its keys are getting heavier than its probe tile
+  // promised (or there are simply many of them) -- moves its fixed offset up by d = ceil(log2(denominator)) - 5 and scales its
+  // accumulators by 2^-d (a power of two; numerator and denominator alike), which puts the denominator back into (16, 32].  Gradual
+  // growth away from the probe thus never reaches fp16's range -- the softmax is exact for any offset -- while keys down to 2^-19 of the
+  // denominator keep full fp16 precision (re-basing all the way down to 1, as a running maximum does, pushed the light keys of a peaky row
+  // into fp16's subnormals: 2-3 ulp on such rows instead of 1).  One compare and a wave-uniform branch per query tile and stage; only a
+  // jump of more than ~2^7 in the denominator inside ONE stage still ends in phase B.
+#ifndef ME_ATTN_REBASE_AT
+#define ME_ATTN_REBASE_AT 512.f
+#endif
+  constexpr float REBASE_AT = ME_ATTN_REBASE_AT, REBASE_TO_LOG2 = 5.f;   // (a lane of the kernels without the ones row holds a quarter of the denominator: it re-bases a little later)
+  auto rebase = [&]() {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float lq;
+      if constexpr (ONES) lq = (g == (DH % 16) / 4) ? o[qt][DH / 16][(DH % 16) % 4] : 0.f;   // the ones row of the PV accumulators
+      else lq = lrun[qt];                                                                     // this lane's share of the denominator
+      if (__builtin_amdgcn_readfirstlane(__any(lq > REBASE_AT))) {
+        float l;
+        if constexpr (ONES) l = __shfl(o[qt][DH / 16][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
+        else l = xor32_sum(xor16_sum(lrun[qt]));
+        // per query (lane column); the four lane groups of a query agree.  A denominator at or beyond 65504 may already contain a saturated P:
+        // that query is left alone -- its denominator can only grow, and the check after the sweep sends the block to phase B.
+        const float d = (l > REBASE_AT && l < 65504.f) ? ceilf(__log2f(l)) - REBASE_TO_LOG2 : 0.f;
+        const float sc = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= sc;
+        if constexpr (!ONES) lrun[qt] *= sc;
+        set_ref(qt, mrun[qt] + d);
+      }
+    }
+  };
   const int nfull = a.nk / KT;
   auto sweep = [&](auto fold_c) {
     int st_c = 0;   // compute cursor: stage inside the segment
@@ -875,6 +910,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
           else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
         }
       }
+      if constexpr (FOLD && decltype(fold_c)::value) rebase();
       if (++st_c == nst) st_c = 0;
       if (NBUF == 1 && si + 1 < T) {
         __syncthreads();   // single buffer: every wave is done reading it
@@ -905,6 +941,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     if (trip) trip_flag = 1;
     __syncthreads();
     if (trip_flag) {
+      if (tid == 0) atomicAdd(&g_fallback_blocks, 1ull);   // diagnostic: me_attn_fallback_blocks()
       load_q(BF{});
       reset_acc();
       prime();
@@ -1029,6 +1066,16 @@ int launch_attn(const me_attn_args* a, hipStream_t st) {
 }  // namespace
 
 extern "C" void me_set_error(const char* msg);
+
+extern "C" int64_t me_attn_fallback_blocks(int32_t reset) {
+  unsigned long long v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fallback_blocks), sizeof(v)) != hipSuccess) return -1;   // synchronises with the device
+  if (reset) {
+    const unsigned long long z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_fallback_blocks), &z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return (int64_t)v;
+}
 
 extern "C" int64_t me_attn_vsum_bytes(int32_t n_kv_items, int32_t channels) {
   return n_kv_items > 0 && channels > 0 ? (int64_t)(1 + COLSUM_RS) * n_kv_items * channels * (int64_t)sizeof(float) : 0;

@@ -519,6 +519,15 @@ def geglu_bwd(pre, dy):
     return out
 
 
+def attention_fallback_blocks(reset: bool = False) -> int:
+    """Blocks of the fixed-offset attention kernels that re-ran with the running maximum since the last reset (me_attn_fallback_blocks): a
+    diagnostic for trained checkpoints -- 0 means the speculative fast path (with its per-stage re-basing) held everywhere.  Synchronises."""
+    n = capi.lib().me_attn_fallback_blocks(1 if reset else 0)
+    if n < 0:
+        raise capi.MotionedError("me_attn_fallback_blocks: HIP error")
+    return int(n)
+
+
 def attention_bwd(q, k, v, out, dout, *, dq, dk, dv, lse, heads, dh, n_items, nq, nk, seg_item, seg_mode, mask=None, scale=None, q_items=0):
     """(dq, dk, dv) += the input gradients of me_attn for PLAIN segments ([prev | cur], self, text, [first | prev]): the fused flash-style
     backward (csrc/attn_bwd.hip): P rebuilt per tile from the forward's log-sum-exp `lse`, no score matrix, any key count.  dq / dk / dv are

@@ -347,7 +347,46 @@ def test_attention_fixed_offset_overflow_falls_back_to_running_max(ops, dh, nq, 
     want = emu.attention(q, k, v, **args)
     assert torch.isfinite(got).all()
     check(got, want, f"attn fixed-offset fallback dh={dh} nq={nq} {where}", rel=2e-3, mx=2e-2)
+    ops.attention_fallback_blocks(reset=True)
     assert torch.equal(got, ops.attention(cu(q), cu(k), cu(v), **{**args, "seg_item": cu(si), "seg_mode": cu(sm)}))   # run to run
+    nfb = ops.attention_fallback_blocks()
+    assert where == "edge" or nfb > 0, (where, nfb)   # the sudden 2^50 jump is what phase B is for ("edge": 2^14.4 +- the queries' own spread: either path)
+
+
+@pytest.mark.parametrize("dh,nq,nk", [(40, 512, 2048), (80, 256, 1024), (40, 96, 640)])
+def test_attention_fixed_offset_rebases_under_gradual_growth(ops, dh, nq, nk):
+    """Keys get steadily heavier along the key order (a common component of the keys grows linearly: +0.03 nats per key, i.e. 5.5 binades
+    per 128-key stage, 61 nats = 88 binades over 2048 keys): the first queries' probe tiles promise far lighter keys than the sweep then
+    meets.  The per-stage re-basing of the fixed offset (denominator > 2^9 -> offset += d = ceil(log2) - 5, accumulators x 2^-d) must keep every
+    block on the fast path -- no block may fall back to the running-maximum sweep -- and the result must match the reference softmax."""
+    from motioneditor_amd import segments
+    C, n_items = 8 * dh, 2
+    g = torch.Generator().manual_seed(23)
+    q = torch.randn(n_items * nq, C, generator=g) * 0.5
+    k = torch.randn(n_items * nk, C, generator=g) * 0.5
+    v = torch.randn(n_items * nk, C, generator=g)
+    scale = dh ** -0.5
+    ramp = 0.03 * torch.arange(nk, dtype=torch.float32)   # nats added to the logit of key j for every query
+    for it in range(n_items):
+        for h in range(8):
+            qs = q[it * nq:(it + 1) * nq, h * dh:(h + 1) * dh]
+            d = torch.randn(dh, generator=g)
+            d = d / d.norm()
+            qs -= (qs @ d)[:, None] * d                 # every query gets the SAME component 3 along d ...
+            qs += 3.0 * d
+            ks = k[it * nk:(it + 1) * nk, h * dh:(h + 1) * dh]
+            ks -= (ks @ d)[:, None] * d                 # ... and key j the component ramp_j / (3 scale): logit += ramp_j
+            ks += (ramp / (3.0 * scale))[:, None] * d
+    q, k, v = q.half(), k.half(), v.half()
+    si, sm = segments.self_items(n_items, "cpu")
+    args = dict(heads=8, dh=dh, n_items=n_items, nq=nq, nk=nk, seg_item=si, seg_mode=sm)
+    ops.attention_fallback_blocks(reset=True)
+    got = ops.attention(cu(q), cu(k), cu(v), **{**args, "seg_item": cu(si), "seg_mode": cu(sm)})
+    nfb = ops.attention_fallback_blocks()
+    want = emu.attention(q, k, v, **args)
+    assert torch.isfinite(got).all()
+    check(got, want, f"attn fixed-offset re-base dh={dh} nq={nq}", rel=2e-3, mx=2e-2)
+    assert nfb == 0, f"{nfb} blocks fell back to the running-maximum sweep"
 
 
 def test_attention_large_logits_online_softmax_rescale(ops):

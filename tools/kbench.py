@@ -207,6 +207,16 @@ def bench_attn(only_first=False):
             q[:, C:2 * C] = q[:, :C] * 4.0
             ms = timeit(fn)
             print(f"{name + ' (diagonal-dominant)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}")
+            # gradual growth: every query's logits rise by 60 nats from the first key of a frame to the last (a common component of q against a
+            # ramp in k): without the per-stage re-basing every block of the early queries falls back, with it none does
+            q = rnd(items * N, 3 * C)
+            ramp = torch.linspace(0.0, 60.0, N, device=dev).repeat(items)
+            for h in range(8):
+                q[:, h * dh] = 3.0                                           # query component along e_0 of the head
+                q[:, C + h * dh] = (ramp / (3.0 * dh ** -0.5)).half()        # key component: logit += ramp_j
+            ops.attention_fallback_blocks(reset=True)
+            ms = timeit(fn)
+            print(f"{name + ' (keys grow 60 nats)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}   blocks that fell back: {ops.attention_fallback_blocks()}")
         del q
 
 
