@@ -779,12 +779,16 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a
 // DMA-after-read: a part's slot is re-issued two phases after its last read (A0: read phase 0, issued phase 2; B1: 1 -> 3;
 // A1: 2 -> 0; B0: 3 -> 1).  Tiles past the end are issued as out-of-range offsets (zero fill, no memory traffic) so that the
 // counts stay uniform; everything is drained before the epilogue.
-template <int BN, bool GATHER>
+template <int BM, int BN, bool GATHER>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
-  constexpr int BM = 256, WN = BN / 4, NT = WN / 16, MT = 8, NT0 = (NT + 1) / 2, NT1 = NT / 2;
+  // BM = 256, or 192 for grids whose 256-row tiles would leave the last block round half empty (M = 24576 x N = 1280: 384 tiles = 1.5 rounds of
+  // the 256 CUs, 512 tiles of 192 rows = 2): wave tile GR x WN with GR = BM / 2 rows per wave group, A halves of HALF = GR / 2 rows.
+  constexpr int WN = BN / 4, NT = WN / 16, NT0 = (NT + 1) / 2, NT1 = NT / 2;
+  constexpr int GR = BM / 2, HALF = GR / 2, MH = HALF / 16, MT = 2 * MH;
+  constexpr int NPA = 2 * HALF / 8;   // 8-row DMA pieces per A part (both wave groups): 16, or 12 -- then waves 4-7 issue one piece, waves 0-3 two
   constexpr int ABYTES = BM * 128, BUFBYTES = (BM + BN) * 128;
-  static_assert(BN % 64 == 0 && NT1 >= 1, "wave tile");
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 256 rows | B BN rows][128 B], then (GATHER) the source-row table [taps][256]
+  static_assert(BN % 64 == 0 && NT1 >= 1 && HALF % 16 == 0 && NPA > 8 && NPA <= 16, "wave tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A BM rows | B BN rows][128 B], then (GATHER) the source-row table [taps][256]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -821,10 +825,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   // first LDS row of this wave's piece i of a part (wave-uniform; the DMA's LDS address travels in M0)
   int rA[2][2], rB0[NT0], rB1[NT1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    rA[0][i] = __builtin_amdgcn_readfirstlane(i * 128 + 8 * wave);        // A0 / A1: 16 pieces each, 2 per wave
-    rA[1][i] = __builtin_amdgcn_readfirstlane(i * 128 + 64 + 8 * wave);
+  for (int i = 0; i < 2; ++i) {   // A0 / A1: piece p = wave + 8 i (< NPA) -> wave group p / (HALF / 8), rows 8 (p % (HALF / 8)) of that group's half
+    const int p = wave + 8 * i;
+    rA[0][i] = __builtin_amdgcn_readfirstlane((p / (HALF / 8)) * GR + 8 * (p % (HALF / 8)));
+    rA[1][i] = __builtin_amdgcn_readfirstlane((p / (HALF / 8)) * GR + HALF + 8 * (p % (HALF / 8)));
   }
+  const bool two_a = __builtin_amdgcn_readfirstlane(wave + 8 < NPA ? 1 : 0) != 0;   // this wave issues two pieces per A part (always at BM = 256)
 #pragma unroll
   for (int i = 0; i < NT0; ++i) {   // B0: 8 NT0 pieces
     const int p = wave + 8 * i;
@@ -843,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   unsigned xo[2][2];
   if constexpr (GATHER) {
     const int r = tid & 255;
-    const RowInfo ri = make_row(a, m0 + r);
+    const RowInfo ri = make_row(a, r < BM ? m0 + r : a.M);
     for (int tap = tid >> 8; tap < taps; tap += 2) {
       const int sr = src_row(a, ri, tap);
       tab[tap * 256 + r] = sr < 0 ? OOB : (unsigned)((long)(sr - brow) * a.ldx * 2);
@@ -855,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int m = m0 + rA[h][i] + prow;
-        xo[h][i] = m < a.M ? (unsigned)(((long)(m - brow) * a.ldx + scol) * 2) : OOB;
+        xo[h][i] = (m < a.M && (i == 0 || two_a)) ? (unsigned)(((long)(m - brow) * a.ldx + scol) * 2) : OOB;
       }
   }
   unsigned wo0[NT0], wo1[NT1];
@@ -876,12 +882,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
     unsigned v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      if constexpr (GATHER) v[i] = tab[__builtin_amdgcn_readfirstlane(min(c.tap, taps - 1)) * 256 + rA[half][i] + prow] + (unsigned)(scol * 2);
+      if constexpr (GATHER) v[i] = tab[__builtin_amdgcn_readfirstlane(min(c.tap, taps - 1)) * 256 + min(rA[half][i] + prow, 255)] + (unsigned)(scol * 2);
       else v[i] = xo[half][i];
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(base + rA[half][i] * 128), 16, (int)(live ? v[i] : OOB), sx, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(base + rA[half][0] * 128), 16, (int)(live ? v[0] : OOB), sx, 0, 0);
+    if (BM == 256 || two_a) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(base + rA[half][1] * 128), 16, (int)(live ? v[1] : OOB), sx, 0, 0);
     ++c.tl;
     if constexpr (GATHER) {
       if (++c.kc == nkc) { c.kc = 0; ++c.tap; }
@@ -913,14 +918,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   // multiple of 16 rows, so the swizzle term depends on the lane alone and the two k-steps differ by an XOR with 64 bytes
   const int frow = lane & 15, fg = lane >> 4;
   const int c0 = (fg ^ ((frow >> 1) & 7)) << 4;
-  const int la0 = (wr * 128 + frow) * 128 + c0, la1 = la0 ^ 64;
+  const int la0 = (wr * GR + frow) * 128 + c0, la1 = la0 ^ 64;
   const int lb0 = ABYTES + (wc * WN + frow) * 128 + c0, lb1 = lb0 ^ 64;
-  f16x8 fa[2][4], fb[2][NT0];
+  f16x8 fa[2][MH], fb[2][NT0];
   auto readA = [&](int buf, int half) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[0][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la0 + (half * 4 + i) * 2048);
-      fa[1][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la1 + (half * 4 + i) * 2048);
+    for (int i = 0; i < MH; ++i) {
+      fa[0][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la0 + (half * MH + i) * 2048);
+      fa[1][i] = *reinterpret_cast<const f16x8*>(smem + buf * BUFBYTES + la1 + (half * MH + i) * 2048);
     }
   };
   auto readB = [&](int buf, int j0, int nj) {
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
       for (int j = 0; j < NT0; ++j)
         if (j < nj) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[j0 + j][half * 4 + i] = mfma16(fb[ks][j], fa[ks][i], acc[j0 + j][half * 4 + i]);
+          for (int i = 0; i < MH; ++i) acc[j0 + j][half * MH + i] = mfma16(fb[ks][j], fa[ks][i], acc[j0 + j][half * MH + i]);
         }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -958,6 +963,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
     __builtin_amdgcn_sched_barrier(0);                   \
   } while (0)
 
+  // the counted wait: everything but the two youngest parts (one A part: 2 or 1 pieces of this wave, B1: NT1 pieces) has landed
+  auto wait_young = [&]() {
+    static_assert(NT1 == 2, "vmcnt literals below");
+    if (BM == 256 || two_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  };
   // prologue: tile 0 whole, the first two parts of tile 1
   issueA(cA0, 0);
   issueB0();
@@ -965,8 +976,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   issueA(cA1, 1);
   issueA(cA0, 0);
   issueB1();
-  if constexpr (NT1 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  wait_young();
   ME_BAR();
   if (wr == 1) ME_BAR();   // the second wave of every SIMD runs one barrier behind the first
 
@@ -997,8 +1007,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
     // phase 3: (A1, B0)
     readB(buf, 0, NT0);
     issueB1();
-    if constexpr (NT1 == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    wait_young();
     ME_BAR();
     ME_LGKM0();
     cluster(1, 0, NT0);
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #undef ME_LGKM0
 
   auto rowfn = [&](int i) {
-    const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+    const int m = m0 + wr * GR + i * 16 + (lane & 15);
     return m < a.M ? m : -1;
   };
   epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wc, lane, nullptr, 0);
@@ -1066,6 +1075,12 @@ int use_8p() {   // ME_GEMM_8P=0: every big-tile GEMM stays on the one-barrier-p
   return e ? atoi(e) : 2;
 }
 
+long min_tiles_192() {   // ME_GEMM_8P_192: smallest grid (in 192 x 320 tiles) that takes the 192-row 8-phase kernel (0 = never)
+  const char* e = getenv("ME_GEMM_8P_192");
+  const long v = e ? atol(e) : 448;
+  return v > 0 ? v : (1L << 60);
+}
+
 long n64_below() {   // ME_GEMM_N64_BELOW: grids of fewer 128 x 128 tiles than this take 128 x 64 tiles (M = 1536 convolutions: 0.136 -> 0.117 ms)
   const char* e = getenv("ME_GEMM_N64_BELOW");
   return e ? atol(e) : 200;
@@ -1114,26 +1129,26 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   return ME_OK;
 }
 
-template <int BN, bool GATHER>
+template <int BM, int BN, bool GATHER>
 static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
-  const int lds = 2 * (256 + BN) * 128 + (GATHER ? 9 * 256 * 4 : 0);
+  const int lds = 2 * (BM + BN) * 128 + (GATHER ? 9 * 256 * 4 : 0);
   static bool attr_set_dev[64] = {};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BM, BN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return ME_EHIP;
     }
     attr_set = true;
   }
-  const int nbm = (a->M + 255) / 256, nbn = (a->N + BN - 1) / BN;
+  const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();
-  hipLaunchKernelGGL((gemm8p_kernel<BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, *a);
+  hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, *a);
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm8p_kernel<%d,%s>", BN, GATHER ? "true" : "false");
+    snprintf(nm, sizeof(nm), "gemm8p_kernel<%d,%d,%s>", BM, BN, GATHER ? "true" : "false");
     me_set_kernel(nm);
   }
   if (hipGetLastError() != hipSuccess) {
@@ -1200,17 +1215,22 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);
     const bool buf = a->K % 64 == 0 && buf_stage();   // scalar-offset buffer staging (no K tail, no packed-tap mode)
+    const int nit8 = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
+    const bool dense = a->gather == ME_GATHER_DENSE;
     if (a->N % 320 == 0 && big_blocks >= big_min_blocks()) {
       // the 8-phase kernel: K tiles of 64, at least use_8p() of them; GEGLU pairs (value, gate) column tiles inside a wave -> 256-wide
       // tiles with 4 column tiles per wave (every GEGLU width of the model, 2560 ... 10240, is a multiple of 256)
-      const int nit8 = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
       if (buf && use_8p() > 0 && nit8 >= use_8p()) {
-        const bool dense = a->gather == ME_GATHER_DENSE;
-        if (!a->geglu) return dense ? launch_gemm8p<320, false>(a, st) : launch_gemm8p<320, true>(a, st);
-        if (dense && a->N % 256 == 0 && (long)((a->M + 255) / 256) * (a->N / 256) >= big_min_blocks()) return launch_gemm8p<256, false>(a, st);
+        if (!a->geglu) return dense ? launch_gemm8p<256, 320, false>(a, st) : launch_gemm8p<256, 320, true>(a, st);
+        if (dense && a->N % 256 == 0 && (long)((a->M + 255) / 256) * (a->N / 256) >= big_min_blocks()) return launch_gemm8p<256, 256, false>(a, st);
       }
       return buf ? launch_gemm<256, 320, STAGE_BUF>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
     }
+    // grids of 256 < tiles < 512 (the M = 24576 level at N = 1280: 384 tiles = 1.5 rounds of the 256 CUs): 192-row tiles of the 8-phase kernel
+    // make it 512 = 2 full rounds
+    // (K >= 512 only: the K = 320 projections of this size are bound by their residual / output traffic and measured 7 % slower)
+    if (a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= 8 && nit8 >= use_8p() && (long)((a->M + 191) / 192) * (a->N / 320) >= min_tiles_192())
+      return dense ? launch_gemm8p<192, 320, false>(a, st) : launch_gemm8p<192, 320, true>(a, st);
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
     const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);

@@ -151,16 +151,17 @@ def test_gemm_tconv(ops, C, frames, npix, chunk, nb):
 
 
 @pytest.mark.parametrize("case", ["dense k320 bias+res", "dense tail k128 res+res2", "dense generic epilogue", "dense one k tile", "geglu", "conv stride 2",
-                                  "conv upsampled", "tconv"])
+                                  "conv upsampled", "tconv", "dense 192-row tiles", "dense 192-row tiles tail", "conv 192-row tiles", "tconv 192-row tiles"])
 def test_gemm_8phase_kernel(ops, case, monkeypatch):
-    """The 8-phase ping-pong kernel (grids of >= 512 tiles of 256 rows): against the emulation, BITWISE against the one-barrier-per-slab
-    kernel (same MFMA order per accumulator, same epilogue code) and bitwise across repeated runs -- a staging race would show as a tile
-    that differs on some run."""
+    """The 8-phase ping-pong kernel (grids of >= 512 tiles of 256 rows; 192-row tiles for grids of 256 .. 511 such tiles): against the
+    emulation, BITWISE against the one-barrier-per-slab kernels (same MFMA order per accumulator, same epilogue code) and bitwise across
+    repeated runs -- a staging race would show as a tile that differs on some run."""
     kw, ekw = {}, {}
     geglu = False
     if case.startswith("dense"):
         M, N, K = {"dense k320 bias+res": (256 * 520, 320, 320), "dense tail k128 res+res2": (66000, 640, 128),
-                   "dense generic epilogue": (256 * 260, 640, 192), "dense one k tile": (256 * 520, 320, 64)}[case]
+                   "dense generic epilogue": (256 * 260, 640, 192), "dense one k tile": (256 * 520, 320, 64),
+                   "dense 192-row tiles": (24576, 1280, 640), "dense 192-row tiles tail": (24000, 1280, 512)}[case]
         x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
         ekw["bias"] = rnd(N, seed=3)
         ekw["res"] = rnd(M, N, seed=4)
@@ -177,13 +178,14 @@ def test_gemm_8phase_kernel(ops, case, monkeypatch):
         ekw["bias"] = Pc.geglu_vec("b")
         geglu = True
     elif case.startswith("conv"):
-        Cin, Cout, H, W, stride, ups, nimg = (128, 320, 32, 32, 2, 0, 512) if "stride" in case else (64, 320, 8, 8, 1, 1, 512)
+        Cin, Cout, H, W, stride, ups, nimg = ((128, 320, 32, 32, 2, 0, 512) if "stride" in case else (64, 1280, 16, 16, 1, 0, 96) if "192" in case
+                                              else (64, 320, 8, 8, 1, 1, 512))
         ho, wo = ((H << ups) - 1) // stride + 1, ((W << ups) - 1) // stride + 1
         M = nimg * ho * wo
         x, w = rnd(nimg * H * W, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
         ekw.update(M=M, conv=(H, W, ho, wo, stride, ups), bias=rnd(Cout, seed=3), res=rnd(M, Cout, seed=4))
     else:
-        C, frames, npix, chunk, nb = 320, 16, 64, 8, 128
+        C, frames, npix, chunk, nb = (320, 16, 64, 8, 128) if "192" not in case else (1280, 24, 256, 8, 4)
         M = nb * frames * npix
         x, w = rnd(M, C, seed=1), rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
         ekw.update(tconv=(frames, npix, chunk), bias=rnd(C, seed=3), rowvec=rnd(nb, C, seed=5), rows_per_vec=frames * npix, res=rnd(M, C, seed=4))
@@ -192,15 +194,35 @@ def test_gemm_8phase_kernel(ops, case, monkeypatch):
     xg, wg = cu(x), cu(w)
     monkeypatch.setenv("ME_GEMM_8P", "0")
     ref = ops.gemm(xg, wg, geglu=geglu, **kw)
-    assert ops._last_kernel().startswith("gemm_kernel<256,320"), ops._last_kernel()
+    assert ops._last_kernel().startswith("gemm_kernel<"), ops._last_kernel()
     monkeypatch.setenv("ME_GEMM_8P", "1")
     for rep in range(4):
         got = ops.gemm(xg, wg, geglu=geglu, **kw)
-        assert ops._last_kernel().startswith("gemm8p_kernel"), ops._last_kernel()
+        assert ops._last_kernel().startswith("gemm8p_kernel<192" if "192" in case else "gemm8p_kernel<256"), ops._last_kernel()
         assert torch.equal(got, ref), f"{case}: run {rep} differs from the one-barrier kernel in {int((got != ref).sum())} elements"
     sub = slice(0, None, 7)   # every 7th row against the emulation (the bitwise check above covers the rest)
     want = emu.gemm(x, w, geglu=geglu, **ekw)
     check(got[sub], want[sub], f"8-phase gemm {case}")
+
+
+def test_gemm_8phase_kernel_views_inplace_and_shared_residual(ops, monkeypatch):
+    """The 8-phase kernel on what the launch graph actually hands it: X as a column slice of a wider tensor (ldx > K), the output as a column
+    slice, the residual aliased to the output (in place), and a residual shared by several batch entries (res_rows)."""
+    monkeypatch.setenv("ME_GEMM_8P", "1")
+    M, C = 256 * 520, 320
+    big = rnd(M, 3 * C, seed=1)
+    w, bias = rnd(C, 1, C, seed=2, scale=C ** -0.5), rnd(C, seed=3)
+    t = rnd(M, 2 * C, seed=4)
+    tg = cu(t).clone()
+    ops.gemm(cu(big)[:, C:2 * C], cu(w), bias=cu(bias), res=tg[:, C:], out=tg[:, C:])          # strided X, strided out, out aliases res
+    assert ops._last_kernel().startswith("gemm8p_kernel"), ops._last_kernel()
+    want = emu.gemm(big[:, C:2 * C], w, bias=bias, res=t[:, C:])
+    check(tg[::5, C:], want[::5], "8-phase gemm strided views, in-place residual")
+    assert torch.equal(tg[:, :C].cpu(), t[:, :C])                                                # the other columns are untouched
+    shared = rnd(M // 4, C, seed=5)
+    got = ops.gemm(cu(big)[:, :C], cu(w), res=cu(shared), res_rows=M // 4)
+    assert ops._last_kernel().startswith("gemm8p_kernel"), ops._last_kernel()
+    check(got[::5], emu.gemm(big[:, :C], w, res=shared, res_rows=M // 4)[::5], "8-phase gemm shared residual rows")
 
 
 def test_gemm_rejects_bad_arguments(ops):

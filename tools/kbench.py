@@ -76,7 +76,9 @@ def bench_gemm_8p():
                   (f"L{li} ff1 geglu", M, 8 * C, C, None, None, True, "b"), (f"L{li} ff2 +b+res", M, C, 4 * C, None, None, False, "br")]
         if li < 2:
             cases += [(f"L{li} tconv +b+rv+res", M, C, C, None, (f, hw * hw, f), False, "bvr")]
-    cases += [("L1->L0 ups conv 640", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, False, "b"),
+    cases += [("L2 conv3x3", B * f * 256, 1280, 1280, (16, 16, 16, 16, 1, 0), None, False, "b"), ("L2 conv 2560->1280", B * f * 256, 1280, 2560, (16, 16, 16, 16, 1, 0), None, False, "b"),
+              ("L2 tconv +b+rv+res", B * f * 256, 1280, 1280, None, (f, 256, f), False, "bvr"), ("cn L1 out +b+res", 2 * f * 1024 * 2, 320, 320, None, None, False, "br"),
+              ("L1->L0 ups conv 640", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, False, "b"),
               ("L2->L1 ups conv 1280", B * f * 1024, 1280, 1280, (16, 16, 32, 32, 1, 1), None, False, "b"),
               ("L0->L1 s2 conv 320", B * f * 1024, 320, 320, (64, 64, 32, 32, 2, 0), None, False, "b"),
               ("L2 conv 2560->1280 @32", B * f * 1024, 1280, 2560, (32, 32, 32, 32, 1, 0), None, False, "b"),
