@@ -17,6 +17,7 @@
 // Splitting costs two extra matrix products (S and dP are computed in both kernels: 7 instead of 5) and buys determinism and
 // single-owner outputs.  Activations fp16, gradients fp32 in memory (loss-scaled by the caller), fp16 as MFMA operands.
 #include "me_common.h"
+#include <stdlib.h>
 #include "../../include/motioned.h"
 
 extern "C" void me_set_error(const char* msg);
@@ -448,8 +449,16 @@ extern "C" int me_attn_bwd(const me_attn_bwd_args* a, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   (void)hipGetLastError();
   switch (a->dh) {
-    case 40: return launch_bwd<40, 4>(a, st);
-    case 80: return launch_bwd<80, 2>(a, st);
+    case 40: {
+      // keys per block = 64 * NKT.  NKT = 4 amortises a staged query tile over the most MFMAs but needs 376 VGPRs (one wave per SIMD, one block per
+      // CU); NKT = 2 (196 VGPRs, two blocks per CU) measured 9.35 vs 11.4 ms for the whole L0 [prev | cur] backward, NKT = 1 11.1.  ME_ATTN_BWD_NKT for A/B.
+      static const int nkt = getenv("ME_ATTN_BWD_NKT") ? atoi(getenv("ME_ATTN_BWD_NKT")) : 2;
+      return nkt == 1 ? launch_bwd<40, 1>(a, st) : nkt == 2 ? launch_bwd<40, 2>(a, st) : launch_bwd<40, 4>(a, st);
+    }
+    case 80: {
+      static const int nkt = getenv("ME_ATTN_BWD_NKT") ? atoi(getenv("ME_ATTN_BWD_NKT")) : 2;
+      return nkt == 1 ? launch_bwd<80, 1>(a, st) : launch_bwd<80, 2>(a, st);
+    }
     case 160: return launch_bwd<160, 1>(a, st);
     default: me_set_error("me_attn_bwd: head dim must be 40, 80 or 160"); return ME_EINVAL;
   }
