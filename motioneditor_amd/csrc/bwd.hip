@@ -4,6 +4,7 @@
 // fp16 as in the forward.  First, straightforward versions: these run a few times per optimisation step on a batch-1 clip and are
 // HBM-bound at worst; they have not been tuned.
 #include "me_common.h"
+#include <stdlib.h>
 #include "../../include/motioned.h"
 
 extern "C" void me_set_error(const char* msg);
@@ -290,6 +291,204 @@ __global__ __launch_bounds__(64) void tattn_bwd_kernel(const f16* __restrict__ Q
 }
 
 
+// ---- temporal attention backward, lane-parallel form (frames <= 32, head dim 40 / 80 / 160) ----
+// The first version above runs one (pixel, head) per 64-thread block with 24 busy lanes, scalar loops and per-element strided global loads: 1.6-2.0 ms
+// per call where the forward takes 0.08.  Here a block owns ONE pixel and HB heads (HB * DH = 320 columns: every frame's row segment is 640 contiguous
+// bytes), stages q, k, v and the fp16-rounded dO of all frames in LDS with 16-byte loads, and each wave takes one head:
+//   lane (i, half) -- frame i = lane / 2 -- keeps row i of q and dO in registers and computes S[i][j], dP[i][j] for the j of its half with v_dot2 against
+//   k_j / v_j read from LDS (two distinct addresses per wave instruction: broadcasts); softmax, delta and dS across the lane pair; P and dS go to LDS
+//   [i][j]; then dQ_i (this lane's half of the head dim) = sum_j dS[i][j] k_j, and with the lane now standing for KEY frame j, dK_j = sum_i dS[i][j] q_i,
+//   dV_j = sum_i P[i][j] dO_i.  Causal: key frame <= query frame.  Results are written (=), as the first version does.
+template <int DH, int HB>
+__global__ __launch_bounds__(HB * 64) void tattn_bwd2_kernel(const f16* __restrict__ Q, int ldq, const f16* __restrict__ K, int ldk, const f16* __restrict__ V, int ldv,
+                                                             const float* __restrict__ dO, int lddo, float* __restrict__ dQ, int lddq, float* __restrict__ dK, int lddk,
+                                                             float* __restrict__ dV, int lddv, int batch, int F, int npix, int heads, float scale) {
+  constexpr int CH = DH / 8, DH2 = DH / 2, C4 = DH2 / 4;
+  const int FP = F | 1;   // row pitch of the [i][j] tiles (odd: column reads spread over the banks)
+  extern __shared__ __attribute__((aligned(16))) char smraw[];
+  f16* sq = reinterpret_cast<f16*>(smraw);   // [HB][F][DH]
+  f16* sk = sq + HB * F * DH;
+  f16* sv = sk + HB * F * DH;
+  f16* sd = sv + HB * F * DH;
+  float* sp = reinterpret_cast<float*>(sd + HB * F * DH);   // [HB][F][FP]
+  float* sds = sp + HB * F * FP;
+  const int tid = threadIdx.x;
+  int bid = blockIdx.x;
+  const int ng = heads / HB;
+  const int hg = bid % ng;
+  bid /= ng;
+  const int p = bid % npix;
+  const int b = bid / npix;
+  const int col0 = hg * HB * DH;
+  // stage: chunk (frame j, 16-byte column chunk c) of the HB * DH columns
+  for (int idx = tid; idx < F * HB * CH; idx += HB * 64) {
+    const int j = idx / (HB * CH), c = idx - j * (HB * CH);
+    const long row = ((long)b * F + j) * npix + p;
+    const int hh = c / CH, cc = c - hh * CH;
+    const int o = (hh * F + j) * DH + cc * 8;
+    *reinterpret_cast<uint4*>(sq + o) = ldg128(Q + row * ldq + col0 + c * 8);
+    *reinterpret_cast<uint4*>(sk + o) = ldg128(K + row * ldk + col0 + c * 8);
+    *reinterpret_cast<uint4*>(sv + o) = ldg128(V + row * ldv + col0 + c * 8);
+    const float* g = dO + row * lddo + col0 + c * 8;
+    const float4 a = *reinterpret_cast<const float4*>(g), b4 = *reinterpret_cast<const float4*>(g + 4);
+    U128 u;
+    u.e[0] = (f16)a.x; u.e[1] = (f16)a.y; u.e[2] = (f16)a.z; u.e[3] = (f16)a.w;
+    u.e[4] = (f16)b4.x; u.e[5] = (f16)b4.y; u.e[6] = (f16)b4.z; u.e[7] = (f16)b4.w;
+    *reinterpret_cast<uint4*>(sd + o) = u.u;
+  }
+  __syncthreads();
+  const int hh = tid >> 6, lane = tid & 63;
+  const int i = lane >> 1, half = lane & 1;
+  const bool act = i < F;
+  const int ic = act ? i : 0;
+  const f16* hq = sq + hh * F * DH;
+  const f16* hk = sk + hh * F * DH;
+  const f16* hv = sv + hh * F * DH;
+  const f16* hd = sd + hh * F * DH;
+  float* hp = sp + hh * F * FP;
+  float* hs = sds + hh * F * FP;
+  const int JH = (F + 1) / 2;   // keys per lane of a pair: j = half * JH + jj
+  {
+    // ---- S, dP for this lane's keys; softmax / delta / dS across the pair ----
+    U128 qi[CH], di[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      qi[c].u = *reinterpret_cast<const uint4*>(hq + ic * DH + c * 8);
+      di[c].u = *reinterpret_cast<const uint4*>(hd + ic * DH + c * 8);
+    }
+    float sv_[16], dp_[16];
+    float mx = -1.0e30f;
+    const float cs = scale * 1.4426950408889634f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      sv_[jj] = -1.0e30f;
+      dp_[jj] = 0.f;
+      if (jj < JH) {   // uniform
+        const int j = half * JH + jj;
+        const int jc = j < F ? j : 0;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          U128 kk, vv;
+          kk.u = *reinterpret_cast<const uint4*>(hk + jc * DH + c * 8);
+          vv.u = *reinterpret_cast<const uint4*>(hv + jc * DH + c * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f16x2 q2 = {qi[c].e[2 * e], qi[c].e[2 * e + 1]}, k2 = {kk.e[2 * e], kk.e[2 * e + 1]};
+            const f16x2 d2 = {di[c].e[2 * e], di[c].e[2 * e + 1]}, v2 = {vv.e[2 * e], vv.e[2 * e + 1]};
+            s = __builtin_amdgcn_fdot2(q2, k2, s, false);
+            dp = __builtin_amdgcn_fdot2(d2, v2, dp, false);
+          }
+        }
+        if (act && j <= i && j < F) {
+          sv_[jj] = s * cs;
+          dp_[jj] = dp;
+          mx = fmaxf(mx, s * cs);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float e = sv_[jj] > -1.0e29f ? __builtin_amdgcn_exp2f(sv_[jj] - mx) : 0.f;
+      sv_[jj] = e;
+      l += e;
+    }
+    l += __shfl_xor(l, 1, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float delta = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      sv_[jj] *= inv;
+      delta += sv_[jj] * dp_[jj];
+    }
+    delta += __shfl_xor(delta, 1, 64);
+    if (act) {
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int j = half * JH + jj;
+        if (jj < JH && j < F) {
+          hp[i * FP + j] = sv_[jj];
+          hs[i * FP + j] = sv_[jj] * (dp_[jj] - delta) * scale;
+        }
+      }
+    }
+  }
+  __syncthreads();   // (the tiles of a head are written and read by one wave; the barrier is the simple way to order them)
+  const int d0 = half * DH2;
+  if (act) {
+    // ---- dQ_i[d0 .. d0 + DH2) = sum_j dS[i][j] k_j ----
+    float acc[DH2];
+#pragma unroll
+    for (int d = 0; d < DH2; ++d) acc[d] = 0.f;
+    for (int j = 0; j <= i; ++j) {
+      const float ds = hs[i * FP + j];
+#pragma unroll
+      for (int c = 0; c < C4; ++c) {
+        U64 kk;
+        kk.u = *reinterpret_cast<const uint2*>(hk + j * DH + d0 + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c * 4 + e] = fmaf(ds, (float)kk.e[e], acc[c * 4 + e]);
+      }
+    }
+    float* o = dQ + (((long)b * F + i) * npix + p) * lddq + col0 + hh * DH + d0;
+#pragma unroll
+    for (int c = 0; c < C4; ++c) *reinterpret_cast<float4*>(o + c * 4) = make_float4(acc[c * 4], acc[c * 4 + 1], acc[c * 4 + 2], acc[c * 4 + 3]);
+  }
+  if (act) {
+    // ---- the lane now stands for KEY frame j = i: dK_j = sum_{i' >= j} dS[i'][j] q_i',  dV_j = sum_{i' >= j} P[i'][j] dO_i' ----
+    float ak[DH2], av[DH2];
+#pragma unroll
+    for (int d = 0; d < DH2; ++d) { ak[d] = 0.f; av[d] = 0.f; }
+    for (int r = i; r < F; ++r) {
+      const float ds = hs[r * FP + i], pp = hp[r * FP + i];
+#pragma unroll
+      for (int c = 0; c < C4; ++c) {
+        U64 qq, dd;
+        qq.u = *reinterpret_cast<const uint2*>(hq + r * DH + d0 + c * 4);
+        dd.u = *reinterpret_cast<const uint2*>(hd + r * DH + d0 + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ak[c * 4 + e] = fmaf(ds, (float)qq.e[e], ak[c * 4 + e]);
+          av[c * 4 + e] = fmaf(pp, (float)dd.e[e], av[c * 4 + e]);
+        }
+      }
+    }
+    const long row = ((long)b * F + i) * npix + p;
+    float* ok = dK + row * lddk + col0 + hh * DH + d0;
+    float* ov = dV + row * lddv + col0 + hh * DH + d0;
+#pragma unroll
+    for (int c = 0; c < C4; ++c) {
+      *reinterpret_cast<float4*>(ok + c * 4) = make_float4(ak[c * 4], ak[c * 4 + 1], ak[c * 4 + 2], ak[c * 4 + 3]);
+      *reinterpret_cast<float4*>(ov + c * 4) = make_float4(av[c * 4], av[c * 4 + 1], av[c * 4 + 2], av[c * 4 + 3]);
+    }
+  }
+}
+
+template <int DH, int HB>
+static int launch_tattn_bwd2(void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout,
+                             int lddo, int batch, int frames, int npix, int heads, float scale, hipStream_t st) {
+  const size_t lds = (size_t)4 * HB * frames * DH * sizeof(f16) + (size_t)2 * HB * frames * (frames | 1) * sizeof(float);
+  static bool attr_set_dev[64] = {};
+  int dev_id = 0;
+  (void)hipGetDevice(&dev_id);
+  if (!attr_set_dev[dev_id & 63]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tattn_bwd2_kernel<DH, HB>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+      me_set_error("me_tattn_bwd: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return ME_EHIP;
+    }
+    attr_set_dev[dev_id & 63] = true;
+  }
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((tattn_bwd2_kernel<DH, HB>), dim3((unsigned)((long)batch * npix * (heads / HB))), dim3(HB * 64), lds, st, reinterpret_cast<const f16*>(q), ldq,
+                     reinterpret_cast<const f16*>(k), ldk, reinterpret_cast<const f16*>(v), ldv, reinterpret_cast<const float*>(dout), lddo, reinterpret_cast<float*>(dq), lddq,
+                     reinterpret_cast<float*>(dk), lddk, reinterpret_cast<float*>(dv), lddv, batch, frames, npix, heads, scale);
+  const hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) { me_set_hip_error("me_tattn_bwd", (int)e_); return ME_EHIP; }
+  return ME_OK;
+}
+
 // Row softmax backward: dS = P * (dP - sum_j P_j dP_j) * scale, one wave per row (cols a multiple of 8).  Used by the first,
 // matrix-materialising form of the spatial attention backward (ops.attention_bwd).
 __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const f16* __restrict__ P, int ldp, const f16* __restrict__ dP, int lddp, f16* __restrict__ dS, int ldds,
@@ -435,6 +634,17 @@ extern "C" int me_tattn_bwd(void* dq, int32_t lddq, void* dk, int32_t lddk, void
   if (!dq || !dk || !dv || !q || !k || !v || !dout || batch <= 0 || frames <= 0 || frames > 64 || npix <= 0 || heads <= 0 || dh <= 0) {
     me_set_error("me_tattn_bwd: bad arguments (frames <= 64)");
     return ME_EINVAL;
+  }
+  {   // the lane-parallel kernel: frames <= 32, 16-byte aligned rows, heads a multiple of the heads per block
+    static const bool v2 = !(getenv("ME_TATTN_BWD2") && atoi(getenv("ME_TATTN_BWD2")) == 0);
+    const bool al = !((ldq | ldk | ldv) % 8) && !((lddo | lddq | lddk | lddv) % 4) &&
+                    !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15);
+    hipStream_t st2 = reinterpret_cast<hipStream_t>(stream);
+    if (v2 && al && frames <= 32) {
+      if (dh == 40 && heads % 8 == 0) return launch_tattn_bwd2<40, 8>(dq, lddq, dk, lddk, dv, lddv, q, ldq, k, ldk, v, ldv, dout, lddo, batch, frames, npix, heads, scale, st2);
+      if (dh == 80 && heads % 4 == 0) return launch_tattn_bwd2<80, 4>(dq, lddq, dk, lddk, dv, lddv, q, ldq, k, ldk, v, ldv, dout, lddo, batch, frames, npix, heads, scale, st2);
+      if (dh == 160 && heads % 2 == 0) return launch_tattn_bwd2<160, 2>(dq, lddq, dk, lddk, dv, lddv, q, ldq, k, ldk, v, ldv, dout, lddo, batch, frames, npix, heads, scale, st2);
+    }
   }
   const size_t lds = ((size_t)4 * frames * dh + (size_t)2 * frames * frames) * sizeof(float);
   if (lds > 150 * 1024) { me_set_error("me_tattn_bwd: frames * head dim too large for the LDS tile"); return ME_EINVAL; }

@@ -693,7 +693,7 @@ def test_groupnorm_bwd(ops, C, rpg, nsg, silu):
     assert torch.equal(got, ops.groupnorm_bwd(cu(x), cu(gm), cu(bt), cu(dy), rows_per_group=rpg, eps=1e-5, silu=silu))   # fixed-order sums: bitwise reproducible
 
 
-@pytest.mark.parametrize("F,dh,npix", [(24, 40, 5), (8, 80, 3), (16, 160, 2), (24, 160, 2), (48, 160, 1)])   # the last two need > 64 KB of LDS
+@pytest.mark.parametrize("F,dh,npix", [(24, 40, 5), (8, 80, 3), (16, 160, 2), (24, 160, 2), (48, 160, 1), (7, 40, 4), (32, 80, 2), (1, 40, 3), (24, 80, 70)])   # F <= 32: the lane-parallel kernel; 48: the first version
 def test_temporal_attention_bwd(ops, F, dh, npix):
     g = torch.Generator().manual_seed(9)
     B, C = 2, 8 * dh
