@@ -23,6 +23,7 @@ python tools/rocpd_summary.py $(find gpurun_out/${tag}_prof -name "*.db" | head 
 ( cd /tmp && timeout 1200 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${tag}_pmc_w -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-overlap > $R/gpurun_out/${tag}_pmc_w.log 2>&1 )
 python tools/pmc_summary.py $(find gpurun_out/${tag}_pmc_f -name "*.db" | head -1) $(find gpurun_out/${tag}_pmc_w -name "*.db" | head -1) gpurun_out/${tag}_pmc_hbm.csv gpurun_out/${tag}_pmc_traffic.json 3 >> gpurun_out/${tag}_summary.txt 2>&1
 timeout 600 python tools/kbench.py gemm attn misc bwd > gpurun_out/${tag}_kbench.txt 2>&1
+timeout 300 python tools/kbench.py gemm8p > gpurun_out/${tag}_kbench_8p.txt 2>&1
 # secondary measurements: null-text inner iteration, other shapes, the frame-sharded path on one rank (eager / captured)
 timeout 400 python bench.py --null-text --steps 3 --warmup 1 > gpurun_out/${tag}_nulltext.log 2>&1; tail -1 gpurun_out/${tag}_nulltext.log > gpurun_out/${tag}_bench_nulltext.json
 timeout 300 python bench.py --frames 8 --latent 32 --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_8f_256.json
