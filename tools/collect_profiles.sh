@@ -28,8 +28,8 @@ timeout 300 python tools/kbench.py gemm8p > gpurun_out/${tag}_kbench_8p.txt 2>&1
 timeout 400 python bench.py --null-text --steps 3 --warmup 1 > gpurun_out/${tag}_nulltext.log 2>&1; tail -1 gpurun_out/${tag}_nulltext.log > gpurun_out/${tag}_bench_nulltext.json
 timeout 300 python bench.py --frames 8 --latent 32 --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_8f_256.json
 timeout 600 python bench.py --frames 48 --latent 96 --steps 2 --warmup 1 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_48f_768.json
-timeout 300 python bench.py --parallel frames --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_frames1_graph.json
-timeout 300 python bench.py --parallel frames --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_frames1_eager.json
+timeout 300 python bench.py --parallel frames --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | grep '^{' | tail -1 > gpurun_out/${tag}_bench_frames1_graph.json
+timeout 300 python bench.py --parallel frames --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | grep '^{' | tail -1 > gpurun_out/${tag}_bench_frames1_eager.json
 timeout 300 python bench.py --no-overlap --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_no_overlap.json
 timeout 300 python bench.py --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_graph.json
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${tag}_prof_nt -o r -- python $R/bench.py --null-text --steps 1 --warmup 1 > $R/gpurun_out/${tag}_rocprof_nt.log 2>&1 )

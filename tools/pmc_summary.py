@@ -21,6 +21,9 @@ def short(k: str):
     m = re.search(r"(attn2_kernel)<(\d+), (\d+), (\d+)", k)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>"
+    m = re.search(r"(gemm8p_kernel)<(\d+), (\d+), (true|false)", k)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>"
     m = re.search(r"(gemm_kernel)<(\d+), (\d+)", k)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
@@ -45,7 +48,7 @@ with open(out_csv, "w", newline="") as fh:
     for k, n, f_kb, w_kb in rows[:40]:
         per = (2 * f_kb + w_kb) * 1024 / n
         w.writerow([k, n, f"{f_kb:.0f}", f"{w_kb:.0f}", f"{per:.0f}", f"{(2 * f_kb + w_kb) * 1024 / steps / 1e9:.2f}"])
-        for name in (short(k), "gemm" if ("gemm_kernel" in k or "conv3_halo_kernel" in k) else None):
+        for name in (short(k), "gemm" if ("gemm_kernel" in k or "gemm8p_kernel" in k or "conv3_halo_kernel" in k) else None):
             if name:
                 d = fam.setdefault(name, [0, 0.0])
                 d[0] += n
