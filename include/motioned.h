@@ -368,7 +368,9 @@ int me_layernorm_bwd_params(float* dgamma, float* dbeta, const void* x, int32_t 
 int64_t me_layernorm_bwd_params_work_bytes(int64_t rows, int32_t C);
 /* dst[r, c] += alpha * src[r, c] on an fp32 [rows, cols] view (src fp32 or fp16): the gradient accumulation of the reverse-mode tape.
  * pool_h, pool_w > 0: dst pixel (img, y, x) of a pool_h x pool_w grid collects the 2 x 2 block (2y + a, 2x + b) of the 2 pool_h x 2 pool_w
- * source grid -- the input gradient of the nearest-2x upsample in front of a convolution (resnet_2d.py:77) */
+ * source grid -- the input gradient of the nearest-2x upsample in front of a convolution (resnet_2d.py:77).
+ * src_is_f16: bit 0 = src is fp16 (else fp32); bit 1 = STORE, dst = alpha * src without reading dst -- the first contribution to a gradient
+ * buffer that was allocated but never zeroed (saves the fill and the read) */
 int me_grad_acc(void* dst, int32_t lddst, const void* src, int32_t ldsrc, int32_t src_is_f16, int64_t rows, int32_t cols, float alpha, int32_t pool_h, int32_t pool_w,
                 void* stream);
 /* out = {sum x^2, max |x|} of an fp32 vector (gradient-norm clipping, loss, loss-scale selection); work: me_sumsq_work_bytes() bytes */

@@ -39,6 +39,9 @@ class Tape:
         self.keep.extend(outs)
 
 
+_POISON = bool(__import__("os").environ.get("ME_GRAD_POISON"))   # tests: never-zeroed gradient buffers start as NaN, so a read before the first store shows
+
+
 def _base(t: torch.Tensor) -> torch.Tensor:
     """The allocation `t` lives in.  Operator outputs are fresh contiguous 2-D allocations (or `out=` views of one) on the GPU;
     the CPU emulation sometimes returns a view of a permuted temporary -- such a tensor counts as its own allocation."""
@@ -53,6 +56,7 @@ class Grads:
     def __init__(self, backend, trainable: Optional[Dict[int, str]] = None, param_buffers: Optional[Dict[str, torch.Tensor]] = None):
         self.B = backend
         self.buf: Dict[int, torch.Tensor] = {}
+        self.fresh: set = set()                       # ids of allocations whose buffer exists but holds nothing yet (first-touch store pending)
         self.keep: List[torch.Tensor] = []
         self.trainable = trainable or {}              # id(packed parameter tensor) -> its key in weights.Packed.cache
         self.params: Dict[str, torch.Tensor] = param_buffers if param_buffers is not None else {}   # key -> fp32 gradient in the packed layout
@@ -72,25 +76,50 @@ class Grads:
     def has(self, t: torch.Tensor) -> bool:
         return id(_base(t)) in self.buf
 
-    def view(self, t: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _whole(t: torch.Tensor, b: torch.Tensor) -> bool:
+        return b is t or (t.shape == b.shape and t.stride() == b.stride() and t.storage_offset() == b.storage_offset())
+
+    def view(self, t: torch.Tensor, first_store: bool = False) -> torch.Tensor:
+        """The part of its allocation's gradient buffer that `t` covers.  Buffers are zeroed at their first touch -- unless the caller says the
+        touch STORES the whole buffer (`first_store`, and `t` is the whole allocation): then the buffer is allocated uninitialised and marked
+        fresh until `take_fresh` hands the store permission out; any other touch of a fresh buffer zeroes it first."""
         b = _base(t)
         g = self.buf.get(id(b))
+        whole = self._whole(t, b)
         if g is None:
-            g = torch.zeros(b.shape, dtype=torch.float32, device=b.device)
+            if first_store and whole:
+                g = torch.full(b.shape, float("nan"), dtype=torch.float32, device=b.device) if _POISON else torch.empty(b.shape, dtype=torch.float32, device=b.device)
+                self.fresh.add(id(b))
+            else:
+                g = torch.zeros(b.shape, dtype=torch.float32, device=b.device)
             self.buf[id(b)] = g
             self.keep.append(b)          # keeps id(b) unique for the life of the buffers
+        elif id(b) in self.fresh and not (first_store and whole):
+            g.zero_()
+            self.fresh.discard(id(b))
         if b is t:
             return g
         return g.as_strided(t.shape, t.stride(), t.storage_offset() - b.storage_offset())
 
+    def take_fresh(self, t: torch.Tensor) -> bool:
+        """True exactly once for a buffer `view(t, first_store=True)` left uninitialised: the caller now stores ALL of it."""
+        i = id(_base(t))
+        if i in self.fresh:
+            self.fresh.discard(i)
+            return True
+        return False
+
     def add(self, t: Optional[torch.Tensor], g: torch.Tensor, alpha: float = 1.0) -> None:
         if t is None:
             return
-        v = self.view(t)
+        covers = (g.dim() == 2 and t.dim() == 2 and g.shape[0] >= t.shape[0] and g.shape[1] >= t.shape[1]) or (g.dim() != 2 and g.numel() == t.numel())
+        v = self.view(t, first_store=covers)
+        store = covers and self.take_fresh(t)
         if g.dim() == 2 and v.dim() == 2:
-            self.B.grad_acc(v[:g.shape[0], :g.shape[1]], g, alpha)
+            self.B.grad_acc(v[:g.shape[0], :g.shape[1]], g, alpha, None, store)
         else:
-            self.B.grad_acc(v, g.reshape(v.shape), alpha)
+            self.B.grad_acc(v, g.reshape(v.shape), alpha, None, store)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -122,7 +151,9 @@ def _rule_gemm(B, x, w, out, kw):
             B.gemm_dw(dpre, x, dst=G.param(w), taps=taps, K=K, M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
         if G.wants(kw.get("bias")):
             B.colsum_grad(dpre[:M], dst=G.param(kw["bias"]))
-        B.gemm_dx(dpre, w, dst=G.view(x[:, :K]), M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"))
+        xv = x[:, :K]
+        dst = G.view(xv, first_store=True)
+        B.gemm_dx(dpre, w, dst=dst, M=M, alpha=alpha, conv=kw.get("conv"), tconv=kw.get("tconv"), store=G.take_fresh(xv))
     return rule
 
 

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void grad_acc_kernel(float* dst, int lddst, co
     const int c = (int)(idx - r * vpr) * 4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     auto add = [&](long sr) {
-      if (is_f16) {
+      if (is_f16 & 1) {
         U64 u;
         u.u = *reinterpret_cast<const uint2*>(reinterpret_cast<const f16*>(src) + sr * ldsrc + c);
         acc.x += (float)u.e[0]; acc.y += (float)u.e[1]; acc.z += (float)u.e[2]; acc.w += (float)u.e[3];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void grad_acc_kernel(float* dst, int lddst, co
       add(r);
     }
     float4* d = reinterpret_cast<float4*>(dst + r * lddst + c);
-    float4 o = *d;
+    float4 o = (is_f16 & 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *d;   // bit 1: first touch of the buffer -- store, do not read
     o.x += alpha * acc.x; o.y += alpha * acc.y; o.z += alpha * acc.z; o.w += alpha * acc.w;
     *d = o;
   }
@@ -449,7 +449,7 @@ extern "C" int me_layernorm_bwd_params(float* dgamma, float* dbeta, const void* 
 
 extern "C" int me_grad_acc(void* dst, int32_t lddst, const void* src, int32_t ldsrc, int32_t src_is_f16, int64_t rows, int32_t cols, float alpha, int32_t pool_h,
                            int32_t pool_w, void* stream) {
-  if (!dst || !src || rows <= 0 || cols <= 0 || cols % 4 || lddst % 4 || ldsrc % 4 || (((uintptr_t)dst | (uintptr_t)src) & (src_is_f16 ? 7 : 15)) || ((uintptr_t)dst & 15)) {
+  if (!dst || !src || rows <= 0 || cols <= 0 || cols % 4 || lddst % 4 || ldsrc % 4 || (((uintptr_t)dst | (uintptr_t)src) & ((src_is_f16 & 1) ? 7 : 15)) || (src_is_f16 & ~3) || ((uintptr_t)dst & 15)) {
     me_set_error("me_grad_acc: bad arguments (cols and strides multiples of 4, aligned pointers)");
     return ME_EINVAL;
   }

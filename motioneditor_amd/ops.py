@@ -450,13 +450,14 @@ def _chk_grad(t: torch.Tensor, name: str) -> None:
         raise ValueError(f"{name}: expected a CUDA fp32 2-D gradient view with unit column stride, got {t.dtype} {tuple(t.shape)} {t.stride()}")
 
 
-def grad_acc(dst: torch.Tensor, src: torch.Tensor, alpha: float = 1.0, pool: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+def grad_acc(dst: torch.Tensor, src: torch.Tensor, alpha: float = 1.0, pool: Optional[Tuple[int, int]] = None, store: bool = False) -> torch.Tensor:
     """dst (fp32 view) += alpha * src (fp32 or fp16, at least dst's rows x cols; pool=(H, W): src holds the 2H x 2W grid whose 2 x 2 blocks
-    are summed into dst's H x W pixels).  1-D / n-D contiguous operands are treated as one row."""
+    are summed into dst's H x W pixels).  1-D / n-D contiguous operands are treated as one row.  store=True: dst = alpha * src (dst is not
+    read: the first contribution to a gradient buffer that was never zeroed)."""
     if dst.dim() != 2:
         if not (dst.is_contiguous() and src.is_contiguous() and dst.numel() == src.numel() and dst.numel() % 4 == 0):
             raise ValueError("grad_acc: non-2-D operands must be contiguous, of equal size and a multiple of 4 elements")
-        return grad_acc(dst.reshape(1, -1), src.reshape(1, -1), alpha).reshape(dst.shape)
+        return grad_acc(dst.reshape(1, -1), src.reshape(1, -1), alpha, None, store).reshape(dst.shape)
     _chk_grad(dst, "grad_acc.dst")
     if src.dtype not in (torch.float32, F16) or src.dim() != 2 or src.stride(1) != 1:
         raise ValueError("grad_acc: src must be an fp32 / fp16 2-D view with unit column stride")
@@ -464,7 +465,7 @@ def grad_acc(dst: torch.Tensor, src: torch.Tensor, alpha: float = 1.0, pool: Opt
     if src.shape[1] < cols or src.shape[0] < (4 * rows if pool else rows):
         raise ValueError(f"grad_acc: src {tuple(src.shape)} does not cover dst {tuple(dst.shape)}")
     ph, pw = pool if pool else (0, 0)
-    capi.check(capi.lib().me_grad_acc(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), 1 if src.dtype == F16 else 0, rows, cols, float(alpha), ph, pw,
+    capi.check(capi.lib().me_grad_acc(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), (1 if src.dtype == F16 else 0) | (2 if store else 0), rows, cols, float(alpha), ph, pw,
                                       _stream()), "me_grad_acc")
     return dst
 
@@ -479,11 +480,12 @@ def _f16(dy: torch.Tensor, cols: int) -> torch.Tensor:
     return d16
 
 
-def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None):
+def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None, store=False):
     """dst (fp32 view of dX, [x_rows, K]) += the input gradient of me_gemm's y = alpha * gather(x) @ w^T.  me_gemm itself on the
     [K][taps reversed][N] weights: a dense GEMM, the stride-1 3x3 correlation / TemporalConv with reversed taps; the stride-2
     convolution's input gradient is that correlation over the ZERO-STUFFED dy (gather mode ups = 2), the nearest-upsampled
-    convolution's the 2 x 2 block sum of it (me_grad_acc's pooling).  dy arrives loss-scaled and is cast to fp16 like every activation."""
+    convolution's the 2 x 2 block sum of it (me_grad_acc's pooling).  dy arrives loss-scaled and is cast to fp16 like every activation.
+    store=True: dst was never written (nor zeroed) -- this product is its first contribution and is stored."""
     N, taps, K = w.shape
     wt = _w_transposed(w)
     d16 = _f16(dy[:M], wt.shape[2])
@@ -505,7 +507,10 @@ def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None):
     else:
         du = gemm(d16, wt, alpha=alpha)
     rows = du.shape[0] // 4 if pool else du.shape[0]
-    grad_acc(dst[:rows], du, 1.0, pool)
+    if store and (rows < dst.shape[0] or du.shape[1] < dst.shape[1]):   # the product does not cover the whole (never zeroed) buffer
+        dst.zero_()
+        store = False
+    grad_acc(dst[:rows], du, 1.0, pool, store)
     return dst
 
 

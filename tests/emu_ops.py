@@ -292,7 +292,9 @@ def _leaf(t):
     return t.detach().float().clone().requires_grad_(True)
 
 
-def grad_acc(dst, src, alpha=1.0, pool=None):
+def grad_acc(dst, src, alpha=1.0, pool=None, store=False):
+    if store:   # the buffer was never written: whatever it holds (NaN under ME_GRAD_POISON) must not be read
+        dst.zero_()
     s_ = src.float()
     if pool is not None:
         H, W = pool
@@ -308,8 +310,10 @@ def invalidate_transposed(tensors=None):
     pass
 
 
-def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None):
+def gemm_dx(dy, w, *, dst, M, alpha=1.0, conv=None, tconv=None, store=False):
     """dst += dX of y = alpha * gather(x) @ w^T (any gather mode): linear in x, so the point of linearisation is irrelevant."""
+    if store:
+        dst.zero_()
     K = w.shape[2]
     x0 = torch.zeros((dst.shape[0], K), dtype=torch.float32, requires_grad=True)
     y = gemm(x0, w.float(), M=M, alpha=alpha, conv=conv, tconv=tconv)
