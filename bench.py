@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--null-text", action="store_true",
                     help="secondary measurement: inner iterations of the null-text optimisation (UNet forward on a tape + backward + Adam, batch 1)")
     ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
+    ap.add_argument("--no-cfg-prefix-sharing", action="store_true",
+                    help="execute the classifier-free-guidance prefix (conv_in .. first cross-attention queries) for both halves of the batch, as the reference does (A/B)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from Python -- "
                          "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
@@ -328,6 +330,7 @@ def main():
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (cfg), or for all ranks
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"], emu_dtype)
     pipe.overlap_controlnet = pipe.overlap_adapter = not (args.no_overlap or args.emulate)
+    pipe.dedup_cfg_prefix = not args.no_cfg_prefix_sharing
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
     if shard is not None:   # this rank's frames only
@@ -433,7 +436,8 @@ def main():
                "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
                           "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
-                          "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
+                          "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
+                          "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
                           "hip_graph_replay": bool(use_graph), "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,

@@ -29,6 +29,10 @@ class MutualSelfAttentionControl(MutualAttentionBase):
         self.step_idx = step_idx if step_idx is not None else list(range(start_step, total_steps))
 
 
+    def edits_next_self_attention(self) -> bool:
+        return self.cur_step in self.step_idx and self.cur_att_layer // 2 in self.layer_idx   # the gate of forward() (reference :434)
+
+
 class FullySelfAttentionControlMask(MutualSelfAttentionControl):
     def __init__(self, start_step=4, start_layer=10, layer_idx=None, step_idx=None, total_steps=50, thres=0.1,
                  ref_token_idx=[1], cur_token_idx=[1], mask_save_dir=None, model_type="SD", source_masks=None,

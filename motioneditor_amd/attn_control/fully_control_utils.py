@@ -43,6 +43,11 @@ class MutualAttentionBase:
             return call.run(*text_seg)
         return call.run(*segments.prev_cur(call.B, call.f, call.q.device, getattr(call, "shard", None)))
 
+    def edits_next_self_attention(self) -> bool:
+        """Will the NEXT self-attention call be edited (K/V injection)?  The UNet graph asks before it shares the classifier-free-guidance
+        prefix between batch entries (an edited layer needs the full (recon, edit) x (uncond, cond) batch).  The base class never edits."""
+        return False
+
     def reset(self):
         self.cur_step = 0
         self.cur_att_layer = 0

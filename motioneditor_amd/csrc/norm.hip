@@ -345,15 +345,17 @@ static int gn_validate(const me_groupnorm_args* a) {
   return ME_OK;
 }
 
-// chunk geometry of the statistics pass (shared by me_groupnorm_scratch_bytes): ~1024 blocks in total, at most 512 per sample-group
+// chunk geometry of the statistics pass (shared by me_groupnorm_scratch_bytes).  A function of rows_per_group ALONE: the statistics of a
+// sample must not depend on how many samples share the launch (the UNet graph runs the first blocks on half the batch when the
+// classifier-free-guidance halves are copies of each other, and the step has to stay bitwise the same).
 static void gn_chunks(const me_groupnorm_args* a, int* chunks_out, int* chunk_rows_out) {
-  const int nsg = a->rows / a->rows_per_group;
-  int chunks = 1024 / nsg;
-  if (chunks > 512) chunks = 512;
-  if (chunks < 1) chunks = 1;
-  int chunk_rows = (a->rows_per_group + chunks - 1) / chunks;
-  if (chunk_rows < 8) chunk_rows = 8;
-  chunks = (a->rows_per_group + chunk_rows - 1) / chunk_rows;
+  // large groups (the five-dimensional GroupNorm of the upper levels, few samples per launch): ~256 chunks per sample;
+  // small groups (per-frame statistics, many samples per launch): ~16
+  const int big = a->rows_per_group > 4096;
+  int chunk_rows = (a->rows_per_group + (big ? 255 : 15)) / (big ? 256 : 16);
+  if (chunk_rows < 24) chunk_rows = 24;
+  if (chunk_rows > (big ? 384 : 256)) chunk_rows = big ? 384 : 256;
+  const int chunks = (a->rows_per_group + chunk_rows - 1) / chunk_rows;
   *chunks_out = chunks;
   *chunk_rows_out = chunk_rows;
 }

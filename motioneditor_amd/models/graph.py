@@ -62,10 +62,11 @@ class AttnCall:
     nk: int          # keys per kv item (N for self, 77 for text)
     is_cross: bool
     shard: object = None   # parallel.FrameShard: k/v are then the all-gather of every rank's frames (part-major items)
+    q_items: int = 0       # > 0: q holds that many query items; item i reads item i % q_items (queries shared by the CFG halves, unet_forward)
 
     def run(self, seg_item: torch.Tensor, seg_mode: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         return ops.attention(self.q, self.k, self.v, heads=HEADS, dh=self.dh, n_items=self.B * self.f, nq=self.N, nk=self.nk,
-                             seg_item=seg_item, seg_mode=seg_mode, mask=mask)
+                             seg_item=seg_item, seg_mode=seg_mode, mask=mask, **({"q_items": self.q_items} if self.q_items else {}))
 
 
 @dataclass
@@ -200,8 +201,11 @@ def _ext_rows(x: "Act", shard) -> int:
 
 
 def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_seg, *, spatial, temporal, place: str,
-                sc_attn: bool, has_temp: bool, shard=None, text_kv: Optional[torch.Tensor] = None) -> Act:
-    """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C]."""
+                sc_attn: bool, has_temp: bool, shard=None, text_kv: Optional[torch.Tensor] = None, expand: int = 1) -> Act:
+    """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C].
+    expand > 1 (unet_forward's CFG prefix): x holds B / expand distinct batch entries -- entry b + k B / expand of the full batch would be a
+    bit-for-bit copy of entry b up to the text cross-attention -- so attn1 runs once per distinct entry, attn2 reads the shared queries
+    (q_items) against every entry's own text keys, and its output projection adds the shared residual (res_rows): from there on the batch is full."""
     t, C = x.t, x.C
     dh = C // HEADS
     # --- attn1 (MotionFrameAttention / patched closure, attention_2d.py:705-768, fully_control_utils.py:113-161)
@@ -217,16 +221,20 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
         a = call.run(*segments.self_items(x.B * x.f, t.device))
     t = ops.gemm(a, P.mat(p + ".attn1.to_out.0.weight"), bias=P.vec(p + ".attn1.to_out.0.bias"), res=t)
     # --- attn2 (CrossAttention, attention_2d.py:115-201): K/V projected once per text row
+    if expand > 1 and text is None:
+        raise ValueError("basic_block: expand needs the text cross-attention (that is where the batch entries start to differ)")
     if text is not None:
         q = ops.gemm(_ln(P, p + ".norm2", t), P.mat(p + ".attn2.to_q.weight"))
         # k | v of the text rows: this block's column slice of the one GEMM that projects the text for every layer (text_kv_all), or its own
         kv = text_kv if text_kv is not None else ops.gemm(text, P.fused([p + ".attn2.to_k.weight", p + ".attn2.to_v.weight"]))
-        call = AttnCall(q, kv[:, :C], kv[:, C:], x.B, x.f, x.N, dh, 77, True)
+        call = AttnCall(q, kv[:, :C], kv[:, C:], x.B * expand, x.f, x.N, dh, 77, True, None, x.B * x.f if expand > 1 else 0)
         if spatial is not None:
             a = spatial(call=call, is_cross=True, place_in_unet=place, num_heads=HEADS, text_seg=text_seg)
         else:
             a = call.run(*text_seg)
-        t = ops.gemm(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t)
+        t = ops.gemm(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t, **({"res_rows": t.shape[0]} if expand > 1 else {}))
+        if expand > 1:
+            x = Act(t, x.B * expand, x.f, x.h, x.w)
     # --- feed-forward (attention_2d.py:531)
     t = feed_forward(P, p + ".ff", _ln(P, p + ".norm3", t), t)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
@@ -237,14 +245,16 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
 
 
 def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, temporal=None, place: str = "", sc_attn: bool = True,
-                  has_temp: bool = True, shard=None, out: Optional[torch.Tensor] = None, text_kv: Optional[dict] = None) -> Act:
+                  has_temp: bool = True, shard=None, out: Optional[torch.Tensor] = None, text_kv: Optional[dict] = None, expand: int = 1) -> Act:
     """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out.
     out: where the block's result is written (a column slice of the next skip-concat buffer)."""
     n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
     t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
     t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
-                    sc_attn=sc_attn, has_temp=has_temp, shard=shard, text_kv=None if text_kv is None else text_kv[p]).t
-    return x.like(ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t, **({} if out is None else {"out": out})))
+                    sc_attn=sc_attn, has_temp=has_temp, shard=shard, text_kv=None if text_kv is None else text_kv[p], expand=expand).t
+    y = ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t, **({} if out is None else {"out": out}),
+                 **({"res_rows": x.t.shape[0]} if expand > 1 else {}))
+    return Act(y, x.B * expand, x.f, x.h, x.w)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -384,10 +394,16 @@ def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
 
 def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *, down_res: Optional[Sequence[torch.Tensor]] = None,
                  mid_res: Optional[torch.Tensor] = None, two_branch: bool = False, spatial=None, temporal=None,
-                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False, res_ready=None, side_stream=None) -> Act:
+                 taps: Optional[dict] = None, shard=None, normal_infer: bool = False, res_ready=None, side_stream=None, cfg_dup: bool = False) -> Act:
     """sample: fp32 [B,4,f,h,w] (reference layout).  down_res: 12 row tensors [(2 f N_i), C_i] (two_branch,
     ControlNet batch = the two edit rows) or [(B f N_i), C_i]; mid_res rows [(2|B f N_3), 1280].
-    Returns eps rows [(B f N), 4] as an Act."""
+    Returns eps rows [(B f N), 4] as an Act.
+
+    cfg_dup: the caller guarantees sample[B/2:] is a copy of sample[:B/2] (the pipeline's `torch.cat([latents] * 2)` for classifier-free
+    guidance, pipeline_motion_editor.py:605).  The two halves then differ only through the text embedding, which first enters at the
+    cross-attention of down_blocks.0.attentions.0: conv_in, the first resnet, that block's GroupNorm / proj_in / self-attention and the
+    cross-attention's query projection are bit-for-bit the same work for both halves and are run ONCE (B / 2 entries); the rest of the graph
+    sees the full batch.  The outputs are bitwise those of the un-shared graph (every kernel treats batch entries independently)."""
     B, _, f, h, w = sample.shape
     dev = sample.device
     sample = sample.contiguous().float()
@@ -399,8 +415,12 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     kw = dict(spatial=spatial, temporal=temporal, shard=shard, sc_attn=not normal_infer,   # shard: this rank holds f = f_total / world consecutive frames
               text_kv=text_kv_all(P, text, attention_block_names(True)))
 
-    x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=B * f, Cin=4, H=h, Wd=w,
-                           img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), B, f, h, w)
+    # the CFG prefix (docstring): only when the spatial editor leaves the first self-attention alone (it does for start_layer > 0), un-sharded, not recording
+    share = (cfg_dup and B % 2 == 0 and shard is None and DOWN_HAS_ATTN[0] and not getattr(ops, "recording", False) and
+             (spatial is None or (hasattr(spatial, "edits_next_self_attention") and not spatial.edits_next_self_attention())))
+    Bp = B // 2 if share else B
+    x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=Bp * f, Cin=4, H=h, Wd=w,
+                           img_stride=4 * f * h * w, ch_stride=f * h * w, frames=f, frame_stride=h * w), Bp, f, h, w)
     # Adapter block i needs skip i and ControlNet residual i only, and its output is consumed by the UP path: with a side
     # stream (the one ControlNet ran on, so the residuals are ordered) every block is enqueued there as soon as its skip
     # exists and runs beside the rest of the down path and the mid block; the skips themselves are updated after the
@@ -427,13 +447,19 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 motion.append(adapter_for(len(skips) - 1, s))
 
     skips: List[Act] = []
-    push_skip(x)
+    if share:   # skip 0 (the up path's last concat and the adapter's first block read all B entries): the shared rows, twice
+        full = torch.empty((B * f * h * w, x.C), dtype=x.t.dtype, device=dev)
+        ops.copy_rows(full[:x.t.shape[0]], x.t)
+        ops.copy_rows(full[x.t.shape[0]:], x.t)
+        push_skip(Act(full, B, f, h, w))
+    else:
+        push_skip(x)
     for i in range(4):
         for j in range(2):
             n = f"down_blocks.{i}.resnets.{j}"
             x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
             if DOWN_HAS_ATTN[i]:
-                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", **kw)
+                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", expand=2 if (share and i == 0 and j == 0) else 1, **kw)
             push_skip(x)
         if i < 3:
             x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)

@@ -70,7 +70,7 @@ class UNet2DConditionModel(ModuleShims):
         return ops.nchw5_to_rows(res.to(self.device))
 
     def forward_rows(self, sample, timestep, encoder_hidden_states, down_rows=None, mid_rows=None, two_branch=False, taps=None, shard=None,
-                     normal_infer: bool = False, res_ready=None, side_stream=None) -> graph.Act:
+                     normal_infer: bool = False, res_ready=None, side_stream=None, cfg_dup: bool = False) -> graph.Act:
         t = float(timestep.item() if torch.is_tensor(timestep) else timestep)
         # normal_infer = the plain SD forward of the inversion (attention_2d.py:770-777 bypasses the patched closures' edits):
         # registered editors neither act nor count there, so a later denoising run starts from un-advanced counters
@@ -78,7 +78,7 @@ class UNet2DConditionModel(ModuleShims):
         temporal = None if normal_infer else self.temporal_editor
         return graph.unet_forward(self.P, sample.to(self.device), t, encoder_hidden_states.to(self.device), down_res=down_rows, mid_res=mid_rows,
                                   two_branch=two_branch, spatial=spatial, temporal=temporal, taps=taps, shard=shard,
-                                  normal_infer=normal_infer, res_ready=res_ready, side_stream=side_stream)
+                                  normal_infer=normal_infer, res_ready=res_ready, side_stream=side_stream, cfg_dup=cfg_dup)
 
     def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None, return_dict: bool = True,
                 normal_infer: bool = False, skeleton=None, down_block_additional_residuals=None, mid_block_additional_residual=None,

@@ -49,6 +49,10 @@ class MotionEditorPipeline:
         # identical latents, images and prompt pattern and produce identical residuals: compute one, use it twice.
         # Set False to execute the redundant second entry exactly as the reference does.
         self.dedup_controlnet = True
+        # `torch.cat([latents] * 2)` (:605) makes the conditional half of the UNet batch a copy of the unconditional half until the text enters
+        # (the cross-attention of the first transformer block): that prefix is computed once (graph.unet_forward, cfg_dup).  Exact -- the
+        # step's output is bitwise the same; False executes the duplicated prefix as the reference does.
+        self.dedup_cfg_prefix = True
         # ControlNet feeds the UNet only after its down path (the adapter consumes the residuals, unet_2d_condition.py:477-494):
         # run it on a second HIP stream beside the UNet's down blocks; its small grids (24-frame batch) fill CUs the
         # UNet's tile tails leave idle.  The adapter then runs on the same side stream beside the mid block (tiny grids),
@@ -280,7 +284,8 @@ class MotionEditorPipeline:
             if taps is not None:
                 taps["cn_down"], taps["cn_mid"] = [d.clone() for d in down], mid.clone()
         eps = self.unet.forward_rows(x4, t, text_embeddings_input, down, mid, two, taps, res_ready=ready,
-                                     side_stream=self._side_stream if (ready is not None and self.overlap_adapter) else None)   # :632-640
+                                     side_stream=self._side_stream if (ready is not None and self.overlap_adapter) else None,
+                                     cfg_dup=self.dedup_cfg_prefix and nb * 2 == x4.shape[0])   # :632-640
         if taps is not None:
             taps["eps_rows"] = eps.t.clone()
         ca, cb = self.scheduler.coeffs(int(t))
@@ -319,7 +324,7 @@ class MotionEditorPipeline:
             mode = ("single",)
             step = lambda lat, emb: self.denoise_step(lat, t, emb, images, guidance_scale, controlnet_conditioning_scale)   # noqa: E731
         key = (mode, tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr()),
-               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.overlap_controlnet, self.overlap_adapter)
+               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter)
         ca, cb = self.scheduler.coeffs(int(t))
         host = torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32)
         ent = self._graphs.get(key)

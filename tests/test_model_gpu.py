@@ -183,6 +183,30 @@ def test_denoise_step_24_frames_16x16_vs_cpu_oracle(unet, controlnet, unet_sd_to
     assert e <= STEP_TOL, e
 
 
+def test_cfg_prefix_sharing_is_bitwise_exact(unet, controlnet):
+    """pipeline.dedup_cfg_prefix: conv_in, the first resnet and the first transformer block up to its text cross-attention run once for the
+    unconditional / conditional copies of the latents (graph.unet_forward, cfg_dup) -- shared queries in me_attn, shared residual rows in
+    the GEMM epilogues.  The step must equal the one that executes the duplicated prefix BIT FOR BIT, with the editors inactive and active,
+    at 8 and at 24 frames."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    for f, hw, step in ((8, 8, 0), (8, 8, 4), (24, 16, 4)):
+        x = step_inputs(f=f, h=hw, w=hw)
+        images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * hw, 8 * hw).cuda()
+        emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+        pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+        pipe.scheduler.set_timesteps(50)
+        outs = []
+        for share in (True, False):
+            sed, ted = editors(unet, x["masks"])
+            sed.cur_step = ted.cur_step = step
+            pipe.dedup_cfg_prefix = share
+            outs.append(pipe.denoise_step(x["latents"].cuda(), pipe.scheduler.timesteps[step], emb, images, 7.5).clone())
+            assert (sed.cur_step, sed.cur_att_layer) == (step + 1, 0)
+        unet.spatial_editor = unet.temporal_editor = None
+        assert torch.equal(outs[0], outs[1]), (f, hw, step, rel_l2(outs[0], outs[1]))
+
+
 def test_graph_replay_six_steps_equals_eager(unet, controlnet):
     """denoise_step_graphed (one captured hipGraph per editor gating, device-resident step scalars) over steps 0..5 --
     across the editors' start at step 4, with a different unconditional embedding and timestep every step -- must

@@ -54,6 +54,19 @@ def test_denoise_step_matches_oracle(monkeypatch, unet_sd_np, cn_sd_np, unet_sd_
     pipe.scheduler.set_timesteps(50)
     assert pipe.scheduler.timesteps == ddim.timesteps
     emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]])
+    assert pipe.dedup_cfg_prefix      # the classifier-free-guidance prefix is computed once by default
     got = pipe.denoise_step(x["latents"], t, emb, images, 7.5)
     assert max_rel(got, want) < 2e-4
     assert (sed.cur_step, ted.cur_step) == (step + 1, step + 1)
+    # the duplicated prefix executed as the reference does: the same step (on the GPU bitwise, test_model_gpu.py; here up to BLAS blocking)
+    pipe.dedup_cfg_prefix = False
+    ted.cur_step = sed.cur_step = step
+    got2 = pipe.denoise_step(x["latents"], t, emb, images, 7.5)
+    assert max_rel(got2, got) < 1e-5
+    # an editor that edits from layer 0 on keeps the full batch in the first block too
+    pipe.dedup_cfg_prefix = True
+    sed0 = FullySelfAttentionControlMask(start_step=4, start_layer=0, source_masks=x["masks"])
+    regiter_fully_attention_editor_diffusers(pipe, sed0)
+    sed0.cur_step = ted.cur_step = step
+    assert sed0.edits_next_self_attention() == (step >= 4)
+    pipe.denoise_step(x["latents"], t, emb, images, 7.5)
