@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 4
+#define ME_ABI_VERSION 5
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -91,9 +91,18 @@ typedef struct me_gemm_args {
   int32_t res_rows;   /* > 0: res holds res_rows rows and output row m reads row m % res_rows (a residual shared by several batch entries,
                          e.g. the adapter's ControlNet-only half broadcast over the edit rows); 0: row m reads row m */
   int32_t res2_rows;  /* the same for res2 */
+  /* Optional split-K scratch (ABI 5).  Grids too small to fill the chip (the 8 x 8-latent level, batch-1 backward passes) are split along K:
+   * every split stores fp32 partial sums into `work`, a second kernel adds them in a fixed order and applies the epilogue.  work: device
+   * memory of at least me_gemm_work_bytes(a) bytes, 16-byte aligned, or NULL (never split).  splits_ is set by me_gemm itself. */
+  void* work;
+  int64_t work_bytes;
+  int32_t splits_;
+  int32_t reserved_;
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);
+/* bytes of `work` that me_gemm may use for these arguments (0: the launch is never split) */
+int64_t me_gemm_work_bytes(const me_gemm_args* a);
 
 /* ---- direct convolution for tiny channel counts (C_in < 8) --------------------------------- *
  * conv_in of the UNet / ControlNet on fp32 latents in the REFERENCE layout, and the first conv of

@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 4
+ABI_VERSION = 5
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -29,6 +29,7 @@ class GemmArgs(C.Structure):
         ("frame0", _i32), ("frames_total", _i32), ("halo_prev", _i32), ("halo_next", _i32),
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
         ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32), ("res_rows", _i32), ("res2_rows", _i32),
+        ("work", _vp), ("work_bytes", _i64), ("splits_", _i32), ("reserved_", _i32),
     ]
 
 
@@ -99,6 +100,7 @@ class LayerNormArgs(C.Structure):
 # every symbol include/motioned.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "me_abi_version": (C.c_int, []),
+    "me_gemm_work_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "me_last_error": (C.c_char_p, []),
     "me_last_kernel": (C.c_char_p, []),
     "me_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),

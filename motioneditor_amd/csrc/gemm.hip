@@ -114,8 +114,8 @@ __device__ __forceinline__ int src_row(const me_gemm_args& a, const RowInfo& r, 
 // The bias enters as the accumulators' initial value (bias / alpha, so that alpha * acc adds exactly the bias): its
 // loads happen before the K loop, when registers are free, and the epilogue never sees it.
 template <int NT, int MT, int WN>
-__device__ __forceinline__ void init_acc(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int n0, int wn, int lane) {
-  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+__device__ __forceinline__ void init_acc(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int n0, int wn, int lane, bool use_bias = true) {
+  const f16* __restrict__ bias = use_bias ? reinterpret_cast<const f16*>(a.bias) : nullptr;
   const int nb = n0 + wn * WN + (lane >> 4) * 4;
   const float inv_alpha = bias ? 1.0f / a.alpha : 0.f;
 #pragma unroll
@@ -457,8 +457,12 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
     }
   };
 
+  // split-K (me_gemm sets splits_ for small grids, STAGE_BUF only): blockIdx.y owns K tiles [it0, it1) and stores raw fp32 partial sums
+  const int S = STAGE == STAGE_BUF ? a.splits_ : 0;
+  const int it0 = S > 1 ? (int)((long)nit * blockIdx.y / S) : 0;
+  const int it1 = S > 1 ? (int)((long)nit * (blockIdx.y + 1) / S) : nit;
   f32x4 acc[NT][MT];
-  init_acc<NT, MT, WN>(a, acc, n0, wn, lane);
+  init_acc<NT, MT, WN>(a, acc, n0, wn, lane, S <= 1);
 
   const int frow = lane & 15;
   const int fg = lane >> 4;
@@ -513,8 +517,8 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
         xo[i] = sr < 0 ? OOB : (unsigned)(((long)(sr - brow) * a.ldx + scol) * 2);
       }
     };
-    int tap_l = 0, kc_l = 0;   // load cursor
-    set_tap_off(0);
+    int tap_l = it0 / nkc, kc_l = it0 - (it0 / nkc) * nkc;   // load cursor
+    set_tap_off(tap_l);
     auto gload = [&](int buf) {
       char* dx = reinterpret_cast<char*>(sX + buf * BM * LD) + wave * 1024;
       char* dw = reinterpret_cast<char*>(sW + buf * BN * LD) + wave * 1024;
@@ -530,11 +534,25 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
     };
     gload(0);
     __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-      const int buf = it & 1;
-      if (it + 1 < nit) gload(buf ^ 1);
+    for (int it = it0; it < it1; ++it) {
+      const int buf = (it - it0) & 1;
+      if (it + 1 < it1) gload(buf ^ 1);
       compute(buf);
       __syncthreads();  // LDS-DMA pending -> the compiler drains vmcnt(0) here: next slab landed, this slab free
+    }
+    if (S > 1) {   // raw partial sums: work[split][m][n], the lane's four consecutive columns as one 16-byte store
+      float* wk = reinterpret_cast<float*>(a.work) + (long)blockIdx.y * a.M * a.N;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int m = m0 + wm * WM + i * 16 + (lane & 15);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+          if (n < a.N) *reinterpret_cast<f32x4*>(wk + (long)m * a.N + n) = acc[j][i];
+        }
+      }
+      return;
     }
   } else if constexpr (STAGE == STAGE_GLDS) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -1025,6 +1043,72 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wc, lane, nullptr, 0);
 }
 
+// split-K second pass: C = epilogue(alpha * sum_s work[s] + bias ...) with the epilogue semantics of the one-pass kernels (no activation: round to
+// fp16, then add rowvec / res / res2 in fp16; with an activation: everything in fp32, one rounding)
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const me_gemm_args a) {
+  const int vpr = a.N / 4;
+  const long total = (long)a.M * vpr;
+  const float* __restrict__ wk = reinterpret_cast<const float*>(a.work);
+  const f16* __restrict__ bias = reinterpret_cast<const f16*>(a.bias);
+  const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
+  const f16* res = reinterpret_cast<const f16*>(a.res);
+  const f16* res2 = reinterpret_cast<const f16*>(a.res2);
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const long plane = (long)a.M * a.N;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int m = (int)(idx / vpr);
+    const int n = (int)(idx - (long)m * vpr) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(wk + (long)m * a.N + n);
+    for (int s_ = 1; s_ < a.splits_; ++s_) v += *reinterpret_cast<const f32x4*>(wk + s_ * plane + (long)m * a.N + n);
+    v *= a.alpha;
+    if (bias) {
+      U64 b;
+      b.u = *reinterpret_cast<const uint2*>(bias + n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += (float)b.e[r];
+    }
+    U64 rv, r1, r2, o;
+    if (rowvec) rv.u = *reinterpret_cast<const uint2*>(rowvec + (long)(m / a.rows_per_vec) * a.ldrv + n);
+    if (res) r1.u = *reinterpret_cast<const uint2*>(res + (long)(a.res_rows > 0 ? m % a.res_rows : m) * a.ldr + n);
+    if (res2) r2.u = *reinterpret_cast<const uint2*>(res2 + (long)(a.res2_rows > 0 ? m % a.res2_rows : m) * a.ldr2 + n);
+    if (a.act == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f16 h = (f16)v[r];
+        if (rowvec) h = h + rv.e[r];
+        if (res) h = h + r1.e[r];
+        if (res2) h = h + r2.e[r];
+        o.e[r] = h;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float f = v[r];
+        if (rowvec) f += (float)rv.e[r];
+        f = a.act == 1 ? fmaxf(f, 0.f) : silu_f(f);
+        if (res) f += (float)r1.e[r];
+        if (res2) f += (float)r2.e[r];
+        o.e[r] = (f16)f;
+      }
+    }
+    *reinterpret_cast<uint2*>(C + (long)m * a.ldc + n) = o.u;
+  }
+}
+
+// split-K decision (shared by me_gemm and me_gemm_work_bytes): small grids of the 128-row kernels with a long K loop.  `blocks` = tiles of the kernel
+// that would run; returns the number of K splits (1 = none).
+long split_below() {   // ME_GEMM_SPLITK: grids of fewer blocks than this are split along K (0 = never)
+  const char* e = getenv("ME_GEMM_SPLITK");
+  return e ? atol(e) : 400;
+}
+int choose_split(const me_gemm_args* a, long blocks, int nit) {
+  if (a->geglu || a->K % 64 || blocks >= split_below() || nit < 32) return 1;   // (a 20-tile K loop measured slower split than whole)
+  int S = (int)((640 + blocks - 1) / blocks);
+  if (S > 4) S = 4;
+  if (S > nit / 4) S = nit / 4;
+  return S < 2 ? 1 : S;
+}
+
 int stage_impl() {
   static int impl = -1;
   if (impl < 0) {
@@ -1116,10 +1200,25 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   }
   const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn), dim3(BM / WM * 128), lds, st, *a);
+  me_gemm_args b = *a;
+  b.splits_ = 0;
+  int S = 1;
+  if (STAGE == STAGE_BUF && a->work) {
+    const int nit = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
+    S = choose_split(a, (long)nbm * nbn, nit);
+    if ((int64_t)S * a->M * a->N * 4 > a->work_bytes || a->N % 4 || ((uintptr_t)a->work & 15)) S = 1;
+  }
+  if (S > 1) {
+    b.splits_ = S;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn, S), dim3(BM / WM * 128), lds, st, b);
+    const long vec = (long)a->M * (a->N / 4);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((vec + 255) / 256 < 4096 ? (vec + 255) / 256 : 4096)), dim3(256), 0, st, b);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, STAGE, WM>), dim3(nbm * nbn), dim3(BM / WM * 128), lds, st, b);
+  }
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>", BM, BN, STAGE == STAGE_REG ? ",reg" : "");
+    snprintf(nm, sizeof(nm), "gemm_kernel<%d,%d%s>%s", BM, BN, STAGE == STAGE_REG ? ",reg" : "", S > 1 ? "+splitk" : "");
     me_set_kernel(nm);
   }
   if (hipGetLastError() != hipSuccess) {
@@ -1180,6 +1279,16 @@ static int launch_conv_halo(const me_gemm_args* a, hipStream_t st) {
     return ME_EHIP;
   }
   return ME_OK;
+}
+
+extern "C" int64_t me_gemm_work_bytes(const me_gemm_args* a) {
+  // upper bound over the tile choices of the 128-row kernels (the smallest tile, 128 x 64, gives the most blocks and so the fewest splits: use the
+  // largest tile, 128 x 160, for the bound): 4 splits at most
+  if (!a || a->M <= 0 || a->N <= 0 || a->K <= 0 || a->geglu || a->K % 64 || a->N % 4) return 0;
+  const int nit = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
+  const long blocks = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);
+  const int S = choose_split(a, blocks, nit);
+  return S > 1 ? (int64_t)4 * a->M * a->N * 4 : 0;
 }
 
 extern "C" int me_gemm(const me_gemm_args* a, void* stream) {

@@ -225,6 +225,47 @@ def test_gemm_8phase_kernel_views_inplace_and_shared_residual(ops, monkeypatch):
     check(got[::5], emu.gemm(big[:, :C], w, res=shared, res_rows=M // 4)[::5], "8-phase gemm shared residual rows")
 
 
+@pytest.mark.parametrize("case", ["conv 8x8 bias+res", "dense rowvec+res+res2", "dense silu generic", "tconv", "conv stride 2"])
+def test_gemm_split_k_small_grids(ops, case, monkeypatch):
+    """Grids too small to fill the chip (the 8 x 8-latent level, batch-1 backward GEMMs) are split along K: fp32 partial sums in a scratch,
+    a second kernel adds them in a fixed order and applies the epilogue.  Against the emulation, against the un-split launch (same values up
+    to fp32 summation order) and bitwise run to run."""
+    kw, ekw = {}, {}
+    if case == "conv 8x8 bias+res":
+        Cin, Cout, H, W, nimg = 1280, 1280, 8, 8, 24
+        M = nimg * H * W
+        x, w = rnd(M, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
+        ekw.update(M=M, conv=(H, W, H, W, 1, 0), bias=rnd(Cout, seed=3), res=rnd(M, Cout, seed=4))
+    elif case == "conv stride 2":
+        Cin, Cout, H, W, nimg = 640, 640, 16, 16, 24
+        M = nimg * 8 * 8
+        x, w = rnd(nimg * H * W, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
+        ekw.update(M=M, conv=(H, W, 8, 8, 2, 0), bias=rnd(Cout, seed=3))
+    elif case == "tconv":
+        C, frames, npix, chunk, nb = 1280, 24, 64, 8, 1
+        M = nb * frames * npix
+        x, w = rnd(M, C, seed=1), rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
+        ekw.update(tconv=(frames, npix, chunk), bias=rnd(C, seed=3), res=rnd(M, C, seed=4))
+    else:
+        M, N, K = (3072, 1280, 2048) if "rowvec" in case else (3000, 640, 2560)
+        x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+        ekw.update(bias=rnd(N, seed=3), rowvec=rnd(8, N, seed=6), rows_per_vec=(M + 7) // 8, res=rnd(M, N, seed=4), res2=rnd(M, N, seed=5))
+        if "silu" in case:
+            ekw["act"] = 2
+    for k, v in ekw.items():
+        kw[k] = cu(v) if isinstance(v, torch.Tensor) else v
+    xg, wg = cu(x), cu(w)
+    monkeypatch.setenv("ME_GEMM_SPLITK", "0")
+    ref = ops.gemm(xg, wg, **kw)
+    assert "splitk" not in ops._last_kernel(), ops._last_kernel()
+    monkeypatch.delenv("ME_GEMM_SPLITK")
+    got = ops.gemm(xg, wg, **kw)
+    assert ops._last_kernel().endswith("+splitk"), ops._last_kernel()
+    assert torch.equal(got, ops.gemm(xg, wg, **kw))                       # fixed-order reduction: run to run bitwise
+    check(got, ref, f"split-K vs one pass {case}", rel=5e-4, mx=1e-2)     # same products, another fp32 summation order (+ one fp16 rounding)
+    check(got, emu.gemm(x, w, **ekw), f"split-K gemm {case}")
+
+
 def test_gemm_rejects_bad_arguments(ops):
     x, w = cu(rnd(16, 12)), cu(rnd(8, 1, 12))
     with pytest.raises(ValueError):
