@@ -1102,7 +1102,10 @@ long split_below() {   // ME_GEMM_SPLITK: grids of fewer blocks than this are sp
   return e ? atol(e) : 400;
 }
 int choose_split(const me_gemm_args* a, long blocks, int nit) {
-  if (a->geglu || a->K % 64 || blocks >= split_below() || nit < 32) return 1;   // (a 20-tile K loop measured slower split than whole)
+  // N >= 1280 only (the 16 x 16- and 8 x 8-latent levels): a split changes the fp32 summation order, and the level-0 / level-1 launches must give
+  // the same rows whatever the batch size -- the UNet graph runs its first blocks on half the batch (classifier-free-guidance prefix) and the
+  // step has to stay bitwise the same.  (A 20-tile K loop measured slower split than whole: 32 tiles at least.)
+  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32) return 1;
   int S = (int)((640 + blocks - 1) / blocks);
   if (S > 4) S = 4;
   if (S > nit / 4) S = nit / 4;

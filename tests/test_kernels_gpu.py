@@ -237,7 +237,7 @@ def test_gemm_split_k_small_grids(ops, case, monkeypatch):
         x, w = rnd(M, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
         ekw.update(M=M, conv=(H, W, H, W, 1, 0), bias=rnd(Cout, seed=3), res=rnd(M, Cout, seed=4))
     elif case == "conv stride 2":
-        Cin, Cout, H, W, nimg = 640, 640, 16, 16, 24
+        Cin, Cout, H, W, nimg = 640, 1280, 16, 16, 24
         M = nimg * 8 * 8
         x, w = rnd(nimg * H * W, Cin, seed=1), rnd(Cout, 9, Cin, seed=2, scale=(9 * Cin) ** -0.5)
         ekw.update(M=M, conv=(H, W, 8, 8, 2, 0), bias=rnd(Cout, seed=3))
@@ -247,7 +247,7 @@ def test_gemm_split_k_small_grids(ops, case, monkeypatch):
         x, w = rnd(M, C, seed=1), rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)
         ekw.update(tconv=(frames, npix, chunk), bias=rnd(C, seed=3), res=rnd(M, C, seed=4))
     else:
-        M, N, K = (3072, 1280, 2048) if "rowvec" in case else (3000, 640, 2560)
+        M, N, K = (3072, 1280, 2048) if "rowvec" in case else (3000, 1280, 2560)
         x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
         ekw.update(bias=rnd(N, seed=3), rowvec=rnd(8, N, seed=6), rows_per_vec=(M + 7) // 8, res=rnd(M, N, seed=4), res2=rnd(M, N, seed=5))
         if "silu" in case:
