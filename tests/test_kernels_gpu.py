@@ -266,6 +266,45 @@ def test_gemm_split_k_small_grids(ops, case, monkeypatch):
     check(got, emu.gemm(x, w, **ekw), f"split-K gemm {case}")
 
 
+def test_full_size_properties_of_the_level0_kernels(ops):
+    """Size-independent properties at the benchmarked geometry (24 frames x 64 x 64 latents, batch 4: 393216 rows), where no reference
+    can be computed in the test: (1) a GEMM is linear in its activations and exact on one-hot activations; (2) an attention whose values are
+    all equal returns that value whatever the scores, and whose V is the one-hot of the key index returns rows that sum to 1 (the softmax
+    weights); (3) LayerNorm output rows have zero mean and unit variance; (4) GroupNorm output groups likewise."""
+    from motioneditor_amd import segments
+    M, C = 4 * 24 * 4096, 320
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x1 = (torch.randn(M, C, device="cuda", generator=g) * 0.5).half()
+    # (1a) exactness on one-hot rows: row m selects column (m % C) of W^T
+    w = (torch.randn(3 * C, 1, C, device="cuda", generator=g) * C ** -0.5).half()
+    eye = torch.zeros(M, C, dtype=torch.float16, device="cuda")
+    eye[torch.arange(M, device="cuda"), torch.arange(M, device="cuda") % C] = 1.0
+    y = ops.gemm(eye, w)
+    wt = w[:, 0, :].t().contiguous()
+    rows = torch.cat([torch.arange(0, 2 * C), torch.arange(M // 2 - C, M // 2 + C), torch.arange(M - 2 * C, M)]).cuda()   # first, middle and last tiles
+    assert torch.equal(y[rows], wt[rows % C])
+    # (1b) linearity with an exactly representable scaling: gemm(2 x) == 2 gemm(x) bitwise wherever the result is a normal fp16 number (a power of
+    # two commutes with every rounding except the one into fp16's subnormals)
+    y1, y2 = ops.gemm(x1, w), ops.gemm(x1 * 2, w)
+    normal = y1.abs() >= 2.0 ** -13
+    assert torch.equal(y2[normal], (y1 * 2)[normal]) and float((y2.float() - 2 * y1.float()).abs().max()) <= 2.0 ** -23
+    # (2) attention, [prev | cur] segments, dh = 40
+    f, B, N, dh = 24, 4, 4096, 40
+    qkv = (torch.randn(M, 3 * C, device="cuda", generator=g) * 0.7).half()
+    si, sm = segments.prev_cur(B, f, "cuda")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=N, nk=N, seg_item=si, seg_mode=sm)
+    vconst = torch.full((M, C), 0.75, dtype=torch.float16, device="cuda")
+    o = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vconst, **args)
+    assert float((o.float() - 0.75).abs().max()) <= 1e-3          # sum_j p_j * 0.75 with sum_j p_j = 1 (fp16 P, fp32 accumulation)
+    # (3) LayerNorm rows
+    ln = ops.layernorm(x1, torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda")).float()
+    assert float(ln.mean(1).abs().max()) < 2e-3 and float((ln.var(1, unbiased=False) - 1).abs().max()) < 5e-3
+    # (4) GroupNorm over (frames x pixels x 10 channels) per batch entry
+    gn = ops.groupnorm(x1, torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda"), rows_per_group=24 * 4096, eps=1e-5,
+                       silu=False).float().reshape(4, 24 * 4096, 32, 10)
+    assert float(gn.mean((1, 3)).abs().max()) < 1e-3 and float((gn.var((1, 3), unbiased=False) - 1).abs().max()) < 2e-3
+
+
 def test_gemm_rejects_bad_arguments(ops):
     x, w = cu(rnd(16, 12)), cu(rnd(8, 1, 12))
     with pytest.raises(ValueError):
