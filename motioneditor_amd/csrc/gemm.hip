@@ -20,6 +20,18 @@
 // 16 distinct 16-byte slots.  Padding taps / tails read a 16-byte zero buffer.  Two LDS buffers:
 // the next K-slab's DMA is in flight while the current slab feeds the MFMAs; one barrier per slab.
 // STAGE_REG keeps the first implementation (global -> VGPR -> padded LDS) for A/B runs.
+//
+// Kernels in this file and who gets what (me_gemm, bottom):
+//   gemm8p_kernel<256 | 192, 320 | 256, GATHER>  the 8-phase ping-pong schedule (two wave groups half a phase apart, DMA parts in flight across
+//                                                 barriers): grids of >= 512 tiles of 256 rows, or >= 448 tiles of 192 rows when 256-row tiles would leave
+//                                                 the last block round half empty; GEGLU takes the 256-wide tile
+//   conv3_halo_kernel                             3x3 stride-1 convolutions on grids of >= 512 (16 x 16 pixel, 320 channel) patches: the input patch
+//                                                 with its halo is staged once per 64 channels, only the weight slab changes per tap
+//   gemm_kernel<128, 160 | 128 | 64>              everything smaller (one barrier per slab); grids of < 400 blocks with long K loops are split along K
+//                                                 (fp32 partials in me_gemm_args.work + gemm_splitk_reduce_kernel), N >= 1280 only
+//   gemm_kernel<256, 320>                         the one-barrier form of the big tile, kept for A/B (ME_GEMM_8P=0) and K % 64 != 0
+// Every kernel accumulates an output element over (tap, 64-channel slab) in the same order, so their results are bitwise equal (tested); only a
+// K split changes the fp32 summation order.
 #include "me_common.h"
 #include "../../include/motioned.h"
 #include <stdio.h>
