@@ -97,7 +97,9 @@ typedef struct me_gemm_args {
   void* work;
   int64_t work_bytes;
   int32_t splits_;
-  int32_t reserved_;
+  int32_t sel_rows;   /* > M: choose between the LDS-halo convolution kernel and the gather kernels as a launch of sel_rows rows would (they add the
+                         (tap, channel slab) products in different orders): a caller that computes a sub-batch of a launch once gets bitwise the rows
+                         of the full launch.  0: decide on M */
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);

@@ -30,8 +30,9 @@
 //   gemm_kernel<128, 160 | 128 | 64>              everything smaller (one barrier per slab); grids of < 400 blocks with long K loops are split along K
 //                                                 (fp32 partials in me_gemm_args.work + gemm_splitk_reduce_kernel), N >= 1280 only
 //   gemm_kernel<256, 320>                         the one-barrier form of the big tile, kept for A/B (ME_GEMM_8P=0) and K % 64 != 0
-// Every kernel accumulates an output element over (tap, 64-channel slab) in the same order, so their results are bitwise equal (tested); only a
-// K split changes the fp32 summation order.
+// The gemm / gemm8p kernels accumulate an output element over (tap, 64-channel slab) in the same order, so their results are bitwise equal
+// whatever the tile (tested); the halo kernel walks (slab, tap) and a K split adds partial sums: those two change the fp32 summation order,
+// which is why their selection can be pinned to a larger launch's (me_gemm_args.sel_rows) and the split is confined to N >= 1280.
 #include "me_common.h"
 #include "../../include/motioned.h"
 #include <stdio.h>
@@ -1334,7 +1335,11 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   const bool wide = a->N % 128 == 0 || a->N % 64 != 0;
   if (stage_impl() == STAGE_GLDS) {
     // big tile when the grid still fills the chip: every model width is a multiple of 320
-    const long big_blocks = (long)((a->M + 255) / 256) * (a->N / 320);
+    // kernel selection looks at the grid the launch WOULD have with sel_rows rows (> 0: the caller computes a sub-batch of a larger launch once -- the
+    // classifier-free-guidance prefix of the UNet graph -- and wants the rows it gets to be bitwise those of the full launch: the halo kernel and the
+    // gather kernels add the (tap, channel slab) products in different orders)
+    const int Msel = a->sel_rows > a->M ? a->sel_rows : a->M;
+    const long big_blocks = (long)((Msel + 255) / 256) * (a->N / 320);
     if (a->gather == ME_GATHER_CONV3 && a->stride == 1 && a->ups == 0 && !a->pad0 && a->N % 320 == 0 && a->K % 64 == 0 && a->Hin % 16 == 0 &&
         a->Win % 16 == 0 && !a->geglu && big_blocks >= halo_min_blocks() && conv_halo())
       return launch_conv_halo(a, st);

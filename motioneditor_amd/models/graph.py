@@ -457,9 +457,16 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     for i in range(4):
         for j in range(2):
             n = f"down_blocks.{i}.resnets.{j}"
-            x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
-            if DOWN_HAS_ATTN[i]:
-                x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", expand=2 if (share and i == 0 and j == 0) else 1, **kw)
+            prefix = share and i == 0 and j == 0
+            if prefix:   # the shared sub-batch: me_gemm picks its kernels as for the full batch, so that the rows are bitwise those of the duplicated execution
+                ops.SELECT_ROWS_SCALE = 2
+            try:
+                x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
+                if DOWN_HAS_ATTN[i]:
+                    x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", expand=2 if prefix else 1, **kw)
+            finally:
+                if prefix:
+                    ops.SELECT_ROWS_SCALE = 1
             push_skip(x)
         if i < 3:
             x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)

@@ -40,6 +40,7 @@ def _chk2d(t: torch.Tensor, name: str) -> None:
 
 
 # ---- optional per-launch profiling (bench.py): HIP events on the launch stream around each kernel call ----
+SELECT_ROWS_SCALE = 1   # > 1 while the UNet graph computes a shared sub-batch (classifier-free-guidance prefix): me_gemm then selects its kernel as for the full batch
 PROFILE = None  # None = off; else a list receiving (family, algorithmic_flops, algorithmic_bytes, start_event, end_event)
 
 
@@ -126,6 +127,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.act = act
     a.alpha = alpha
     a.res_rows, a.res2_rows = res_rows, res2_rows
+    if SELECT_ROWS_SCALE > 1:
+        a.sel_rows = M * SELECT_ROWS_SCALE
     for r_, n_ in ((res, res_rows), (res2, res2_rows)):
         if r_ is not None and r_.shape[0] < (n_ or M):
             raise ValueError("gemm: residual has fewer rows than the output reads")

@@ -292,6 +292,9 @@ def _leaf(t):
     return t.detach().float().clone().requires_grad_(True)
 
 
+SELECT_ROWS_SCALE = 1   # (kernel-selection hint of the HIP backend: no meaning here)
+
+
 def grad_acc(dst, src, alpha=1.0, pool=None, store=False):
     if store:   # the buffer was never written: whatever it holds (NaN under ME_GRAD_POISON) must not be read
         dst.zero_()

@@ -187,10 +187,11 @@ def test_cfg_prefix_sharing_is_bitwise_exact(unet, controlnet):
     """pipeline.dedup_cfg_prefix: conv_in, the first resnet and the first transformer block up to its text cross-attention run once for the
     unconditional / conditional copies of the latents (graph.unet_forward, cfg_dup) -- shared queries in me_attn, shared residual rows in
     the GEMM epilogues.  The step must equal the one that executes the duplicated prefix BIT FOR BIT, with the editors inactive and active,
-    at 8 and at 24 frames."""
+    at 8 and at 24 frames -- and at 8 frames x 64 x 64 latents, where the full batch takes the LDS-halo convolution kernel and the half batch
+    alone would not (me_gemm_args.sel_rows keeps the choice, and with it the summation order, that of the full batch)."""
     from motioneditor_amd.pipelines import MotionEditorPipeline
     from test_step_cpu import step_inputs
-    for f, hw, step in ((8, 8, 0), (8, 8, 4), (24, 16, 4)):
+    for f, hw, step in ((8, 8, 0), (8, 8, 4), (24, 16, 4), (8, 64, 4)):
         x = step_inputs(f=f, h=hw, w=hw)
         images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * hw, 8 * hw).cuda()
         emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
