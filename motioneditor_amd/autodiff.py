@@ -30,11 +30,11 @@ import torch
 class Tape:
     def __init__(self, backend=None):
         self.backend = backend
-        self.entries: List[Tuple[Sequence[torch.Tensor], Callable]] = []
+        self.entries: List[Tuple[Sequence[torch.Tensor], Callable, Sequence[torch.Tensor]]] = []   # (outputs, backward rule, tensors the call read)
         self.keep: List[torch.Tensor] = []   # every tensor a rule needs stays alive (and un-recycled) until the tape dies
 
     def record(self, outs: Sequence[torch.Tensor], rule: Callable, *saved: Optional[torch.Tensor]) -> None:
-        self.entries.append((tuple(outs), rule))
+        self.entries.append((tuple(outs), rule, tuple(t for t in saved if t is not None)))
         self.keep.extend(t for t in saved if t is not None)
         self.keep.extend(outs)
 
@@ -294,15 +294,31 @@ class record:
 
 
 def backward(tape: Tape, seeds: Sequence[Tuple[torch.Tensor, torch.Tensor]], trainable: Optional[Dict[int, str]] = None, backend=None,
-             param_buffers: Optional[Dict[str, torch.Tensor]] = None, seed_scale: float = 1.0) -> Grads:
+             param_buffers: Optional[Dict[str, torch.Tensor]] = None, seed_scale: float = 1.0, wrt: Optional[Sequence[torch.Tensor]] = None) -> Grads:
     """seeds: (tensor the forward produced, gradient of the loss w.r.t. it), entered as seed_scale * gradient (the loss scale).  Returns
     the gradient store; `G.view(t)` of any tensor the forward read is its gradient (zeros if nothing depended on it).  trainable:
     id(packed parameter tensor) -> key (weights.Packed.trainable_ids); their gradients, in the packed layout, end up in `G.params[key]`
-    (accumulated into `param_buffers[key]` when the caller provides the buffers).  backend: the ops module the tape recorded on."""
+    (accumulated into `param_buffers[key]` when the caller provides the buffers).  backend: the ops module the tape recorded on.
+
+    wrt: the input tensors whose gradients the caller will read.  With `wrt` and / or `trainable` given, the walk is PRUNED to the calls that
+    lie downstream of one of them: the null-text optimisation differentiates w.r.t. the text rows only, which first enter at the first
+    cross-attention -- conv_in's successor resnet and the first block's self-attention need no backward at all; the adapter's parameters
+    feed the up path only -- the UNet's down path and mid block need none.  (Without both, every call with a gradient is walked.)"""
     G = Grads(backend if backend is not None else tape.backend, trainable, param_buffers)
+    relevant = None
+    if wrt is not None or trainable:
+        reach = {id(_base(t)) for t in (wrt or ())}
+        tr = trainable or {}
+        relevant = []
+        for outs, _, ins in tape.entries:
+            r = any(id(_base(t)) in reach or id(t) in tr for t in ins)
+            relevant.append(r)
+            if r:
+                reach.update(id(_base(o)) for o in outs)
     for t, g in seeds:
         G.add(t, g, seed_scale)
-    for outs, rule in reversed(tape.entries):
-        if any(G.has(o) for o in outs):
+    for i in range(len(tape.entries) - 1, -1, -1):
+        outs, rule, _ = tape.entries[i]
+        if (relevant is None or relevant[i]) and any(G.has(o) for o in outs):
             rule(G)
     return G

@@ -121,7 +121,7 @@ def null_optimization(pipeline, ddim_scheduler, latents, context: torch.Tensor, 
             st = torch.cat([B_.sumsq_absmax(diff), B_.sumsq_absmax(d_rows)]).tolist()     # one host read: loss, seed magnitude
             loss = st[0] / nel
             ls = _loss_scale(st[3])
-            G = autodiff.backward(tape, [(act.t, d_rows)], seed_scale=ls)
+            G = autodiff.backward(tape, [(act.t, d_rows)], seed_scale=ls, wrt=[text])   # only what lies downstream of the text rows is walked
             g = G.view(text)
             if grads is not None:      # test hook (not part of the reference): the un-scaled gradient of this inner step
                 grads.append((g / ls).reshape(uncond0.shape).clone())
