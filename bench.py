@@ -252,9 +252,17 @@ def main():
         run(args.steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the DDIM step around the inner loop costs a conditional forward before it and a batch-2 forward after it: a second run with twice the inner
+        # iterations separates the per-iteration time (slope) from that per-step overhead (intercept)
+        t1 = time.perf_counter()
+        run(2 * args.steps)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        inner = (dt2 - dt) / args.steps
         print(json.dumps({"metric": "null-text inner iterations/sec (UNet forward on a tape + backward + Adam, batch 1; each timed call also runs the 2 plain forwards of its DDIM step)",
                           "value": round(args.steps / dt, 4), "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 1), "higher_is_better": True, "dtype": "f16 (fp32 gradient buffers, loss-scaled fp16 between layers)",
+                          "ms_per_step": round(dt / args.steps * 1e3, 1), "inner_iteration_ms": round(inner * 1e3, 1), "ddim_step_overhead_ms": round((dt - inner * args.steps) * 1e3, 1),
+                          "higher_is_better": True, "dtype": "f16 (fp32 gradient buffers, loss-scaled fp16 between layers)",
                           "data": "synthetic", "config": {"workload": f"{f} frames x {8*h}x{8*h}, single-branch UNet3D, sparse-causal attn1 (normal_infer=False as the reference hard-codes)",
                                                           "attention_backward": "fused flash-style me_attn_bwd (P rebuilt from the stashed log-sum-exp; key-centric dK / dV + query-centric dQ kernels)",
                                                           "loss_and_optimiser": "device kernels (me_mse_seed, me_sumsq_absmax, me_adamw); two floats read by the host per iteration"}}))
