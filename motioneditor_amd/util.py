@@ -130,7 +130,7 @@ def null_optimization(pipeline, ddim_scheduler, latents, context: torch.Tensor, 
             if loss < epsilon + i * 2e-5:
                 break
         out.append(uncond.reshape(uncond0.shape).clone())
-        both = graph.unet_forward(P, torch.cat([latent_cur] * 2), float(t), torch.cat([text_of(uncond), cond_rows]))
+        both = graph.unet_forward(P, torch.cat([latent_cur] * 2), float(t), torch.cat([text_of(uncond), cond_rows]), cfg_dup=True)   # the two rows are copies up to the text
         latent_cur = B_.cfg_ddim(latent_cur, both.t, guidance=guidance_scale, ca=ca, cb=cb)       # get_noise_pred + prev_step (:53-65)
     return out
 
