@@ -43,6 +43,52 @@ def test_views_and_out_targets_accumulate_in_their_allocation_and_match_autograd
     assert torch.allclose(G.view(x), xa.grad, atol=1e-5, rtol=1e-4)
 
 
+def test_backward_walk_is_pruned_to_what_lies_downstream_of_the_requested_input():
+    """`wrt=`: calls that do not depend on the requested input are not walked (the null-text optimisation asks for the text rows only, which
+    first enter at the first cross-attention), the gradient of the requested input is unchanged, and never-zeroed (NaN-poisoned in the tests)
+    first-touch buffers never leak into it."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(12, 16, generator=g)          # "latents": the prefix below depends on x only
+    txt = torch.randn(12, 8, generator=g)         # "text rows": enter at the second GEMM pair
+    w1 = torch.randn(16, 1, 16, generator=g) * 0.3
+    wt = torch.randn(16, 1, 8, generator=g) * 0.3
+    w2 = torch.randn(8, 1, 16, generator=g) * 0.3
+    gm, bt = torch.ones(16), torch.zeros(16)
+    called = []
+    real = {n: getattr(emu_ops, n) for n in ("gemm_dx", "layernorm_bwd")}
+
+    class Spy:   # the backend the tape calls: counts the backward primitives
+        def __getattr__(self, name):
+            f = getattr(emu_ops, name)
+            if name in real:
+                def wrapped(*a, **k):
+                    called.append(name)
+                    return f(*a, **k)
+                return wrapped
+            return f
+
+    class M:
+        ops = Spy()
+
+    with autodiff.record(M) as tape:
+        ops = M.ops
+        h = ops.layernorm(ops.gemm(x, w1), gm, bt)            # prefix: two calls that never see the text
+        t = ops.gemm(txt, wt)                                  # the text enters
+        y = ops.gemm(ops.layernorm(ops.gemm(h, w1, res=t), gm, bt), w2)
+    seed = torch.randn(12, 8, generator=g)
+    G_all = autodiff.backward(tape, [(y, seed)])
+    n_all = len(called)
+    del called[:]
+    G = autodiff.backward(tape, [(y, seed)], wrt=[txt])
+    assert torch.equal(G.view(txt), G_all.view(txt)) and torch.isfinite(G.view(txt)).all()
+    assert len(called) < n_all and called.count("layernorm_bwd") == 1     # the prefix LayerNorm (and its GEMM) are not differentiated
+    ta = txt.clone().requires_grad_(True)
+    ha = torch.nn.functional.layer_norm(x @ w1[:, 0].t(), (16,), gm, bt)
+    ya = torch.nn.functional.layer_norm(ha @ w1[:, 0].t() + ta @ wt[:, 0].t(), (16,), gm, bt) @ w2[:, 0].t()
+    ya.backward(seed)
+    assert torch.allclose(G.view(txt), ta.grad, atol=1e-5, rtol=1e-4)
+
+
 def test_writing_a_region_twice_while_recording_is_refused():
     x = torch.randn(4, 8)
     w = torch.randn(8, 1, 8)
