@@ -70,11 +70,16 @@ def main() -> None:
     dev = "cuda"
     vae, unet, cn = AutoencoderKL.from_synthetic(dev), UNet2DConditionModel.from_synthetic(dev), ControlNetModel.from_synthetic(dev)
     trainer = util.AdapterTrainer(unet, lr=args.lr)
+    import time
     g = torch.Generator().manual_seed(0)
     for i in range(args.steps):
         t = int(torch.randint(0, 1000, (1,), generator=g))                                                         # (:335)
-        loss = step(trainer, vae, cn, training_batch(args.frames, args.size, args.size, seed=7 + i), t)
-        print(f"step {i}: t = {t}, loss = {loss:.5f}")
+        batch = training_batch(args.frames, args.size, args.size, seed=7 + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = step(trainer, vae, cn, batch, t)
+        torch.cuda.synchronize()
+        print(f"step {i}: t = {t}, loss = {loss:.5f}   ({(time.perf_counter() - t0) * 1e3:.0f} ms: VAE encode, ControlNet, UNet + adapter forward / backward, clip, AdamW)")
 
 
 if __name__ == "__main__":
