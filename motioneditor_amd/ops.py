@@ -132,9 +132,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     for r_, n_ in ((res, res_rows), (res2, res2_rows)):
         if r_ is not None and r_.shape[0] < (n_ or M):
             raise ValueError("gemm: residual has fewer rows than the output reads")
-    nb = capi.lib().me_gemm_work_bytes(C.byref(a))   # > 0: a grid too small to fill the chip -- me_gemm may split it along K through this scratch
-    if nb > 0:
-        a.work, a.work_bytes = _work(nb, x.device, "splitk").data_ptr(), nb
+    if N >= 1280 and M <= 8192:   # (the library splits only small grids at N >= 1280: do not even ask for the ~500 large launches of a step)
+        nb = capi.lib().me_gemm_work_bytes(C.byref(a))   # > 0: a grid too small to fill the chip -- me_gemm may split it along K through this scratch
+        if nb > 0:
+            a.work, a.work_bytes = _work(nb, x.device, "splitk").data_ptr(), nb
     e0 = _pb()
     capi.check(capi.lib().me_gemm(C.byref(a), _stream()), "me_gemm")
     if e0 is not None:
