@@ -35,6 +35,11 @@ __device__ unsigned long long g_fallback_blocks;   // blocks of the fixed-offset
 
 
 constexpr float NEG_BIG = -1.0e30f;
+// Ablation builds (tools/build_abl.sh, never the shipped library): bit 0 = no K/V DMA inside the sweep (the stage buffers keep the first stage),
+// bit 1 = no barrier / vmcnt wait inside the sweep, bit 2 = no exp (P = cvt(S)), bit 3 = no tile arithmetic (DMA + barriers only), bit 4 = no re-basing test
+#ifndef ME_ATTN_ABL
+#define ME_ATTN_ABL 0
+#endif
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: 16 rows x 16 B hit 64 distinct banks)
 
@@ -798,8 +803,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
           union { f16x2 h[4]; f16x8 v; } f;
 #pragma unroll
           for (int h2 = 0; h2 < 2; ++h2) {
+#if ME_ATTN_ABL & 4
+            const float p0 = s[qt][2 * kk][2 * h2], p1 = s[qt][2 * kk][2 * h2 + 1], p2 = s[qt][2 * kk + 1][2 * h2], p3 = s[qt][2 * kk + 1][2 * h2 + 1];
+#else
             const float p0 = __builtin_amdgcn_exp2f(s[qt][2 * kk][2 * h2]), p1 = __builtin_amdgcn_exp2f(s[qt][2 * kk][2 * h2 + 1]);
             const float p2 = __builtin_amdgcn_exp2f(s[qt][2 * kk + 1][2 * h2]), p3 = __builtin_amdgcn_exp2f(s[qt][2 * kk + 1][2 * h2 + 1]);
+#endif
             f.h[h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
             f.h[2 + h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(p2, p3));
             if constexpr (!ONES) psum += (p0 + p1) + (p2 + p3);
@@ -898,26 +907,28 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   auto sweep = [&](auto fold_c) {
     int st_c = 0;   // compute cursor: stage inside the segment
     for (int si = 0; si < T; ++si) {
-      if (NBUF > 1 && si + 1 < T) dma_stage(si + 1);
+      if (NBUF > 1 && si + 1 < T && !(ME_ATTN_ABL & 1)) dma_stage(si + 1);
       const char* st = smem + (si & (NBUF - 1)) * STAGE;
 #pragma unroll
       for (int j = 0; j < NSUB; ++j) {
         const int kt = st_c * NSUB + j;
         if constexpr (FOLD) {   // keys past nk are masked through the K image (pad marks, see dma_stage): one tile variant only
-          if (kt < ntk) tile(BT{}, fold_c, st + j * SUB, kt);
+          if (kt < ntk && !(ME_ATTN_ABL & 8)) tile(BT{}, fold_c, st + j * SUB, kt);
         } else {
           if (kt < nfull) tile(BT{}, fold_c, st + j * SUB, kt);
           else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
         }
       }
-      if constexpr (FOLD && decltype(fold_c)::value) rebase();
+      if constexpr (FOLD && decltype(fold_c)::value && !(ME_ATTN_ABL & 16)) rebase();
       if (++st_c == nst) st_c = 0;
       if (NBUF == 1 && si + 1 < T) {
         __syncthreads();   // single buffer: every wave is done reading it
         dma_stage(si + 1);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
-      __syncthreads();                                    // ... and so have everyone else's; this stage is free
+      if (!(ME_ATTN_ABL & 2)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next stage have landed ...
+        __syncthreads();                                    // ... and so have everyone else's; this stage is free
+      }
     }
   };
   if constexpr (FOLD) {

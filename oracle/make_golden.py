@@ -17,7 +17,7 @@ not product code.  What it does:
   5. (--only-inversion / full run) DDIM inversion: the reference UNet with ``normal_infer=True`` and the reference's
      in-tree ``next_step`` (util.py:77-87) walked over three inversion steps -> inversion.npz.
 
-Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3]
+Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-controlnet]
 """
 from __future__ import annotations
 
@@ -307,39 +307,122 @@ def inversion_goldens(unet, sd):
     print("inversion.npz written")
 
 
-def config3_golden():
-    """BASELINE configs[2] at FULL size -- 24 frames x 64x64 latents, two-branch + ControlNet + adapter, both editors ACTIVE (step 4),
-    the inputs and weights of bench.py -- through the oracle (the reference's own modules cannot run this size in the container:
-    their materialised 5N-key scores alone are 64 GB).  The oracle is pinned against the reference at 16x16 / 32x32 (cases above);
-    this fixture pins the HIP path to the oracle at the benchmarked geometry: a strided sub-sample of the updated latents and of the
-    guided noise prediction plus per-stage checksums (12 skips, 12 motion residuals, mid, 12 + 1 ControlNet residuals).
-    ~20-40 min on 8 cores; needs no reference import."""
+def _sub(t: torch.Tensor, sf: int, sp: int) -> np.ndarray:
+    """Strided sub-sample of a [B, C, f, h, w] tensor (every sf-th frame, every sp-th pixel row / column), fp16."""
+    return t[:, :, ::sf, ::sp, ::sp].numpy().astype(np.float16)
+
+
+def step_golden(tag: str, f: int, h: int, step: int = 4, single_branch: bool = False):
+    """One full denoising step through the ORACLE at a size the reference's own modules cannot hold in the container (their materialised
+    5N-key scores alone are 64 GB at config 3), on bench.py's inputs and weights.  The oracle is pinned against the reference at 16x16 /
+    32x32 (cases above); these fixtures pin the HIP path to the oracle at the benchmarked geometries:
+      step_config3   BASELINE configs[2]: 24 frames x 64x64 latents, two-branch + ControlNet + adapter, both editors ACTIVE (step 4)
+      step_geom96    the spatial geometry of BASELINE configs[4] (96x96 latents: 9216 tokens at level 0, 48x48 / 24x24 / 12x12 below) at 8 frames
+      step_single    BASELINE configs[1]: 8 frames x 64x64 latents, ONE clip, single-branch UNet3D (no ControlNet, no adapter input, no editors)
+    Stored: strided sub-samples of the updated latents and of the guided noise prediction, rel-L2-comparable sub-samples of two skips and one
+    motion residual, and per-stage statistics (12 skips, 12 motion residuals, mid, 12 + 1 ControlNet residuals).  Needs no reference import."""
     torch.set_num_threads(os.cpu_count() or 8)
-    f, h, w, step = 24, 64, 64, 4
-    x = synth.bench_inputs(f, h, w)
+    x = synth.bench_inputs(f, h, h)
     usd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.unet_schema()).items()}
-    csd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.").items()}
     ddim = ref_cpu.DDIM()
-    sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
-    sp.cur_step = tp.cur_step = step
     t = ddim.timesteps[step]
-    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w)
     taps = {}
     t0 = time.time()
-    with torch.no_grad():
-        want = ref_cpu.denoise_step(usd, csd, ddim, x["latents"], t, x["uncond"][step], x["cond"], images, sp, tp, 7.5, taps=taps)
+    if single_branch:
+        with torch.no_grad():
+            want = ref_cpu.denoise_step(usd, None, ddim, x["latents"][:1], t, x["uncond"][step], x["cond"][:1], None, None, None, 7.5, taps=taps)
+    else:
+        csd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.").items()}
+        sp, tp = ref_cpu.SpatialEditor(x["masks"]), ref_cpu.TemporalEditor()
+        sp.cur_step = tp.cur_step = step
+        images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * h)
+        with torch.no_grad():
+            want = ref_cpu.denoise_step(usd, csd, ddim, x["latents"], t, x["uncond"][step], x["cond"], images, sp, tp, 7.5, taps=taps)
     dt = time.time() - t0
-    print(f"oracle config-3 step: {dt:.0f} s on {torch.get_num_threads()} threads")
+    print(f"oracle step {tag} ({f} f x {h}x{h}, {'single-branch' if single_branch else 'two-branch'}): {dt:.0f} s on {torch.get_num_threads()} threads")
     assert torch.isfinite(want).all()
-    # the two ControlNet batch entries of the reference are the same computation (even frame count): the product computes one
-    cn = taps["cn_down"]
-    assert all(float((d[0] - d[1]).abs().max()) == 0.0 for d in cn)
-    np.savez_compressed(GOLD / "step_config3.npz", frames=f, latent=h, step=step, t=t, oracle_seconds=dt,
-                        latents_sub=want[:, :, :, ::2, ::2].numpy().astype(np.float32), latents_stats=stats(want),
-                        noise_pred_sub=taps["noise_pred"][:, :, ::2, ::4, ::4].numpy().astype(np.float32), noise_pred_stats=stats(taps["noise_pred"]),
-                        skip_stats=np.stack([stats(s) for s in taps["skips"]]), motion_stats=np.stack([stats(s) for s in taps["motion"]]),
-                        mid_stats=stats(taps["mid"]), cn_down_stats=np.stack([stats(d) for d in cn]), cn_mid_stats=stats(taps["cn_mid"]))
-    print("step_config3.npz written")
+    sp_lat, sp_np = (2, 4) if h >= 64 else (1, 2)
+    sf = 2 if f > 8 else 1
+    out = dict(frames=f, latent=h, step=step, t=t, oracle_seconds=dt, single_branch=int(single_branch),
+               latents_sub=want[:, :, :, ::sp_lat, ::sp_lat].numpy().astype(np.float32), latents_stats=stats(want), lat_stride=sp_lat,
+               noise_pred_sub=taps["noise_pred"][:, :, ::sf, ::sp_np, ::sp_np].numpy().astype(np.float32), noise_pred_stats=stats(taps["noise_pred"]),
+               np_stride=np.array([sf, sp_np]),
+               skip_stats=np.stack([stats(s) for s in taps["skips"]]), mid_stats=stats(taps["mid"]),
+               # level-0 skip after the first transformer block, and a level-2 skip: rel-L2 on a strided sub-sample catches a mis-scaled block
+               skip1_sub=_sub(taps["skips"][1], sf, 4), skip7_sub=_sub(taps["skips"][7], sf, 2))
+    if not single_branch:
+        cn = taps["cn_down"]
+        # the two ControlNet batch entries of the reference are the same computation (even frame count): the product computes one
+        assert all(float((d[0] - d[1]).abs().max()) == 0.0 for d in cn)
+        out.update(motion_stats=np.stack([stats(s) for s in taps["motion"]]), cn_down_stats=np.stack([stats(d) for d in cn]), cn_mid_stats=stats(taps["cn_mid"]),
+                   motion4_sub=_sub(taps["motion"][4][[1, 3]], sf, 2), cn_down6_sub=_sub(cn[6][:1], sf, 2))
+    np.savez_compressed(GOLD / f"{tag}.npz", **out)
+    print(f"{tag}.npz written")
+
+
+def controlnet_trunk_golden():
+    """R16 (diffusers ControlNetModel, source not in the reference tree): pin the TRUNK against the reference's own blocks.
+    conv_in, the time embedding, down_blocks.* and mid_block.* of the ControlNet share the SD-1.5 key schema with the reference's
+    UNet2DConditionModel, and that model run at f = 1 with temp_conv* and attn_temp.to_out zeroed IS the 2-D SD-1.5 encoder:
+    GroupNorm over one frame (resnet_2d.py:199-249), TemporalConv zero -> identity (resnet_2d.py:15-16, 205-206), [frame 0 | frame 0]
+    keys = plain self-attention (attention_2d.py:732-740), a one-frame temporal attention times a zero out-projection = 0
+    (attention_2d.py:534-545).  So: load the reference UNet with the ControlNet's trunk weights, add the oracle's conditioning embedding to
+    conv_in's output with a forward hook, capture the 12 down-block residuals + the mid-block output with hooks, and compare with the
+    oracle's tensors in front of the zero-convolutions.  The fixture holds the zero-convolved REFERENCE tensors (a 1x1 convolution applied
+    here to the reference's outputs).  What stays self-pinned: the 8 conditioning-embedding convolutions and the 13 1x1 zero-convolutions."""
+    csd_np = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
+    usd_np = dict(synth.synth_state_dict(synth.unet_schema()))
+    trunk = [k for k in csd_np if k in usd_np]
+    assert {k.split(".")[0] for k in trunk} == {"conv_in", "time_embedding", "down_blocks", "mid_block"}, {k.split(".")[0] for k in trunk}
+    assert not [k for k in csd_np if k not in usd_np and not k.startswith(("controlnet_cond_embedding.", "controlnet_down_blocks.", "controlnet_mid_block."))]
+    for k in trunk:
+        assert usd_np[k].shape == csd_np[k].shape, k
+        usd_np[k] = csd_np[k]
+    nz = 0
+    for k in usd_np:
+        if "temp_conv" in k or "attn_temp.to_out" in k:
+            usd_np[k] = np.zeros_like(usd_np[k])
+            nz += 1
+    unet = build_reference_unet(usd_np)
+    csd = {k: torch.from_numpy(v) for k, v in csd_np.items()}
+    n, h, t = 2, 16, 501
+    T = torch.from_numpy
+    sample = T(synth.synth_normal("cn_trunk.sample", (n, 4, h, h), 33))
+    ehs = T(synth.synth_normal("cn_trunk.ehs", (n, 77, 768), 33, 0.3))
+    cond = T(np.clip(synth.synth_normal("cn_trunk.cond", (n, 3, 8 * h, 8 * h), 33, 0.5) + 0.5, 0, 1).astype(np.float32))
+    taps = {}
+    with torch.no_grad():
+        down_o, mid_o = ref_cpu.controlnet_forward(csd, sample, t, ehs, cond, taps=taps)
+    cemb = taps["cond_emb"]
+    got = {"res": [], "mid": None}
+
+    def conv_in_hook(_m, _i, o):
+        o = o + cemb[:, :, None]
+        got["res"].append(o)
+        return o
+
+    hooks = [unet.conv_in.register_forward_hook(conv_in_hook)]
+    for blk in unet.down_blocks:
+        hooks.append(blk.register_forward_hook(lambda _m, _i, o: got["res"].extend(o[1])))
+    hooks.append(unet.mid_block.register_forward_hook(lambda _m, _i, o: got.__setitem__("mid", o)))
+    with torch.no_grad():
+        quiet(unet, sample[:, :, None], torch.tensor(t), ehs)
+    for hk in hooks:
+        hk.remove()
+    assert len(got["res"]) == 12 and got["mid"] is not None
+    errs = [relerr(a, b[:, :, 0]) for a, b in zip(taps["outs"], got["res"])] + [relerr(taps["mid"], got["mid"][:, :, 0])]
+    print(f"ControlNet trunk: oracle vs the reference's 2-D blocks ({len(trunk)} shared tensors, {nz} temporal tensors zeroed): max rel err {max(errs):.2e}")
+    assert max(errs) < 1e-4, errs
+    zc = lambda name, x: torch.nn.functional.conv2d(x, csd[name + ".weight"], csd[name + ".bias"])   # noqa: E731
+    with torch.no_grad():
+        down_r = [zc(f"controlnet_down_blocks.{i}", r[:, :, 0]) for i, r in enumerate(got["res"])]
+        mid_r = zc("controlnet_mid_block", got["mid"][:, :, 0])
+    e2 = max(relerr(a, b) for a, b in zip(down_o + [mid_o], down_r + [mid_r]))
+    assert e2 < 1e-4, e2
+    out = {f"down{i}": (d[:, :, ::2, ::2] if d.shape[-1] >= 8 else d).numpy().astype(np.float32) for i, d in enumerate(down_r)}
+    np.savez_compressed(GOLD / "controlnet_trunk.npz", n=n, latent=h, t=t, mid=mid_r.numpy().astype(np.float32), oracle_relerr=max(max(errs), e2),
+                        trunk_tensors=len(trunk), **out)
+    print("controlnet_trunk.npz written; oracle ControlNet trunk == reference SD-1.5 2-D encoder blocks")
 
 
 def main():
@@ -347,7 +430,16 @@ def main():
     torch.set_num_threads(os.cpu_count() or 8)
     GOLD.mkdir(parents=True, exist_ok=True)
     if "--only-config3" in sys.argv:
-        config3_golden()
+        step_golden("step_config3", 24, 64)
+        return
+    if "--only-geom96" in sys.argv:
+        step_golden("step_geom96", 8, 96)
+        return
+    if "--only-single" in sys.argv:
+        step_golden("step_single", 8, 64, single_branch=True)
+        return
+    if "--only-controlnet" in sys.argv:
+        controlnet_trunk_golden()
         return
     if "--only-prepare-image" in sys.argv:
         prepare_image_golden()

@@ -434,8 +434,10 @@ def unet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor,
 # and plain N-key self attention.
 # --------------------------------------------------------------------------------------------
 def controlnet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor, cond: torch.Tensor,
-                       scale: float = 1.0) -> Tuple[List[torch.Tensor], torch.Tensor]:
-    """sample [n,4,h,w], ehs [n,77,768], cond [n,3,8h,8w] -> 12 down residuals + mid residual (4-D)."""
+                       scale: float = 1.0, taps: Optional[dict] = None) -> Tuple[List[torch.Tensor], torch.Tensor]:
+    """sample [n,4,h,w], ehs [n,77,768], cond [n,3,8h,8w] -> 12 down residuals + mid residual (4-D).
+    taps (test infrastructure): the conditioning embedding and the trunk's tensors in front of the 1x1 zero-convolutions --
+    what oracle/make_golden.py --only-controlnet compares with the reference's own 2-D blocks."""
     n = sample.shape[0]
     emb = time_embed(sd, "", torch.as_tensor(t).reshape(-1).expand(n))
     c = F.silu(F.conv2d(cond, sd["controlnet_cond_embedding.conv_in.weight"], sd["controlnet_cond_embedding.conv_in.bias"], padding=1))
@@ -457,6 +459,8 @@ def controlnet_forward(sd: SD, sample: torch.Tensor, t, ehs: torch.Tensor, cond:
     x = resnet_block(sd, "mid_block.resnets.0", x, emb, temporal=False)
     x = transformer2d(sd, "mid_block.attentions.0", x, ehs, None, None, sc_attn=False, has_temp=False)
     x = resnet_block(sd, "mid_block.resnets.1", x, emb, temporal=False)
+    if taps is not None:
+        taps["cond_emb"], taps["outs"], taps["mid"] = c, [o[:, :, 0] for o in outs], x[:, :, 0]
     down = [inflated_conv(sd, f"controlnet_down_blocks.{i}", o, padding=0)[:, :, 0] * scale for i, o in enumerate(outs)]
     mid = inflated_conv(sd, "controlnet_mid_block", x, padding=0)[:, :, 0] * scale
     return down, mid

@@ -31,6 +31,46 @@ def test_unet_single_branch_matches_reference_golden(emu, unet_sd_np):
     assert max_rel(out, torch.from_numpy(g["out"])) < 2e-4
 
 
+def controlnet_trunk_case():
+    """Inputs of tests/golden/controlnet_trunk.npz (oracle/make_golden.py --only-controlnet) and its expected residuals."""
+    g = np.load(GOLD / "controlnet_trunk.npz")
+    n, h, t = int(g["n"]), int(g["latent"]), int(g["t"])
+    T = torch.from_numpy
+    sample = T(synth.synth_normal("cn_trunk.sample", (n, 4, h, h), 33))
+    ehs = T(synth.synth_normal("cn_trunk.ehs", (n, 77, 768), 33, 0.3))
+    cond = T(np.clip(synth.synth_normal("cn_trunk.cond", (n, 3, 8 * h, 8 * h), 33, 0.5) + 0.5, 0, 1).astype(np.float32))
+    want = [T(g[f"down{i}"]) for i in range(12)] + [T(g["mid"])]
+    return sample, t, ehs, cond, want
+
+
+def controlnet_trunk_errors(down, mid, want, metric):
+    """Residuals [(n), C, h', w'] against the fixture (levels with h' >= 8 are stored with every second pixel row / column)."""
+    errs = []
+    for got, w in zip(list(down) + [mid], want):
+        got = got.float().cpu()
+        if got.shape[-1] != w.shape[-1]:
+            got = got[:, :, ::2, ::2]
+        errs.append(metric(got, w))
+    return errs
+
+
+def test_controlnet_trunk_matches_reference_blocks(emu, monkeypatch, cn_sd_np, cn_sd_torch):
+    """R16: the ControlNet's trunk (conv_in, time embedding, down blocks, mid block) against the REFERENCE's own 2-D-degenerate blocks
+    (tests/golden/controlnet_trunk.npz: the reference UNet2DConditionModel at f = 1 with the temporal parts zeroed, loaded with the
+    ControlNet's weights) -- first the oracle, then the product graph on the emulated C ABI."""
+    import motioneditor_amd.models.controlnet as cm
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from oracle import ref_cpu
+    monkeypatch.setattr(cm, "ops", emu_ops)
+    sample, t, ehs, cond, want = controlnet_trunk_case()
+    with torch.no_grad():
+        down, mid = ref_cpu.controlnet_forward(cn_sd_torch, sample, t, ehs, cond)
+    assert max(controlnet_trunk_errors(down, mid, want, max_rel)) < 1e-4
+    cn = ControlNetModel(cn_sd_np, device="cpu", dtype=torch.float32)
+    down, mid = cn(sample, t, ehs, cond)
+    assert max(controlnet_trunk_errors(down, mid, want, max_rel)) < 2e-4
+
+
 @pytest.mark.parametrize("tag,step", [("inactive", 0), ("active", 4)])
 def test_unet_two_branch_with_editors_matches_reference_golden(emu, unet_sd_np, tag, step):
     g = np.load(GOLD / f"unet_two_{tag}.npz")

@@ -554,6 +554,19 @@ def test_frame_sharded_path_on_one_rank_equals_plain_step(unet, controlnet):
         dist.destroy_process_group()
 
 
+def test_controlnet_trunk_vs_reference_blocks(controlnet):
+    """R16 on the GPU: the drop-in ControlNetModel (diffusers call signature, pipeline_motion_editor.py:618-625) against
+    tests/golden/controlnet_trunk.npz -- the residuals of the REFERENCE's own 2-D-degenerate SD-1.5 encoder blocks loaded with the ControlNet's
+    trunk weights (oracle/make_golden.py --only-controlnet); only the conditioning-embedding convolutions and the 1x1 zero-convolutions of the
+    expected values come from the restatement."""
+    from test_graph_cpu import controlnet_trunk_case, controlnet_trunk_errors
+    sample, t, ehs, cond, want = controlnet_trunk_case()
+    down, mid = controlnet(sample.cuda(), t, ehs.cuda(), cond.cuda())
+    errs = controlnet_trunk_errors(down, mid, want, rel_l2)
+    record("controlnet_trunk_vs_reference_max", max(errs))
+    assert max(errs) <= 5e-3, errs
+
+
 def test_step_config3_full_size_vs_golden():
     """BASELINE configs[2] at FULL size -- the benchmarked workload itself (24 frames x 64x64 latents, batch 4, ControlNet + adapter, both editors
     active, bench.py's inputs and weights) -- against tests/golden/step_config3.npz, which oracle/make_golden.py --only-config3 generated in the
