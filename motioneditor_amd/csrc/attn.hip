@@ -40,6 +40,12 @@ constexpr float NEG_BIG = -1.0e30f;
 #ifndef ME_ATTN_ABL
 #define ME_ATTN_ABL 0
 #endif
+// dh = 40, phase A: QK^T as v_mfma_f32_32x32x16_f16 over K = 48 (3 steps: 40 dims + the two fold slots) instead of 16x16x32 over K = 64.
+// ME_ATTN_W32=0 builds the 16x16x32 form (A/B, tools/build_abl.sh).
+#ifndef ME_ATTN_W32
+#define ME_ATTN_W32 1
+#endif
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KT = 64;        // keys per tile
 constexpr int VLD = KT + 8;   // V^T row stride in halves (144 B: 16 rows x 16 B hit 64 distinct banks)
 
@@ -541,7 +547,42 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
       }
     }
   };
-  load_q(std::integral_constant<bool, FOLD>{});
+  // W32 (dh = 40, phase A): the wave's 32 queries as ONE 32-wide block.  S^T = K Q^T by v_mfma_f32_32x32x16_f16: operand A = K rows
+  // (lane (r = lane & 31, hi = lane >> 5) holds K[key(r)][ks*16 + hi*8 .. +8]), operand B = Q (lane (q = lane & 31, hi) holds
+  // Q[q][ks*16 + hi*8 .. +8]), three k-steps cover d = 0..39 and the fold slots 40 (offset) / 41 (pad mark): 6 MFMAs of 32 cycles per
+  // 64 keys instead of 16 of 16.  D: lane (q, hi), register i <-> MFMA row 8*(i>>2) + 4*hi + (i&3).  After exp2 / cvt_pkrtz, four
+  // v_permlane16_swap per 32 keys move the packed P of queries 16..31 out of the lanes of queries 0..15 and leave the two 16-query B operands
+  // of the (unchanged) 16x16x32 PV MFMAs; the MFMA row -> key map (bits 2 and 3 swapped) is chosen so that their k-slot order equals the
+  // 16x16 path's (lane group g <-> keys 4g .. 4g+3 of each 16): the V^T fragment reads, their bank pattern and everything behind PV stay as they are.
+  constexpr bool W32 = FOLD && DH == 40 && QT == 2 && (ME_ATTN_W32 != 0);
+  const int hi32 = lane >> 5;
+  const int krow32 = (lane & 19) | ((lane & 4) << 1) | ((lane & 8) >> 1);   // K row (inside a 32-key block) this lane feeds to MFMA row lane & 31
+  f16x8 fqw[3];
+  float mq = 0.f;   // W32: the fixed offset of query lane & 31 (both hi lanes agree)
+  auto load_qw = [&]() {
+    const int q = qb * BQ + wave * 32 + (lane & 31);
+    const long qsrc = (long)(a.q_items > 0 ? item % a.q_items : item) * a.nq + q;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const int d = ks * 16 + hi32 * 8;
+      U128 u;
+      u.u = (q < a.nq && d < DH) ? ldg128(Q + qsrc * a.ldq + h * DH + d) : zero128();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) u.e[e] = (f16)((float)u.e[e] * c);
+      fqw[ks] = u.h;
+    }
+    if (hi32 == 1) fqw[2][1] = (f16)-1.f;   // k-slot 41, against the pad marks of K column DH + 1
+  };
+  if constexpr (W32) {
+    load_qw();
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
+      qrow[qt] = q < a.nq ? item * a.nq + q : -1;
+    }
+  } else {
+    load_q(std::integral_constant<bool, FOLD>{});
+  }
 
   const int ntk = (a.nk + KT - 1) / KT;          // 64-key sub-tiles per segment
   const int nst = (ntk + NSUB - 1) / NSUB;        // stages per segment
@@ -694,7 +735,37 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     if (g == GS) fq[qt][D32 - 1][0] = hm;
     mrun[qt] = -(float)hm;
   };
-  if constexpr (FOLD) {
+  auto set_refw = [&](float m) {
+    const f16 hm = (f16)(-fminf(fmaxf(m, -2000.f), 2000.f));
+    if (hi32 == 1) fqw[2][0] = hm;
+    mq = -(float)hm;
+  };
+  auto mfma32 = [](f16x8 x, f16x8 y, f32x16 z) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, z, 0, 0, 0); };
+  // S^T of one 32-key block (keys b*32 .. +31 of the sub-tile at sK) against the wave's 32 queries
+  auto qk32 = [&](const char* sK, int b) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const char* row = sK + (b * 32 + krow32) * KPB + hi32 * 16;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) acc = mfma32(*reinterpret_cast<const f16x8*>(row + ks * 32), fqw[ks], acc);
+    return acc;
+  };
+  if constexpr (W32) {
+    if (T > 0) {
+      const int tw = min((wave * QT * 16) / KT, NPROBE - 1);
+      const char* sK = smem + (tw / NSUB) * STAGE + (tw % NSUB) * SUB;
+      float mr = NEG_BIG;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const f32x16 s0 = qk32(sK, b);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mr = fmaxf(mr, s0[i]);   // keys past nk: pad marks put them at -60000
+      }
+      set_refw(ceilf(xor32_max(mr)));
+    }
+    __syncthreads();   // every wave has read its probe tile: the buffers may be overwritten
+  } else if constexpr (FOLD) {
     if (T > 0) {   // initial offset = ceil(row maximum over the probe tile that holds this wave's queries): one extra QK^T, no P, no PV
       const int tw = min((wave * QT * 16) / KT, NPROBE - 1);
       const char* sK = smem + (tw / NSUB) * STAGE + (tw % NSUB) * SUB;
@@ -871,6 +942,102 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     __builtin_amdgcn_sched_barrier(0);   // keep the next tile's K fragment reads below this tile's PV: 8 x 4 registers the kernel does not have
   };
 
+#ifndef ME_ATTN_REBASE_AT
+#define ME_ATTN_REBASE_AT 512.f
+#endif
+  constexpr float REBASE_AT = ME_ATTN_REBASE_AT, REBASE_TO_LOG2 = 5.f;   // (a lane of the kernels without the ones row holds a quarter of the denominator: it re-bases a little later)
+  // W32 re-basing (see "FOLD hedge" below), taken once per 128 keys in the MIDDLE of a tile -- after the tile's first QK^T MFMAs are issued, so that
+  // the test reads PV accumulators that were finished a tile ago instead of stalling on the ones just issued (at the stage end it cost 2.4 % of
+  // the kernel).  Offsets live per query lane (mq, k-slot 40 of fqw[2]); the denominators sit in the PV accumulators' lane order (query (qt, l15)):
+  // lane L's query is ((L >> 4) & 1, L & 15), so the shift of ITS query is dsh[(L >> 4) & 1] as computed in this very lane.  The logits `sw` that
+  // are already in flight carry the old offset: they move down by the same (integer, exact) amount.
+  auto rebase_w32 = [&](f32x16& sw) {
+    if constexpr (!W32) return;
+    constexpr int LT = W32 ? DH / 16 : 0;   // (the accumulator tile that holds the ones row; only the W32 instantiation has it)
+    float dsh[QT];
+    bool any = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      dsh[qt] = 0.f;
+      const float lq = (g == (DH % 16) / 4) ? o[qt][LT][(DH % 16) % 4] : 0.f;
+      if (__builtin_amdgcn_readfirstlane(__any(lq > REBASE_AT))) {
+        any = true;
+        const float l = __shfl(o[qt][LT][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
+        dsh[qt] = (l > REBASE_AT && l < 65504.f) ? ceilf(__log2f(l)) - REBASE_TO_LOG2 : 0.f;
+        const float sc = __builtin_amdgcn_exp2f(-dsh[qt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= sc;
+      }
+    }
+    if (any) {
+      const float dq = (lane & 16) ? dsh[QT - 1] : dsh[0];
+      set_refw(mq + dq);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sw[i] -= dq;
+    }
+  };
+  // W32 tile (phase A only): 6 MFMAs (32x32x16) -> 32 exp2 + 16 cvt_pkrtz + 8 permlane16_swap -> the 12 PV MFMAs of the 16x16 path
+  auto tile32 = [&](const char* st, auto check_c) {
+    const char* sK = st;
+    const char* sV = st + KBYTES;
+    f16x8 pf[QT][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x16 sw = qk32(sK, b);
+      if constexpr (decltype(check_c)::value) {
+        if (b == 0) rebase_w32(sw);
+      }
+      unsigned cw[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#if ME_ATTN_ABL & 4
+        cw[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(sw[2 * j], sw[2 * j + 1]));
+#else
+        cw[j] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(__builtin_amdgcn_exp2f(sw[2 * j]), __builtin_amdgcn_exp2f(sw[2 * j + 1])));
+#endif
+      }
+      // (c0, c2), (c1, c3), (c4, c6), (c5, c7): the first of each pair ends up with queries 0..15 in all four lane groups, the second with 16..31
+      const auto r0 = __builtin_amdgcn_permlane16_swap(cw[0], cw[2], false, false);
+      const auto r1 = __builtin_amdgcn_permlane16_swap(cw[1], cw[3], false, false);
+      const auto r2 = __builtin_amdgcn_permlane16_swap(cw[4], cw[6], false, false);
+      const auto r3 = __builtin_amdgcn_permlane16_swap(cw[5], cw[7], false, false);
+      union { unsigned u[4]; f16x8 v; } f0, f1;
+      f0.u[0] = r0[0]; f0.u[1] = r1[0]; f0.u[2] = r2[0]; f0.u[3] = r3[0];
+      f1.u[0] = r0[1]; f1.u[1] = r1[1]; f1.u[2] = r2[1]; f1.u[3] = r3[1];
+      pf[0][b] = f0.v;
+      pf[QT - 1][b] = f1.v;   // (QT == 2 whenever this lambda is called)
+    }
+    // ---- O^T += V^T P^T, as in tile() ----
+    const unsigned vlane = (unsigned)(size_t)(sV + (g * 4 + (l15 >> 2)) * VPB + (l15 & 3) * 8);
+    uint2 rv[2][4];
+    auto issue = [&](auto dt_c) {
+      constexpr int dt = decltype(dt_c)::value;
+      rv[dt & 1][0] = lds_tr16<(0) * VPB + dt * 32>(vlane);
+      rv[dt & 1][1] = lds_tr16<(16) * VPB + dt * 32>(vlane);
+      rv[dt & 1][2] = lds_tr16<(32) * VPB + dt * 32>(vlane);
+      rv[dt & 1][3] = lds_tr16<(48) * VPB + dt * 32>(vlane);
+    };
+    issue(std::integral_constant<int, 0>{});
+    static_for(std::make_integer_sequence<int, DT>{}, [&](auto dt_c) {
+      constexpr int dt = decltype(dt_c)::value;
+      if constexpr (dt + 1 < DT) {
+        issue(std::integral_constant<int, dt + 1>{});
+        lds_wait<4>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+      } else {
+        lds_wait<0>(rv[dt & 1][0], rv[dt & 1][1], rv[dt & 1][2], rv[dt & 1][3]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        union { uint2 u[2]; f16x8 v; } fv;
+        fv.u[0] = rv[dt & 1][kk * 2];
+        fv.u[1] = rv[dt & 1][kk * 2 + 1];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(fv.v, pf[qt][kk], o[qt][dt]);
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
   // FOLD hedge: once per stage, a query whose denominator has grown past 2^9 -- its keys are getting heavier than its probe tile
   // promised (or there are simply many of them) -- moves its fixed offset up by d = ceil(log2(denominator)) - 5 and scales its
   // accumulators by 2^-d (a power of two; numerator and denominator alike), which puts the denominator back into (16, 32].  Gradual
@@ -878,10 +1045,6 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   // denominator keep full fp16 precision (re-basing all the way down to 1, as a running maximum does, pushed the light keys of a peaky row
   // into fp16's subnormals: 2-3 ulp on such rows instead of 1).  One compare and a wave-uniform branch per query tile and stage; only a
   // jump of more than ~2^7 in the denominator inside ONE stage still ends in phase B.
-#ifndef ME_ATTN_REBASE_AT
-#define ME_ATTN_REBASE_AT 512.f
-#endif
-  constexpr float REBASE_AT = ME_ATTN_REBASE_AT, REBASE_TO_LOG2 = 5.f;   // (a lane of the kernels without the ones row holds a quarter of the denominator: it re-bases a little later)
   auto rebase = [&]() {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -909,17 +1072,24 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     for (int si = 0; si < T; ++si) {
       if (NBUF > 1 && si + 1 < T && !(ME_ATTN_ABL & 1)) dma_stage(si + 1);
       const char* st = smem + (si & (NBUF - 1)) * STAGE;
+      if constexpr (W32 && decltype(fold_c)::value) {
+        static_for(std::make_integer_sequence<int, NSUB>{}, [&](auto j_c) {
+          constexpr int j = decltype(j_c)::value;
+          if (st_c * NSUB + j < ntk && !(ME_ATTN_ABL & 8)) tile32(st + j * SUB, std::integral_constant<bool, (NSUB == 1 || (j & 1) == 1) && !(ME_ATTN_ABL & 16)>{});
+        });
+      }
 #pragma unroll
       for (int j = 0; j < NSUB; ++j) {
         const int kt = st_c * NSUB + j;
-        if constexpr (FOLD) {   // keys past nk are masked through the K image (pad marks, see dma_stage): one tile variant only
+        if constexpr (W32 && decltype(fold_c)::value) {
+        } else if constexpr (FOLD) {   // keys past nk are masked through the K image (pad marks, see dma_stage): one tile variant only
           if (kt < ntk && !(ME_ATTN_ABL & 8)) tile(BT{}, fold_c, st + j * SUB, kt);
         } else {
           if (kt < nfull) tile(BT{}, fold_c, st + j * SUB, kt);
           else if (kt < ntk) tile(BF{}, fold_c, st + j * SUB, kt);
         }
       }
-      if constexpr (FOLD && decltype(fold_c)::value && !(ME_ATTN_ABL & 16)) rebase();
+      if constexpr (FOLD && !W32 && decltype(fold_c)::value && !(ME_ATTN_ABL & 16)) rebase();
       if (++st_c == nst) st_c = 0;
       if (NBUF == 1 && si + 1 < T) {
         __syncthreads();   // single buffer: every wave is done reading it
@@ -951,6 +1121,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     }
     if (trip) trip_flag = 1;
     __syncthreads();
+    if constexpr (W32) {   // the epilogue wants the offsets in the accumulators' lane order
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) mrun[qt] = __shfl(mq, qt * 16 + l15, 64);
+    }
     if (trip_flag) {
       if (tid == 0) atomicAdd(&g_fallback_blocks, 1ull);   // diagnostic: me_attn_fallback_blocks()
       load_q(BF{});
@@ -1127,6 +1301,11 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
       // fold (speculative fixed-offset softmax with the classic sweep as in-kernel fallback) pays from a few tiles per query on:
       // its start-up is one extra QK^T tile.  The 77-key text cross-attention stays classic.  ME_ATTN_FOLD=0: A/B switch.
       case 40:
+        // 16 waves x 32 queries and 256 keys per barrier, one block per CU, when the launch has whole 512-query blocks: half the K/V fill per query
+        // of the 8-wave form (measured -2.2 %; ME_ATTN_NW16=0 builds without it)
+#if !defined(ME_ATTN_NW16) || ME_ATTN_NW16
+        if (fold && a->nq >= 512) { rc = launch_attn2<40, 2, 16, 4, 2, 4, true>(a, st); break; }
+#endif
         if (fold) rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, true>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, true>(a, st);
         else rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, false>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, false>(a, st);
         break;
