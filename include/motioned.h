@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 5
+#define ME_ABI_VERSION 6
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -100,6 +100,15 @@ typedef struct me_gemm_args {
   int32_t sel_rows;   /* > M: choose between the LDS-halo convolution kernel and the gather kernels as a launch of sel_rows rows would (they add the
                          (tap, channel slab) products in different orders): a caller that computes a sub-batch of a launch once gets bitwise the rows
                          of the full launch.  0: decide on M */
+  /* ABI 6: HEAD-MAJOR second output (C2 != NULL).  Output columns n >= c2_col0 are not written to C but to C2 as [head][M][c2_dh]:
+   *     C2[((n - c2_col0) / c2_dh) * c2_hs + m * c2_dh + (n - c2_col0) % c2_dh]
+   * -- the fused q|k|v projection of a self-attention (attention_2d.py:705-768) hands K and V to me_attn as contiguous [keys][dh] panels per
+   * head (me_attn_args.hsk / hsv) instead of dh-wide column slices of 3C-wide rows: the attention's K/V tile fill touches 2.5 x fewer cache
+   * lines, and the projection's own stores land 80 ... 320 bytes apart instead of 1920 ... 7680.  Requires: no geglu / act / rowvec / res /
+   * res2, c2_dh % 8 == 0, c2_col0 % 16 == 0, (N - c2_col0) % c2_dh == 0, c2_hs % 8 == 0, C2 16-byte aligned. */
+  void* C2;
+  int32_t c2_col0, c2_dh;
+  int64_t c2_hs;      /* elements between the panels of consecutive heads (>= M * c2_dh) */
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);
@@ -163,6 +172,9 @@ typedef struct me_attn_args {
                               the adapter's pose queries, controlnet_adapter.py:519-523, broadcast over the edit rows); 0: item i reads item i */
   void* lse;               /* optional fp32 [n_items * nq][heads]: log2 of the softmax denominator in exp2 units, log2(sum_j 2^(s_j scale log2 e)),
                               stashed for me_attn_bwd (plain segments only; NULL = not written) */
+  /* ABI 6: head-major K / V (me_gemm_args.C2).  hsk / hsv > 0: element (row, head, d) of K / V lies at row * ldk + head * hsk + d (ldk = dh for
+   * contiguous per-head panels); 0: at row * ldk + head * dh + d (heads are column slices of the rows, as Q and O always are). */
+  int64_t hsk, hsv;
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);

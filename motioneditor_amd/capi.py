@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 5
+ABI_VERSION = 6
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -30,6 +30,7 @@ class GemmArgs(C.Structure):
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
         ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32), ("res_rows", _i32), ("res2_rows", _i32),
         ("work", _vp), ("work_bytes", _i64), ("splits_", _i32), ("sel_rows", _i32),
+        ("C2", _vp), ("c2_col0", _i32), ("c2_dh", _i32), ("c2_hs", _i64),
     ]
 
 
@@ -50,6 +51,7 @@ class AttnArgs(C.Structure):
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
         ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
         ("vsum", _vp), ("n_kv_items", _i32), ("q_items", _i32), ("lse", _vp),
+        ("hsk", _i64), ("hsv", _i64),
     ]
 
 

@@ -126,16 +126,17 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   // V^T rows keep their 64 keys in MFMA k-slot order: key kk*32 + j*16 + g*4 + r sits at kk*32 + g*8 + j*4 + r, so
   // the eight keys of a lane's PV operand-A fragment are one aligned 16-byte LDS read
   const int vpos = (lane & 32) | ((lane & 12) << 1) | ((lane & 16) >> 2) | (lane & 3);
-  const int koff0 = lane * a.ldk + h * DH;
-  const int voff0 = lane * a.ldv + h * DH;
+  const long hk = a.hsk > 0 ? a.hsk : DH, hv = a.hsv > 0 ? a.hsv : DH;   // head-major K / V panels (ABI 6), or heads as column slices
+  const int koff0 = lane * a.ldk;
+  const int voff0 = lane * a.ldv;
   // load cursor = the tile being fetched (two ahead of the one consumed): uniform tile base pointers, bumped by a
   // constant per tile and re-derived from seg_item only when a segment ends
   int seg_l = 0, kt_l = 0;
   const f16 *kptr_l = K, *vptr_l = V;
   auto seg_base = [&]() {
     const int kit = a.seg_item[item * a.nseg + seg_l];
-    kptr_l = K + (long)kit * a.nk * a.ldk;
-    vptr_l = V + (long)kit * a.nk * a.ldv;
+    kptr_l = K + (long)kit * a.nk * a.ldk + h * hk;
+    vptr_l = V + (long)kit * a.nk * a.ldv + h * hv;
   };
   auto advance_l = [&]() {
     if (++kt_l == ntk) {
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     int ko = koff0, vo = voff0;
     if ((kt_l + 1) * KT > a.nk) {   // tail tile: keys past nk re-read the last key (finite; their logits are masked)
       const int kl = min(lane, a.nk - 1 - kt_l * KT);
-      ko = kl * a.ldk + h * DH;
-      vo = kl * a.ldv + h * DH;
+      ko = kl * a.ldk;
+      vo = kl * a.ldv;
     }
 #pragma unroll
     for (int i = 0; i < NFULL; ++i) {
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     const int key = cl / cpr, ch = cl - key * cpr;
     if (ch >= CKR) return -1;
     const int kc = min(key, maxkey);   // tail sub-tile: rows past nk re-read the last key (finite; their logits are masked)
-    return (kc * (isk ? a.ldk : a.ldv) + h * DH + ch * 8) * 2;
+    return (kc * (isk ? a.ldk : a.ldv) + ch * 8) * 2;   // (the head's offset travels in the base pointers)
   };
   int off[NSLOT];
   unsigned long long msk[NSLOT];
@@ -628,11 +629,12 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   const unsigned smem_base = (unsigned)(size_t)smem;
 
   int seg_l = 0, st_l = 0;    // load cursor: segment, stage inside the segment
+  const long hk = a.hsk > 0 ? a.hsk : DH, hv = a.hsv > 0 ? a.hsv : DH;   // head-major K / V panels (ABI 6), or heads as column slices of the rows
   const char *kptr_l = K, *vptr_l = V;
   auto seg_base = [&]() {
     const int kit = seg_l == 0 ? kit3[0] : (seg_l == 1 ? kit3[1] : kit3[2]);
-    kptr_l = K + (long)kit * a.nk * a.ldk * 2;
-    vptr_l = V + (long)kit * a.nk * a.ldv * 2;
+    kptr_l = K + ((long)kit * a.nk * a.ldk + h * hk) * 2;
+    vptr_l = V + ((long)kit * a.nk * a.ldv + h * hv) * 2;
   };
   auto dma_stage = [&](int si) {   // fetch the load cursor's stage into buffer si % NBUF, advance the cursor
     const unsigned st = smem_base + (si & (NBUF - 1)) * STAGE;
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   if constexpr (FOLD) {
     if (T > 0) {
       const int kitp = nvalid == 1 ? kit3[0] : (nvalid == 2 ? kit3[1] : kit3[2]);   // (no dynamic index: the array would move to scratch)
-      const char* kseg = K + (long)kitp * a.nk * a.ldk * 2;
+      const char* kseg = K + ((long)kitp * a.nk * a.ldk + h * hk) * 2;
 #pragma unroll
       for (int t = 0; t < NPROBE; ++t) {
         const int ktp = min(qb * (BQ / KT) + t, ntk - 1);
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 // the second pass adds the RS partials in order.  (The first version gave every kv item to ONE block per 128 columns: 288
 // blocks of 4-byte loads, 0.9 TB/s.)
 constexpr int COLSUM_RS = 16;
-__global__ __launch_bounds__(256) void colsum_part_kernel(const f16* __restrict__ V, int ldv, int nk, int C, float* __restrict__ part, int n_items) {
+__global__ __launch_bounds__(256) void colsum_part_kernel(const f16* __restrict__ V, int ldv, int nk, int C, float* __restrict__ part, int n_items, int dh, long hsv) {
   __shared__ float red[256][8];
   const int kit = blockIdx.x, rs = blockIdx.y;
   const int tpr = C / 8, RL = 256 / tpr;          // vectors per row, row lanes (C <= 2048)
@@ -1192,7 +1194,8 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const f16* __restrict_
   const int rows = (nk + COLSUM_RS - 1) / COLSUM_RS, r0 = rs * rows, r1 = min(r0 + rows, nk);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rl < RL) {
-    const f16* p = V + (long)kit * nk * ldv + vc * 8;
+    const int col = vc * 8, hd = col / dh;   // head-major V: the vector's head panel (8 | dh: a vector never straddles heads)
+    const f16* p = V + (long)kit * nk * ldv + (hsv > 0 ? hd * hsv + (col - hd * dh) : col);
 #pragma unroll 4
     for (int r = r0 + rl; r < r1; r += RL) {
       U128 u;
@@ -1273,6 +1276,7 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15 || ((uintptr_t)a->O & 7)) { me_set_error("me_attn: misaligned pointer"); return ME_EINVAL; }
   if (a->q_items < 0 || (a->general_dual && (a->q_items > 0 || a->lse))) { me_set_error("me_attn: q_items / lse are not served by the general-dual kernel"); return ME_EINVAL; }
   if (a->lse && a->vsum) { me_set_error("me_attn: lse is written for plain segments only"); return ME_EINVAL; }
+  if (a->hsk < 0 || a->hsv < 0 || a->hsk % 8 || a->hsv % 8) { me_set_error("me_attn: head strides must be non-negative multiples of 8"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (a->general_dual) {   // non-binary masks: the mask-reading kernel
@@ -1291,7 +1295,7 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
       float* vs = reinterpret_cast<float*>(a->vsum);
       const long n = (long)a->n_kv_items * C;
       hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)a->n_kv_items, COLSUM_RS), dim3(256), 0, st, reinterpret_cast<const f16*>(a->V), a->ldv, a->nk, C, vs + n,
-                         a->n_kv_items);
+                         a->n_kv_items, a->dh, (long)a->hsv);
       hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vs + n, vs, n);
     }
     // 8 waves x 32 queries when the launch has whole 256-query blocks (halves the K/V fill per query), else 4 waves

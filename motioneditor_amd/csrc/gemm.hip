@@ -230,6 +230,31 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
     if constexpr (has_rv) { add_wide(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); add_narrow_last(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; }); }
     if constexpr (has_res) { add_wide(res, [&](int m) { return (long)rr(m) * a.ldr; }); add_narrow_last(res, [&](int m) { return (long)rr(m) * a.ldr; }); }
     if constexpr (has_res2) { add_wide(res2, [&](int m) { return (long)rr2(m) * a.ldr2; }); add_narrow_last(res2, [&](int m) { return (long)rr2(m) * a.ldr2; }); }
+    if constexpr (F == 0) {
+      if (a.C2) {   // head-major second output (ABI 6): a lane's 8 (4) consecutive columns never straddle a head (c2_dh % 8 == 0)
+        f16* C2 = reinterpret_cast<f16*>(a.C2);
+        long hoff[NP + 1];   // element offset of the lane's columns inside C2 (row 0), or -1: the columns stay in C
+#pragma unroll
+        for (int jp = 0; jp <= NP; ++jp) {
+          const int col = jp < NP ? nw + 32 * jp : nb + 16 * (NT - 1);
+          const int n2 = col - a.c2_col0, hh = n2 / a.c2_dh;
+          hoff[jp] = n2 >= 0 ? (long)hh * a.c2_hs + (n2 - hh * a.c2_dh) : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (mrow[i] < 0) continue;
+          f16* crow = C + (long)mrow[i] * a.ldc;
+          f16* hrow = C2 + (long)mrow[i] * a.c2_dh;
+#pragma unroll
+          for (int jp = 0; jp < NP; ++jp)
+            if (nw + 32 * jp + 7 < a.N) st16(hoff[jp] >= 0 ? hrow + hoff[jp] : crow + nw + 32 * jp, w[i][jp].u);
+          if constexpr (NT % 2 == 1) {
+            if (nb + 16 * (NT - 1) < a.N) st8(hoff[NP] >= 0 ? hrow + hoff[NP] : crow + nb + 16 * (NT - 1), o[i][NT - 1].u);
+          }
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       if (mrow[i] < 0) continue;
@@ -263,6 +288,24 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
   if constexpr (has_rv) add_term(rowvec, [&](int m) { return (long)(m / a.rows_per_vec) * a.ldrv; });
   if constexpr (has_res) add_term(res, [&](int m) { return (long)rr(m) * a.ldr; });
   if constexpr (has_res2) add_term(res2, [&](int m) { return (long)rr2(m) * a.ldr2; });
+  if constexpr (F == 0) {
+    if (a.C2 && sC == nullptr) {   // head-major second output through the 8-byte path (me_gemm never stages such a launch through LDS)
+      f16* C2 = reinterpret_cast<f16*>(a.C2);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = nb + 16 * j;
+        if (col >= a.N) continue;
+        const int n2 = col - a.c2_col0, hh = n2 / a.c2_dh;
+        const long hoff = n2 >= 0 ? (long)hh * a.c2_hs + (n2 - hh * a.c2_dh) : -1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if (mrow[i] < 0) continue;
+          st8(hoff >= 0 ? C2 + (long)mrow[i] * a.c2_dh + hoff : C + (long)mrow[i] * a.ldc + col, o[i][j].u);
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (mrow[i] < 0) continue;
@@ -645,7 +688,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   const int ncols = a.geglu ? BN / 2 : BN;            // output columns of this block
   const int Nout = a.geglu ? a.N / 2 : a.N;
   constexpr bool CFITS = (size_t)BM * (BN + 8) <= (size_t)2 * (BM + BN) * LD;   // the C tile fits the staging buffers
-  const bool wide_store = CFITS && (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0);
+  const bool wide_store = CFITS && (Nout % 8 == 0) && (a.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.C) & 15) == 0) && !a.C2;
   auto rowfn = [&](int i) {
     const int m = m0 + wm * WM + i * 16 + (lane & 15);
     return m < a.M ? m : -1;
@@ -1118,7 +1161,7 @@ int choose_split(const me_gemm_args* a, long blocks, int nit) {
   // N >= 1280 only (the 16 x 16- and 8 x 8-latent levels): a split changes the fp32 summation order, and the level-0 / level-1 launches must give
   // the same rows whatever the batch size -- the UNet graph runs its first blocks on half the batch (classifier-free-guidance prefix) and the
   // step has to stay bitwise the same.  (A 20-tile K loop measured slower split than whole: 32 tiles at least.)
-  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32) return 1;
+  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32 || a->C2) return 1;
   int S = (int)((640 + blocks - 1) / blocks);
   if (S > 4) S = 4;
   if (S > nit / 4) S = nit / 4;
@@ -1329,6 +1372,11 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->act < 0 || a->act > 2) { me_set_error("me_gemm: bad activation"); return ME_EINVAL; }
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
   if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act || a->alpha != 1.0f)) { me_set_error("me_gemm: geglu needs N % 32 == 0, alpha == 1 and no rowvec/res/act"); return ME_EINVAL; }
+  if (a->C2 && (a->geglu || a->act || a->rowvec || a->res || a->res2 || a->c2_dh <= 0 || a->c2_dh % 8 || a->c2_col0 < 0 || a->c2_col0 % 16 || a->c2_col0 >= a->N ||
+                (a->N - a->c2_col0) % a->c2_dh || a->c2_hs % 8 || a->c2_hs < (int64_t)a->M * a->c2_dh || ((uintptr_t)a->C2 & 15) || a->gather == ME_GATHER_CONV3)) {
+    me_set_error("me_gemm: head-major output (C2) needs a term-free epilogue, c2_dh % 8 == 0, c2_col0 % 16 == 0, whole heads, c2_hs % 8 == 0 and >= M * c2_dh, 16-byte alignment");
+    return ME_EINVAL;
+  }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   // N tile: every channel count of the model (320 ... 10240) is a multiple of 160 -> exact 128x160 tiles;
   // GEGLU needs whole (value, gate) 32-row pairs per wave -> 128; leftovers (4, 16, 32, 96, 256) -> 128 / 64 with a tail

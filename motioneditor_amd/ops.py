@@ -70,15 +70,20 @@ def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((rows, cols), dtype=F16, device=like.device)
 
 
+HEAD_MAJOR_KV = True   # this backend implements gemm(head_major=...) / 3-D k, v in attention (the CPU emulation and the autodiff recorder do not)
+
+
 def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Optional[torch.Tensor] = None,
          bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
          res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
-         tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0) -> torch.Tensor:
+         tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0, head_major: Optional[Tuple[int, int]] = None):
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
 
     w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
-    3 for ``tconv=(frames, npix, chunk)``).  res_rows / res2_rows > 0: res / res2 holds that many rows, output row m reads row m % rows."""
+    3 for ``tconv=(frames, npix, chunk)``).  res_rows / res2_rows > 0: res / res2 holds that many rows, output row m reads row m % rows.
+    head_major = (col0, dh): the output columns from col0 on leave as a second tensor [(N - col0) / dh, M, dh] -- one contiguous [rows, dh]
+    panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels)."""
     _chk2d(x, "gemm.x")
     if w.dtype != F16 or not w.is_contiguous() or w.dim() != 3:
         raise ValueError("gemm.w: expected contiguous fp16 [N, taps, K]")
@@ -105,6 +110,14 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     if x.shape[1] < K:
         raise ValueError(f"gemm: x has {x.shape[1]} columns < K={K}")
     n_out = N // 2 if geglu else N
+    panels = None
+    if head_major is not None:
+        col0, hdh = head_major
+        if out is not None or geglu or (N - col0) % hdh or col0 <= 0:
+            raise ValueError("gemm: head_major needs whole heads behind col0 > 0 and allocates its own outputs")
+        panels = torch.empty(((N - col0) // hdh, M, hdh), dtype=F16, device=x.device)
+        a.C2, a.c2_col0, a.c2_dh, a.c2_hs = panels.data_ptr(), col0, hdh, M * hdh
+        n_out = col0
     if out is None:
         out = empty(M, n_out, x)
     _chk2d(out, "gemm.out")
@@ -144,7 +157,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
         n_terms = (res is not None) + (res2 is not None)
         _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (rows_in * K + N * K * taps + M * n_out * (1 + n_terms)), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
             f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
-    return out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
+    out = out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
+    return out if panels is None else (out, panels)
 
 
 def conv_small(inp: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n_img: int, Cin: int, H: int, Wd: int,
@@ -174,8 +188,15 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
               scale: Optional[float] = None, out: Optional[torch.Tensor] = None, q_items: int = 0, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q_items > 0: q holds q_items query items, item i reads item i % q_items.  lse: fp32 [n_items * nq, heads] that receives the
     log2-domain log-sum-exp of every (query, head) -- what attention_bwd rebuilds P from (plain segments only)."""
-    for t, n in ((q, "q"), (k, "k"), (v, "v")):
-        _chk2d(t, "attention." + n)
+    hm = k.dim() == 3   # head-major K / V: [heads, rows, dh] panels (gemm(head_major=...)); strides (head, row, 1)
+    if hm:
+        if v.dim() != 3 or k.shape[0] != heads or v.shape[0] != heads or k.shape[2] != dh or v.shape[2] != dh or k.stride(2) != 1 or v.stride(2) != 1 \
+                or k.dtype != F16 or v.dtype != F16:
+            raise ValueError("attention: head-major k / v must be fp16 [heads, rows, dh] with unit column stride")
+        _chk2d(q, "attention.q")
+    else:
+        for t, n in ((q, "q"), (k, "k"), (v, "v")):
+            _chk2d(t, "attention." + n)
     if q.shape[0] < (q_items or n_items) * nq:
         raise ValueError("attention: q has fewer rows than the items read")
     if seg_item.dtype != torch.int32 or seg_mode.dtype != torch.int32 or seg_item.shape != seg_mode.shape or seg_item.shape[0] != n_items:
@@ -184,7 +205,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
         out = empty(n_items * nq, heads * dh, q)
     a = AttnArgs()
     a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
-    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), out.stride(0)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(1 if hm else 0), v.stride(1 if hm else 0), out.stride(0)
+    if hm:
+        a.hsk, a.hsv = k.stride(0), v.stride(0)
     a.heads, a.dh = heads, dh
     a.n_items, a.nq, a.nk, a.nseg = n_items, nq, nk, seg_item.shape[1]
     a.seg_item, a.seg_mode, a.mask = seg_item.data_ptr(), seg_mode.data_ptr(), _p(mask)
@@ -202,7 +225,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
             raise ValueError("attention: lse must be a contiguous fp32 [n_items * nq, heads] tensor")
         a.lse = lse.data_ptr()
     if bd and not gd:   # binary dual keys: me_attn needs fp32 scratch for the per-kv-item column sums of V
-        n_kv = k.shape[0] // nk
+        n_kv = k.shape[1 if hm else 0] // nk
         vsum = torch.empty(capi.lib().me_attn_vsum_bytes(n_kv, heads * dh) // 4, dtype=torch.float32, device=q.device)
         a.vsum, a.n_kv_items = vsum.data_ptr(), n_kv
     e0 = _pb()

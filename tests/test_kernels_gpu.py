@@ -989,3 +989,50 @@ def test_conv_small_wide_outputs_tile_kernel(ops, Cin, Cout, n_img, H, W, frames
         x = torch.randn(n_img, Cin, H, W, generator=g)
         kw = dict(n_img=n_img, Cin=Cin, H=H, Wd=W, img_stride=Cin * H * W, ch_stride=H * W)
     check(ops.conv_small(cu(x), cu(wt), cu(bias), **kw), emu.conv_small(x, wt, bias, **kw), f"conv_small tile {Cin}->{Cout}")
+
+
+# ------------------------------------------------------------------ head-major K | V (ABI 6: me_gemm_args.C2, me_attn_args.hsk / hsv)
+@pytest.mark.parametrize("M,C,K", [(512, 320, 320), (1000, 320, 320), (131072, 320, 320), (24576, 640, 640), (6144, 1280, 1280), (300, 1280, 1280), (196608, 320, 320)])
+def test_gemm_head_major_second_output_is_the_same_numbers_elsewhere(ops, M, C, K):
+    """q | k | v projection with K and V leaving as [16, M, dh] panels: bit for bit the column slices of the one-tensor launch -- through the
+    8-phase 256 x 320 kernel (wide 16-byte stores + the odd fifth column tile), the 128-row kernels and ragged last row tiles."""
+    dh = C // 8
+    x, w = rnd(M, K, seed=1).cuda(), rnd(3 * C, 1, K, seed=2, scale=K ** -0.5).cuda()
+    ref = ops.gemm(x, w)
+    q, kv = ops.gemm(x, w, head_major=(C, dh))
+    assert q.shape == (M, C) and kv.shape == (16, M, dh) and kv.is_contiguous()
+    assert torch.equal(q, ref[:, :C])
+    assert torch.equal(kv.permute(1, 0, 2).reshape(M, 2 * C), ref[:, C:])
+    b = rnd(3 * C, seed=3).cuda()
+    q2, kv2 = ops.gemm(x, w, bias=b, head_major=(C, dh))
+    ref2 = ops.gemm(x, w, bias=b)
+    assert torch.equal(q2, ref2[:, :C]) and torch.equal(kv2.permute(1, 0, 2).reshape(M, 2 * C), ref2[:, C:])
+    with pytest.raises(Exception):
+        ops.gemm(x, w, res=ref, head_major=(C, dh))
+    with pytest.raises(Exception):
+        ops.gemm(x, w, head_major=(C, dh + 4))
+
+
+@pytest.mark.parametrize("dh,N,kind", [(40, 4096, "pc"), (40, 4096, "ed_bin"), (40, 4096, "ed_gen"), (80, 1024, "pc"), (80, 1024, "ed_bin"), (160, 256, "pc"), (40, 100, "pc"),
+                                       (40, 576, "ed_bin"), (80, 144, "ed_gen")])
+def test_attention_head_major_kv_equals_row_major(ops, dh, N, kind):
+    """The same launch with K and V as per-head [rows, dh] panels (what the head-major projection writes) must give bitwise the output of the
+    row-major launch: only addresses change (K/V tile fill, column sums of V for the binary dual segments), no arithmetic."""
+    from motioneditor_amd import segments
+    C = 8 * dh
+    if kind == "pc":
+        B, f = 2, 2
+        si, sm = segments.prev_cur(B, f, "cpu")
+        n_items, mask = B * f, None
+    else:
+        B, f = 2, 1
+        si, sm = segments.edited_spatial(f, "cpu", binary_mask=(kind == "ed_bin"), B=B)
+        g = torch.Generator().manual_seed(11)
+        mask = ((torch.rand(8, N, generator=g) > 0.5).half() if kind == "ed_bin" else torch.rand(8, N, generator=g).half()).cuda()
+        n_items = B * f
+    qkv = rnd(n_items * N, 3 * C, seed=3).cuda()
+    args = dict(heads=8, dh=dh, n_items=n_items, nq=N, nk=N, seg_item=cu(si), seg_mode=cu(sm), mask=mask)
+    want = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], **args)
+    kv = qkv[:, C:].reshape(n_items * N, 16, dh).permute(1, 0, 2).contiguous()
+    got = ops.attention(qkv[:, :C], kv[:8], kv[8:], **args)
+    assert torch.equal(got, want)

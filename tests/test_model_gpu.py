@@ -567,48 +567,102 @@ def test_controlnet_trunk_vs_reference_blocks(controlnet):
     assert max(errs) <= 5e-3, errs
 
 
-def test_step_config3_full_size_vs_golden():
-    """BASELINE configs[2] at FULL size -- the benchmarked workload itself (24 frames x 64x64 latents, batch 4, ControlNet + adapter, both editors
-    active, bench.py's inputs and weights) -- against tests/golden/step_config3.npz, which oracle/make_golden.py --only-config3 generated in the
-    build container (one oracle step, 707 s on 8 cores): a strided sub-sample of the updated latents and of the guided noise prediction plus
-    the abs-mean of every skip, motion residual and ControlNet residual."""
+def _rows_to_5d(rows, B, f, h):
+    """[(B f h h), C] token-major rows -> [B, C, f, h, h] (the reference layout of the oracle's taps)."""
+    assert rows.shape[0] == B * f * h * h, (rows.shape, B, f, h)
+    return rows.float().reshape(B, f, h, h, rows.shape[1]).permute(0, 4, 1, 2, 3)
+
+
+def _sub5(t, sf, sp):
+    return t[:, ::8, ::sf, ::sp, ::sp].cpu()
+
+
+def _step_vs_golden(tag):
+    """One full denoising step on bench.py's inputs and weights against an oracle-generated fixture (oracle/make_golden.py step_golden):
+    strided sub-samples of the updated latents and of the guided noise prediction (rel-L2), rel-L2 on sub-samples of two skips / one motion
+    residual / one ControlNet residual where the fixture has them, and the abs-mean of every stage."""
     from motioneditor_amd import synth
     from motioneditor_amd.models.controlnet import ControlNetModel
     from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
     from motioneditor_amd.pipelines import MotionEditorPipeline
-    g = np.load(GOLD / "step_config3.npz")
+    g = np.load(GOLD / f"{tag}.npz")
     f, h, step = int(g["frames"]), int(g["latent"]), int(g["step"])
+    single = "single_branch" in g.files and int(g["single_branch"]) == 1
     x = synth.bench_inputs(f, h, h)
     u = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cuda")
-    c = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
-    pipe = MotionEditorPipeline(unet=u, controlnet=c)
-    sed, ted = editors(u, x["masks"])
-    sed.cur_step = ted.cur_step = step
+    if single:
+        pipe = MotionEditorPipeline(unet=u, controlnet=None)
+        lat, emb, images = x["latents"][:1].cuda(), torch.cat([x["uncond"][step], x["cond"][:1]]).cuda(), None
+    else:
+        c = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
+        pipe = MotionEditorPipeline(unet=u, controlnet=c)
+        sed, ted = editors(u, x["masks"])
+        sed.cur_step = ted.cur_step = step
+        lat = x["latents"].cuda()
+        images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * h).cuda()
+        emb = torch.cat([x["uncond"][step].expand(2, 77, 768), x["cond"]]).cuda()
     pipe.scheduler.set_timesteps(50)
     t = pipe.scheduler.timesteps[step]
     assert int(t) == int(g["t"])
-    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * h).cuda()
-    emb = torch.cat([x["uncond"][step].expand(2, 77, 768), x["cond"]]).cuda()
+    nb = lat.shape[0]
     taps = {}
-    got = pipe.denoise_step(x["latents"].cuda(), t, emb, images, 7.5, taps=taps)
+    got = pipe.denoise_step(lat, t, emb, images, 7.5, taps=taps)
     am = lambda t_: float(t_.float().abs().mean())   # noqa: E731
-    for i, d in enumerate(taps["cn_down"]):           # one ControlNet entry (the reference's two are identical)
-        assert abs(am(d) - g["cn_down_stats"][i, 1]) < 2e-2 * g["cn_down_stats"][i, 1], f"ControlNet residual {i}"
-    assert abs(0.5 * am(taps["cn_mid"]) - g["cn_mid_stats"][1]) < 2e-2 * g["cn_mid_stats"][1]        # golden: [0, m, 0, m]
     for i, s_ in enumerate(taps["skips"]):
         assert abs(am(s_) - g["skip_stats"][i, 1]) < 2e-2 * g["skip_stats"][i, 1], f"skip {i}"
-    for i, m in enumerate(taps["motion"]):            # edit rows only here; the golden statistics are over [0, m0, 0, m1]
-        assert abs(0.5 * am(m) - g["motion_stats"][i, 1]) < 3e-2 * g["motion_stats"][i, 1], f"motion residual {i}"
     assert abs(am(taps["mid"]) - g["mid_stats"][1]) < 2e-2 * g["mid_stats"][1]
+    if not single:
+        for i, d in enumerate(taps["cn_down"]):           # one ControlNet entry (the reference's two are identical)
+            assert abs(am(d) - g["cn_down_stats"][i, 1]) < 2e-2 * g["cn_down_stats"][i, 1], f"ControlNet residual {i}"
+        assert abs(0.5 * am(taps["cn_mid"]) - g["cn_mid_stats"][1]) < 2e-2 * g["cn_mid_stats"][1]        # golden: [0, m, 0, m]
+        for i, m in enumerate(taps["motion"]):            # edit rows only here; the golden statistics are over [0, m0, 0, m1]
+            assert abs(0.5 * am(m) - g["motion_stats"][i, 1]) < 3e-2 * g["motion_stats"][i, 1], f"motion residual {i}"
     N = h * h
-    eps = taps["eps_rows"].float().reshape(4, f, N, 4).permute(0, 3, 1, 2).reshape(4, 4, f, h, h)
-    npred = (eps[:2] + 7.5 * (eps[2:] - eps[:2]))[:, :, ::2, ::4, ::4].cpu()
+    eps = taps["eps_rows"].float().reshape(2 * nb, f, N, 4).permute(0, 3, 1, 2).reshape(2 * nb, 4, f, h, h)
+    if "np_stride" in g.files:
+        sf, sp_np, sp_lat = int(g["np_stride"][0]), int(g["np_stride"][1]), int(g["lat_stride"])
+    else:
+        sf, sp_np, sp_lat = 2, 4, 2
+    npred = (eps[:nb] + 7.5 * (eps[nb:] - eps[:nb]))[:, :, ::sf, ::sp_np, ::sp_np].cpu()
     e_np = rel_l2(npred, torch.from_numpy(g["noise_pred_sub"]))
-    e = rel_l2(got[:, :, :, ::2, ::2].cpu(), torch.from_numpy(g["latents_sub"]))
-    record("config3_full_size_noise_pred", e_np)
-    record("config3_full_size_latents", e)
+    e = rel_l2(got[:, :, :, ::sp_lat, ::sp_lat].cpu(), torch.from_numpy(g["latents_sub"]))
+    record(f"{tag}_noise_pred", e_np)
+    record(f"{tag}_latents", e)
+    if "skip1_sub" in g.files:   # rel-L2 on sub-samples of stage tensors: a mis-scaled single block cannot hide behind an abs-mean
+        B = 2 * nb
+        hs = [h, h, h, h // 2, h // 2, h // 2, h // 4, h // 4, h // 4, h // 8, h // 8, h // 8]
+        for name, idx, sp in (("skip1_sub", 1, 4), ("skip7_sub", 7, 2)):
+            es = rel_l2(_sub5(_rows_to_5d(taps["skips"][idx], B, f, hs[idx]), sf, sp), torch.from_numpy(g[name]).float())
+            record(f"{tag}_{name}", es)
+            assert es <= 5e-3, (name, es)
+        if not single:
+            em = rel_l2(_sub5(_rows_to_5d(taps["motion"][4], 2, f, hs[4]), sf, 2), torch.from_numpy(g["motion4_sub"]).float())
+            ec = rel_l2(_sub5(_rows_to_5d(taps["cn_down"][6], 1, f, hs[6]), sf, 2), torch.from_numpy(g["cn_down6_sub"]).float())
+            record(f"{tag}_motion4_sub", em)
+            record(f"{tag}_cn_down6_sub", ec)
+            assert em <= 1e-2 and ec <= 5e-3, (em, ec)
     u.spatial_editor = u.temporal_editor = None
     assert torch.isfinite(got).all() and e_np <= NOISE_PRED_TOL and e <= STEP_TOL, (e_np, e)
+
+
+def test_step_config3_full_size_vs_golden():
+    """BASELINE configs[2] at FULL size -- the benchmarked workload itself (24 frames x 64x64 latents, batch 4, ControlNet + adapter, both editors
+    active, bench.py's inputs and weights) -- against tests/golden/step_config3.npz, which oracle/make_golden.py --only-config3 generated in the
+    build container (one oracle step, ~12 min on 8 cores)."""
+    _step_vs_golden("step_config3")
+
+
+def test_step_single_branch_config2_vs_golden():
+    """BASELINE configs[1]: 8 frames x 512^2 (64x64 latents), ONE clip through the single-branch UNet3D (no ControlNet, no adapter input, no
+    editors), classifier-free guidance + DDIM -- against tests/golden/step_single.npz (oracle/make_golden.py --only-single)."""
+    _step_vs_golden("step_single")
+
+
+def test_step_96x96_latents_vs_golden():
+    """The spatial geometry of BASELINE configs[4] (768^2 images: 96x96 latents -- 9216 tokens / 18 query blocks of 512 / 72 + 72 (+ 72) stages of
+    keys per item at level 0, 48x48 at level 1 (dh = 80, 2304 keys), 24x24, 12x12) on one GPU at 8 frames, two-branch + ControlNet + adapter, both
+    editors active -- against tests/golden/step_geom96.npz (oracle/make_golden.py --only-geom96)."""
+    _step_vs_golden("step_geom96")
 
 
 @pytest.mark.parametrize("f,hw", [(8, 32), (48, 16)])
