@@ -52,6 +52,13 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--latent", type=int, default=64, help="latent height = width (image size / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=["sample", "full", "off"], default="sample",
+                    help="'sample' (default): the CPU oracle timed on ONE step at BASELINE configs[0] (bounded, ~1 min) next to the committed full-config measurement "
+                         "(profiles/cpu_baseline_full.json); 'full': time ONE oracle step at the bench workload itself (24 f x 64x64 latents: minutes to a quarter of an hour of host "
+                         "time, no GPU involved), print it as one JSON line and exit -- run once per round on the GPU box, commit the line as profiles/cpu_baseline_full.json")
+    ap.add_argument("--single-branch", action="store_true",
+                    help="BASELINE configs[1]: ONE clip through the single-branch UNet3D (batch 2 = the classifier-free-guidance pair), no ControlNet / adapter input / editors; "
+                         "use with --frames 8")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--parallel", choices=["auto", "cfg", "replicas", "frames", "cfg-frames"], default="auto")
     ap.add_argument("--shard-exchange", choices=["lean", "gather"], default="lean",
@@ -137,14 +144,13 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def cpu_baseline(usd, csd):
+def cpu_baseline(usd, csd, f=8, h=32, w=32):
     """CPU oracle (oracle/ref_cpu.py, fp32 torch, the validated restatement of the reference step) timed on ONE full
-    two-branch step with both editors active at BASELINE configs[0] -- 8 frames x 256^2 (32x32 latents), 9.3 TFLOP --
-    and scaled to the bench workload by the reference-semantics FLOP ratio."""
+    two-branch step with both editors active.  Default size: BASELINE configs[0] -- 8 frames x 256^2 (32x32 latents), 9.3 TFLOP --
+    the bounded sample of the default run; --cpu-baseline full times the bench workload itself."""
     import torch
     from oracle import ref_cpu
     cores = torch.get_num_threads()   # torch's default (physical cores); forcing every SMT thread measured 20x slower
-    f, h, w = 8, 32, 32
     x = build_inputs(f, h, w)
     to = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}  # noqa: E731
     u, c = to(usd), to(csd)
@@ -187,6 +193,18 @@ def main():
 
     import numpy as np
     import torch
+
+    if args.cpu_baseline == "full":   # host-only measurement: ONE oracle step at the bench workload, clocked; no GPU, no extrapolation
+        from motioneditor_amd import synth
+        usd = synth.synth_state_dict(synth.unet_schema())
+        csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
+        cdt, cores, cf, ch, cw = cpu_baseline(usd, csd, args.frames, args.latent, args.latent)
+        ctf, exact = step_tflop(cf, ch, cw)
+        print(json.dumps({"cpu_baseline_full": {"seconds": round(cdt, 1), "steps_per_s": round(1.0 / cdt, 6), "cores": cores, "cpu": cpu_model(), "host": socket.gethostname(),
+                                                "threads_available": os.cpu_count(), "workload": f"{cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents), two-branch + ControlNet + adapter, editors active",
+                                                "tflop_reference_semantics": ctf, "tflops": round(ctf / cdt, 3), "kind": "port", "extrapolated": False,
+                                                "what": "oracle/ref_cpu.denoise_step (fp32 torch CPU restatement of pipeline_motion_editor.py:603-648), one step, wall clock"}}), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -353,6 +371,12 @@ def main():
         from motioneditor_amd import util
         pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
         lat = lat[:1].contiguous()
+    if args.single_branch:   # BASELINE configs[1]: one clip, UNet3D only
+        if dist_on or args.inversion:
+            raise SystemExit("--single-branch is a single-GPU measurement of the plain UNet3D step")
+        pipe.unet.spatial_editor = pipe.unet.temporal_editor = None
+        pipe.controlnet = None
+        lat = lat[:1].contiguous()
 
     use_graph = args.graph and not (args.emulate or args.inversion)
 
@@ -361,6 +385,11 @@ def main():
             return util.ddim_loop(pipe, pipe.scheduler, lat, 1, normal_infer=True, text_embeddings=cond[:1])[-1]
         if args.editors == "inactive":
             sed.cur_step = ted.cur_step = 0      # the editors count steps themselves: hold them before start_step
+        if args.single_branch:
+            emb1 = torch.cat([unc[i], cond[:1]])
+            if use_graph and ops.PROFILE is None:
+                return pipe.denoise_step_graphed(lat, ts[i], emb1, None, 7.5)
+            return pipe.denoise_step(lat, ts[i], emb1, None, 7.5)
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
         graphed = use_graph and ops.PROFILE is None
         if shard is not None:
@@ -426,6 +455,8 @@ def main():
         ms = dt / args.steps * 1e3
         value = n_clips * args.steps / dt
         tf_ref, tf_exact = step_tflop(f, h, w)
+        if args.single_branch or args.inversion:   # the two-branch figure does not apply: report executed FLOPs only (below)
+            tf_ref, tf_exact = 0.0, False
         xch = ("frame<->pixel all-to-all for temporal attention (RCCL), <= 2 halo frames of K|V for the adapter's sparse-causal attention (p2p)"
                if args.shard_exchange == "lean" else "RCCL all-gather of K|V (adapter sparse-causal + temporal attention)")
         desc = {"single": "single GPU",
@@ -437,21 +468,26 @@ def main():
                           f"TemporalConv halos, GroupNorm-statistic all-reduce",
                 "replicas": f"dp{world}: one independent clip per GPU, no data-path collective"}[mode]
         out = {"metric": ("ddim-inversion steps/sec (single-branch UNet3D, normal_infer)" if args.inversion else
+                          f"denoise-steps/sec, {f}f x {8 * h}^2 single-branch UNet3D (BASELINE configs[1])" if args.single_branch else
                           f"denoise-steps/sec, {f}f x {8 * h}^2 two-branch UNet3D+ControlNet(+adapter+K/V injection)"), "value": round(value, 4),
                "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
                "higher_is_better": True, "scaling": "weak" if n_clips > 1 else "strong", "vs_baseline": None,
                "dtype": "f32 (CPU emulation of the C ABI: plumbing test, not a measurement)" if args.emulate else "f16", "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
-                                      f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights",
-                          "frames": f, "latent_hw": [h, w], "batch": 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
+               "config": {"workload": (f"BASELINE configs[1]: case-1 shape, {f} frames x {8*h}x{8*w}, ONE clip, single-branch UNet3D only (classifier-free-guidance pair = batch 2), "
+                                       f"1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights" if args.single_branch else
+                                       f"BASELINE configs[2]: case-1 shape, {f} frames x {8*h}x{8*w}, two-branch + ControlNet + adapter + K/V injection "
+                                       f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights"),
+                          "frames": f, "latent_hw": [h, w], "batch": 2 if args.single_branch else 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
                           "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
                           "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
                           "hip_graph_replay": bool(use_graph), "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
-                          "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; the ControlNet restatement (diffusers, not in the reference tree) is unpinned"},
-               "step_tflop_reference_semantics": round(tf_ref, 2), "step_tflop_is_baseline_md_figure": tf_exact,
-               "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1)}
+                          "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; ControlNet (diffusers, source not in the reference tree): TRUNK pinned "
+                                         "against the reference's own 2-D-degenerate SD-1.5 blocks (tests/golden/controlnet_trunk.npz), its 8 conditioning-embedding convolutions and "
+                                         "13 1x1 zero-convolutions self-pinned"},
+               "step_tflop_reference_semantics": round(tf_ref, 2) if tf_ref else None, "step_tflop_is_baseline_md_figure": tf_exact,
+               "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1) if tf_ref else None}
         out["host_enqueue_ms_per_step"] = round(host_dt * 1e3, 2)   # < ms_per_step: the GPU, not the Python launch loop, is the limit
         if comm is not None:
             out["comm"] = comm
@@ -478,7 +514,7 @@ def main():
             exec_tf = sum(v[4] for v in fam.values()) / args.steps / 1e12
             out["executed_tflop_per_step"] = round(exec_tf, 2)
             out["achieved_tflops_executed"] = round(exec_tf * n_clips * args.steps / dt, 1)
-            out["mfma_frac_reference_semantics"] = round(tf_ref * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4)
+            out["mfma_frac_reference_semantics"] = round(tf_ref * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4) if tf_ref else None
             out["mfma_frac_executed"] = round(exec_tf * n_clips * args.steps / dt / PEAK_MFMA_TFLOPS / world, 4)
             dom = max(kern, key=lambda k: kern[k][0])
             tsec, fl, by, n, xfl = kern[dom]
@@ -509,15 +545,25 @@ def main():
                               for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:8]}
             out["kernel_families"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
                                           "gbs": round(v[2] / v[0] / 1e9, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps} for k, v in sorted(fam.items())}
-        if world == 1 and not args.no_cpu_baseline and not args.emulate:
+        if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off" and not args.emulate and not (args.single_branch or args.inversion):
             cdt, cores, cf, ch, cw = cpu_baseline(usd, csd)
             ctf, _ = step_tflop(cf, ch, cw)
             scale = tf_ref / ctf
-            out["cpu_baseline"] = {"value": round(1.0 / (cdt * scale), 6), "unit": "steps/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
-                                   "sample": f"oracle/ref_cpu.py (fp32 torch CPU restatement of the reference step) timed on ONE full two-branch step, editors active, at BASELINE "
-                                             f"configs[0] = {cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents, {ctf} TFLOP): {cdt:.1f} s on {cores} threads = {ctf / cdt:.2f} TFLOP/s; "
-                                             f"scaled to the bench workload by the reference-semantics FLOP ratio x{scale:.1f}",
-                                   "sample_seconds": round(cdt, 2), "sample_steps_per_s": round(1.0 / cdt, 5)}
+            cb = {"value": round(1.0 / (cdt * scale), 6), "unit": "steps/s", "cores": cores, "kind": "port", "cpu": cpu_model(), "extrapolated": True,
+                  "sample": f"oracle/ref_cpu.py (fp32 torch CPU restatement of the reference step) timed on ONE full two-branch step, editors active, at BASELINE "
+                            f"configs[0] = {cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents, {ctf} TFLOP): {cdt:.1f} s on {cores} threads = {ctf / cdt:.2f} TFLOP/s; "
+                            f"scaled to the bench workload by the reference-semantics FLOP ratio x{scale:.1f}",
+                  "sample_seconds": round(cdt, 2), "sample_steps_per_s": round(1.0 / cdt, 5), "sample_extrapolated_steps_per_s": round(1.0 / (cdt * scale), 6)}
+            # the bench workload itself, clocked once per round on a GPU box's host cores (python bench.py --cpu-baseline full) and committed: when the file covers
+            # this workload, `value` is that MEASUREMENT and the bounded sample of this run stands next to it
+            full = ROOT / "profiles" / "cpu_baseline_full.json"
+            if full.exists():
+                fj = json.loads(full.read_text()).get("cpu_baseline_full", {})
+                if fj.get("workload", "").startswith(f"{f} frames x {8*h}x{8*w} "):
+                    cb.update(value=fj["steps_per_s"], extrapolated=False, cores=fj.get("cores", cores), cpu=fj.get("cpu", cb["cpu"]), full_config=fj,
+                              value_source="profiles/cpu_baseline_full.json: one oracle step at this very workload clocked on a GPU box's host cores (not in this run: it takes "
+                                           f"{fj.get('seconds')} s); the sample_* fields are this run's bounded configs[0] sample and its FLOP-ratio extrapolation")
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

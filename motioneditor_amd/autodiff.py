@@ -126,6 +126,10 @@ class Grads:
 # operator rules: (backend, grads) -> None, closed over what the forward call saw
 # ---------------------------------------------------------------------------------------------------------------------
 def _rule_gemm(B, x, w, out, kw):
+    if kw.get("res_rows") or kw.get("res2_rows"):
+        # a residual shared by several batch entries (read modulo its row count) would need its gradient SUMMED over the repeats: no rule does that yet
+        raise NotImplementedError("autodiff: gemm with a shared residual (res_rows / res2_rows) has no backward rule; record with share=False")
+
     def rule(G: Grads):
         N, taps, K = w.shape
         dy = G.view(out)

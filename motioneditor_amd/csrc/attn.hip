@@ -1230,7 +1230,7 @@ int launch_attn2(const me_attn_args* a, hipStream_t st) {
   hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d>", DH, QT, NW);
+    snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d,%s>", DH, QT, NW, FOLD ? "fold" : "classic");   // (the two variants of a shape are different kernels: bench.py / pmc_summary.py key on this)
     me_set_kernel(nm);
   }
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;

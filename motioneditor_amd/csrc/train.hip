@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float max_norm, float grad_scale) {
   float gs = grad_scale;
   if (gnorm_sq) {
+    if (!(gnorm_sq[0] < 3.0e38f)) return;   // inf / NaN gradient norm (fp16 overflow upstream): leave the masters and the moments alone
     const float total = sqrtf(gnorm_sq[0]) * grad_scale;
     gs *= fminf(1.0f, max_norm / (total + 1e-6f));
   }

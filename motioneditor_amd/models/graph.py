@@ -584,16 +584,22 @@ def controlnet_forward(P: Packed, latents: torch.Tensor, lat_index: Sequence[int
     H8, W8 = cond.shape[-2], cond.shape[-1]
     cond = cond.contiguous()
     ckey = (cond.data_ptr(), cond._version, tuple(cond.shape), cond.dtype, nimg)
-    hit = P.cache.get("cond_embed") if COND_EMBED_CACHE else None
-    if hit is not None and hit[0] == ckey:
-        c = hit[1]
+    # one entry per conditioning tensor (address, version, shape), a handful at most: a captured step (denoise_step_graphed) bakes in the address of the
+    # embedding it was captured with and holds a reference to it, so an entry that a later call with another skeleton pushes out of this table stays
+    # alive for exactly as long as a graph can replay against it
+    table = P.cache.setdefault("cond_embed", {}) if COND_EMBED_CACHE else None
+    hit = table.get(ckey) if table is not None else None
+    if hit is not None:
+        c = hit[0]
     else:
         c = Act(ops.conv_small(cond, P.mat32("controlnet_cond_embedding.conv_in.weight"), P.vec32("controlnet_cond_embedding.conv_in.bias"),
                                n_img=nimg, Cin=3, H=H8, Wd=W8, img_stride=3 * H8 * W8, ch_stride=H8 * W8, silu=True), nimg, 1, H8, W8)
         for i in range(6):
             c = conv3x3(P, f"controlnet_cond_embedding.blocks.{i}", c, stride=2 if i % 2 == 1 else 1, act=2)
-        if COND_EMBED_CACHE:
-            P.cache["cond_embed"] = (ckey, c, cond)   # cond kept alive: the key is its address
+        if table is not None:
+            while len(table) >= 4:
+                table.pop(next(iter(table)))
+            table[ckey] = (c, cond)   # cond kept alive: the key is its address
     # conv_in(sample) per ControlNet batch entry, then + cond embedding in the last cond conv's epilogue
     x0 = torch.empty((nimg * h * w, 320), dtype=P.dtype, device=dev)
     for bi, li in enumerate(lat_index):

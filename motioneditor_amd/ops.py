@@ -633,11 +633,17 @@ def layernorm_bwd(x, gamma, dy, *, eps=1e-5):
 _scratch = {}
 
 
+_scratch_retired = []   # outgrown scratch blocks: never freed -- a captured hipGraph may hold their address (me_gemm's split-K `work`)
+
+
 def _work(nbytes: int, device, tag: str) -> torch.Tensor:
-    """Grow-only fp32 scratch per (device, stream, purpose)."""
+    """Grow-only fp32 scratch per (device, stream, purpose).  A block that a larger request replaces is RETIRED, not freed: its raw pointer may sit in a
+    captured step (denoise_step_graphed), whose replays would otherwise write fp32 partial sums into memory the allocator has handed to someone else."""
     key = (str(device), _stream(), tag)
     t = _scratch.get(key)
     if t is None or t.numel() * 4 < nbytes:
+        if t is not None:
+            _scratch_retired.append(t)
         t = _scratch[key] = torch.empty((nbytes + 3) // 4 + 4, dtype=torch.float32, device=device)
     return t
 

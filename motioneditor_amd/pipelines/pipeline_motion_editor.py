@@ -42,6 +42,10 @@ class MotionEditorPipeline:
         self.scheduler = scheduler
         if getattr(self.scheduler.config, "clip_sample", False):  # reference forces clip_sample False (:108-119)
             self.scheduler.config["clip_sample"] = False
+        if getattr(self.scheduler.config, "steps_offset", 1) != 1:  # ... and steps_offset 1 on the PIPELINE's scheduler whatever the config says (:94-105)
+            self.scheduler.config["steps_offset"] = 1
+            if self.scheduler.num_inference_steps:
+                self.scheduler.set_timesteps(self.scheduler.num_inference_steps)
         self.vae_scale_factor = 8
         self.device = unet.device
         # The reference feeds ControlNet rows [1, 3] of cat([latents]*2) -- the SAME edit latent twice -- with prompts
@@ -323,7 +327,9 @@ class MotionEditorPipeline:
         else:
             mode = ("single",)
             step = lambda lat, emb: self.denoise_step(lat, t, emb, images, guidance_scale, controlnet_conditioning_scale)   # noqa: E731
-        key = (mode, tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr()),
+        # the conditioning images enter the key with their address AND version: the ControlNet's conditioning embedding is computed once per such
+        # tensor and the captured graph reads that result -- an in-place rewrite of `images` is a new tensor as far as a replay is concerned
+        key = (mode, tuple(latents.shape), tuple(text_embeddings_input.shape), None if images is None else (tuple(images.shape), images.data_ptr(), images._version),
                self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter)
         ca, cb = self.scheduler.coeffs(int(t))
         host = torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32)
@@ -351,6 +357,8 @@ class MotionEditorPipeline:
                 parallel.STATS[k][1] -= v[1]
             st["graph"] = g
             st["images"] = images      # keep the captured conditioning tensor alive
+            if self.controlnet is not None:   # ... and the conditioning embeddings the graph may have baked in (graph.controlnet_forward's table may drop them later)
+                st["cond_embed"] = dict(self.controlnet.P.cache.get("cond_embed", {}))
             for e, (cs, cl) in zip(editors, counters):
                 e.cur_step, e.cur_att_layer = cs, cl
             ent = self._graphs[key] = st

@@ -199,6 +199,7 @@ class AdapterTrainer:
         self.unet, self.prefix, self.group, self.max_grad_norm = unet, prefix, group, max_grad_norm
         self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         self.steps = 0
+        self.skipped_steps = 0           # optimisation steps dropped because the gradient norm was not finite (fp16 overflow)
         P = unet.P
         P.make_private()                 # a private, mutable weight store
         self.names = sorted(k[len(P.prefix):] for k in P.state if k.startswith(P.prefix + prefix))
@@ -248,8 +249,13 @@ class AdapterTrainer:
             lt = torch.tensor([loss], dtype=torch.float32, device=self.grad.device)
             dist.all_reduce(lt, group=self.group)                        # train_adaptor.py:377 (accelerator.gather(loss).mean())
             loss = float(lt[0]) / world
-        self.steps += 1
         gn = B_.sumsq_absmax(self.grad)                                   # device scalar: sum of squares of the (scaled, summed) bucket
+        if not bool(torch.isfinite(gn.reshape(-1)[0])):
+            # an fp16 overflow somewhere downstream of the seed (the loss scale is chosen from the seed's magnitude): an inf / NaN gradient would
+            # poison the masters and Adam's moments for good.  Skip the update, as accelerate's GradScaler does for the reference's fp16 runs.
+            self.skipped_steps += 1
+            return loss
+        self.steps += 1
         B_.adamw(self.master, self.m, self.v, self.grad, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps, weight_decay=self.weight_decay,
                  step=self.steps, gnorm_sq=gn, max_grad_norm=self.max_grad_norm, grad_scale=1.0 / (ls * world))
         B_.cast_f16(self.weights, self.master)                            # the packed weights of the next forward, in place
@@ -263,4 +269,6 @@ class AdapterTrainer:
         for k in self.keys:
             o, n = self.off[k]
             out.update(P.unpack_grad(k, self.master[o:o + n].view(self.views[k].shape)))
+        for name, val in out.items():    # the model's own state follows the training: state_dict() / named_parameters() / .to(device) see the trained values
+            P.state[P.prefix + name] = val.detach().cpu().clone()
         return out

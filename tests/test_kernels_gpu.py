@@ -305,6 +305,42 @@ def test_full_size_properties_of_the_level0_kernels(ops):
     assert float(gn.mean((1, 3)).abs().max()) < 1e-3 and float((gn.var((1, 3), unbiased=False) - 1).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("dh,N,kind", [(40, 9216, "pc"), (40, 9216, "ed_bin"), (80, 2304, "pc"), (80, 2304, "ed_bin"), (160, 576, "pc")])
+def test_attention_at_the_96x96_latent_geometry(ops, dh, N, kind):
+    """BASELINE configs[4]'s spatial geometry (768^2 images): 9216 tokens at level 0 (18 query blocks of 512, 36 stages of 256 keys per segment),
+    2304 at level 1 (dh = 80: 18 blocks of 128 queries, 36 key tiles per segment), 576 at level 2 -- non-power-of-two block / tile counts that the
+    64x64-latent tests never see.  (1) constant values come back whatever the scores; (2) the output matches the fp32 reference on a random subset
+    of 160 query rows per item; (3) the head-major K | V form is bitwise the row-major one."""
+    from motioneditor_amd import segments
+    C = 8 * dh
+    if kind == "pc":
+        B, f = 1, 2
+        si, sm = segments.prev_cur(B, f, "cpu")
+        n_items, mask = B * f, None
+    else:
+        B, f = 2, 1
+        si, sm = segments.edited_spatial(f, "cpu", binary_mask=True, B=B)
+        mask = (torch.rand(8, N, generator=torch.Generator().manual_seed(11)) > 0.5).half()
+        n_items = B * f
+    qkv = rnd(n_items * N, 3 * C, seed=3)
+    qkv[N // 2 + 5, C:2 * C] *= 4.0
+    qkv[N - 3, C:2 * C] *= 6.0
+    args = dict(heads=8, dh=dh, n_items=n_items, nk=N)
+    dq = cu(qkv)
+    kw = dict(seg_item=cu(si), seg_mode=cu(sm), mask=None if mask is None else cu(mask), nq=N, **args)
+    got = ops.attention(dq[:, :C], dq[:, C:2 * C], dq[:, 2 * C:], **kw)
+    vconst = torch.full((n_items * N, C), 0.75, dtype=torch.float16, device="cuda")
+    o = ops.attention(dq[:, :C], dq[:, C:2 * C], vconst, **kw)
+    assert float((o.float() - 0.75).abs().max()) <= 1e-3
+    kv = dq[:, C:].reshape(n_items * N, 16, dh).permute(1, 0, 2).contiguous()
+    assert torch.equal(ops.attention(dq[:, :C], kv[:8], kv[8:], **kw), got)
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(5))[:160].sort().values
+    rows = torch.cat([it * N + idx for it in range(n_items)])
+    want = emu.attention(qkv[rows, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, mask=mask, nq=idx.numel(), **args)
+    peak = float(want.float().abs().max() / want.float().abs().mean())
+    check(got.cpu()[rows], want, f"attn 96x96 geometry dh={dh} N={N} {kind}", mx=2e-3 * peak)
+
+
 def test_gemm_rejects_bad_arguments(ops):
     x, w = cu(rnd(16, 12)), cu(rnd(8, 1, 12))
     with pytest.raises(ValueError):

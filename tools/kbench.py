@@ -234,6 +234,28 @@ def bench_attn_headmajor():
         print(f"L0 prev|cur head-major K/V {name:16s} {ms:8.3f} ms {4.0*8*N*N*2*B*f*dh/ms/1e9:9.1f} TF/s(ref)")
 
 
+def bench_attn_headmajor_panels():
+    """The production form of head-major K | V: the fused q|k|v projection writes K and V as [16, rows, dh] panels (me_gemm_args.C2), the attention reads
+    them through head strides -- against the row-major form, projection and attention timed separately (level 0 and level 1, [prev | cur] and edited)."""
+    B, f = 4, 24
+    for dh, N in ((40, 4096), (80, 1024)):
+        C = 8 * dh
+        x, w = rnd(B * f * N, C), rnd(3 * C, 1, C) * (C ** -0.5)
+        t_rm = timeit(lambda: ops.gemm(x, w))
+        t_hm = timeit(lambda: ops.gemm(x, w, head_major=(C, dh)))
+        qkv = ops.gemm(x, w)
+        q, kv = ops.gemm(x, w, head_major=(C, dh))
+        print(f"dh {dh}: q|k|v projection row-major {t_rm:.3f} ms, head-major K|V {t_hm:.3f} ms")
+        for seg in ("pc", "ed"):
+            si, sm = segments.prev_cur(B, f, dev) if seg == "pc" else segments.edited_spatial(f, dev, True)
+            mk = (torch.rand(8, N, device=dev) > 0.5).half() if seg == "ed" else None
+            kw = dict(heads=8, dh=dh, n_items=B * f, nq=N, nk=N, seg_item=si, seg_mode=sm, mask=mk)
+            a_rm = timeit(lambda: ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], **kw))
+            a_hm = timeit(lambda: ops.attention(q, kv[:8], kv[8:], **kw))
+            print(f"   attention {seg}: row-major {a_rm:.3f} ms, head-major {a_hm:.3f} ms ({100 * (a_hm / a_rm - 1):+.1f} %)")
+        del x, w, qkv, q, kv
+
+
 def bench_misc():
     B, f = 4, 24
     for C, hw in [(320, 64), (640, 32), (1280, 16)]:
@@ -307,6 +329,8 @@ if __name__ == "__main__":
         bench_gemm_cached()
     if "attnhm" in what:
         bench_attn_headmajor()
+    if "attnhmp" in what:
+        bench_attn_headmajor_panels()
     if "attn1" in what:
         bench_attn(True)
     if "misc" in what:

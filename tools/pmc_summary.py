@@ -18,9 +18,9 @@ def per_kernel(db):
 def short(k: str):
     """rocprofv3 kernel name -> the name me_last_kernel() / bench.py use (first template arguments only)."""
     import re
-    m = re.search(r"(attn2_kernel)<(\d+), (\d+), (\d+)", k)
+    m = re.search(r"(attn2_kernel)<(\d+), (\d+), (\d+), \d+, \d+, \d+, (true|false)", k)
     if m:
-        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>"
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)},{'fold' if m.group(5) == 'true' else 'classic'}>"
     m = re.search(r"(gemm8p_kernel)<(\d+), (\d+), (true|false)", k)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>"
