@@ -20,7 +20,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(str(capi.LIB_PATH))
     for name in declared:
         getattr(L, name)
-    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 5
+    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 6
 
 
 def test_argument_validation_returns_einval_without_a_device():
@@ -31,8 +31,20 @@ def test_argument_validation_returns_einval_without_a_device():
     a.X = a.W = a.C = 4096
     a.M, a.N, a.K, a.ldx, a.ldc = 8, 8, 12, 16, 8
     assert L.me_gemm(ctypes.byref(a), None) == capi.ME_EINVAL and b"multiples" in L.me_last_error()
+    # ABI 6: the head-major second output needs a term-free epilogue, whole heads and aligned panels; the head strides of me_attn multiples of 8
+    a.K, a.N, a.M, a.ldc = 16, 48, 8, 48
+    a.C2, a.c2_col0, a.c2_dh, a.c2_hs = 4096, 16, 16, 8 * 16
+    a.res, a.ldr = 4096, 48
+    assert L.me_gemm(ctypes.byref(a), None) == capi.ME_EINVAL and b"head-major" in L.me_last_error()
+    a.res, a.c2_dh = None, 12
+    assert L.me_gemm(ctypes.byref(a), None) == capi.ME_EINVAL and b"head-major" in L.me_last_error()
     t = capi.AttnArgs()
     t.Q = t.K = t.V = t.O = t.seg_item = t.seg_mode = 4096
+    t.n_items, t.nq, t.nk, t.heads, t.nseg, t.dh = 1, 1, 1, 8, 1, 40
+    t.ldq = t.ldk = t.ldv = t.ldo = 320
+    t.hsk = 12
+    assert L.me_attn(ctypes.byref(t), None) == capi.ME_EINVAL and b"head strides" in L.me_last_error()
+    t.hsk = 0
     t.n_items, t.nq, t.nk, t.heads, t.nseg, t.dh = 1, 1, 1, 8, 1, 64
     t.ldq = t.ldk = t.ldv = t.ldo = 512
     assert L.me_attn(ctypes.byref(t), None) == capi.ME_EINVAL and b"head dim" in L.me_last_error()
