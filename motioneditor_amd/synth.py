@@ -294,7 +294,41 @@ def synth_tensor(name: str, shape: Shape, seed: int = 33) -> np.ndarray:
 
 
 def synth_state_dict(schema: Dict[str, Shape], seed: int = 33, salt: str = "") -> "OrderedDict[str, np.ndarray]":
-    return OrderedDict((k, synth_tensor(salt + k, shp, seed)) for k, shp in schema.items())
+    """The deterministic synthetic weights of a schema.  Generating the 1.3 G parameters of the UNet takes a minute of one core, and the tests / bench /
+    multi-process launches of one session each want them: the flat fp32 image is kept in a per-machine cache file (ME_SYNTH_CACHE, default
+    <tmp>/me_synth_cache; ME_SYNTH_CACHE=0 disables), keyed by the schema, the seed, the salt and the generator's own source text."""
+    import inspect
+    import os
+    import tempfile
+    cache = os.environ.get("ME_SYNTH_CACHE", os.path.join(tempfile.gettempdir(), "me_synth_cache"))
+    total = sum(int(np.prod(shp)) for shp in schema.values())
+    path = None
+    if cache != "0" and total >= 1 << 20:
+        key = zlib.crc32(repr((sorted(schema.items()), seed, salt, inspect.getsource(synth_tensor))).encode())
+        path = os.path.join(cache, f"w_{key:08x}_{total}.npy")
+        if os.path.exists(path):
+            try:
+                flat = np.load(path)
+                if flat.shape == (total,) and flat.dtype == np.float32:
+                    out, o = OrderedDict(), 0
+                    for k, shp in schema.items():
+                        n = int(np.prod(shp))
+                        out[k] = flat[o:o + n].reshape(shp)
+                        o += n
+                    return out
+            except Exception:   # a torn or foreign file: regenerate
+                pass
+    out = OrderedDict((k, synth_tensor(salt + k, shp, seed)) for k, shp in schema.items())
+    if path is not None:
+        try:
+            os.makedirs(cache, exist_ok=True)
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as fh:
+                np.save(fh, np.concatenate([v.reshape(-1) for v in out.values()]))
+            os.replace(tmp, path)   # atomic: concurrent ranks either see the whole file or none
+        except OSError:
+            pass
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
