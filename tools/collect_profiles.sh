@@ -27,6 +27,8 @@ timeout 300 python tools/kbench.py gemm8p > gpurun_out/${tag}_kbench_8p.txt 2>&1
 # secondary measurements: null-text inner iteration, other shapes, the frame-sharded path on one rank (eager / captured)
 timeout 400 python bench.py --null-text --steps 3 --warmup 1 > gpurun_out/${tag}_nulltext.log 2>&1; tail -1 gpurun_out/${tag}_nulltext.log > gpurun_out/${tag}_bench_nulltext.json
 timeout 300 python bench.py --frames 8 --latent 32 --steps 6 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_8f_256.json
+timeout 300 python bench.py --single-branch --frames 8 --steps 10 --warmup 3 2>&1 | tail -1 > gpurun_out/${tag}_bench_single_branch_8f_512.json   # BASELINE configs[1]
+timeout 120 python tools/kbench.py attnhmp > gpurun_out/${tag}_attn_headmajor.txt 2>&1
 timeout 600 python bench.py --frames 48 --latent 96 --steps 2 --warmup 1 --no-cpu-baseline --no-profile 2>&1 | tail -1 > gpurun_out/${tag}_bench_48f_768.json
 timeout 300 python bench.py --parallel frames --graph --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | grep '^{' | tail -1 > gpurun_out/${tag}_bench_frames1_graph.json
 timeout 300 python bench.py --parallel frames --steps 4 --warmup 2 --no-cpu-baseline --no-profile 2>&1 | grep '^{' | tail -1 > gpurun_out/${tag}_bench_frames1_eager.json
