@@ -109,6 +109,10 @@ typedef struct me_gemm_args {
   void* C2;
   int32_t c2_col0, c2_dh;
   int64_t c2_hs;      /* elements between the panels of consecutive heads (>= M * c2_dh) */
+  /* ABI 6: row range.  m_off > 0: the launch computes output rows [m_off, M) only (row indices, gather geometry, residual and rowvec rows all stay
+   * absolute).  A frame-sharded TemporalConv (resnet_2d.py:18-26 over a rank's frames) is issued as an interior launch -- frames that need no remote
+   * data -- behind the posted halo exchange, and boundary launches after it.  DENSE / TCONV only; such a launch is never split along K. */
+  int32_t m_off;
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);

@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ("bias", _vp), ("rowvec", _vp), ("ldrv", _i32), ("rows_per_vec", _i32),
         ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32), ("res_rows", _i32), ("res2_rows", _i32),
         ("work", _vp), ("work_bytes", _i64), ("splits_", _i32), ("sel_rows", _i32),
-        ("C2", _vp), ("c2_col0", _i32), ("c2_dh", _i32), ("c2_hs", _i64),
+        ("C2", _vp), ("c2_col0", _i32), ("c2_dh", _i32), ("c2_hs", _i64), ("m_off", _i32),
     ]
 
 

@@ -466,10 +466,10 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   const int wm = wave >> 1, wn = wave & 1;
 
   const int nbn = (a.N + BN - 1) / BN;
-  const int nbm = (a.M + BM - 1) / BM;
+  const int nbm = (a.M - a.m_off + BM - 1) / BM;   // tiles cover the rows [m_off, M)
   const int w = xcd_remap(blockIdx.x, nbm * nbn);
   const int tile_n = w % nbn, tile_m = w / nbn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_off + tile_m * BM, n0 = tile_n * BN;
 
   const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
   const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
@@ -870,10 +870,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   const int wr = wave >> 2, wc = wave & 3;
 
   const int nbn = (a.N + BN - 1) / BN;
-  const int nbm = (a.M + BM - 1) / BM;
+  const int nbm = (a.M - a.m_off + BM - 1) / BM;   // tiles cover the rows [m_off, M)
   const int w = xcd_remap(blockIdx.x, nbm * nbn);
   const int tile_n = w % nbn, tile_m = w / nbn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_off + tile_m * BM, n0 = tile_n * BN;
 
   const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
   const f16* __restrict__ W = reinterpret_cast<const f16*>(a.W);
@@ -1161,7 +1161,7 @@ int choose_split(const me_gemm_args* a, long blocks, int nit) {
   // N >= 1280 only (the 16 x 16- and 8 x 8-latent levels): a split changes the fp32 summation order, and the level-0 / level-1 launches must give
   // the same rows whatever the batch size -- the UNet graph runs its first blocks on half the batch (classifier-free-guidance prefix) and the
   // step has to stay bitwise the same.  (A 20-tile K loop measured slower split than whole: 32 tiles at least.)
-  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32 || a->C2) return 1;
+  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32 || a->C2 || a->m_off) return 1;
   int S = (int)((640 + blocks - 1) / blocks);
   if (S > 4) S = 4;
   if (S > nit / 4) S = nit / 4;
@@ -1257,7 +1257,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
     }
     attr_set = true;
   }
-  const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
+  const int nbm = (a->M - a->m_off + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();  // drop stale errors left by other HIP users in this thread
   me_gemm_args b = *a;
   b.splits_ = 0;
@@ -1301,7 +1301,7 @@ static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
     }
     attr_set = true;
   }
-  const int nbm = (a->M + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
+  const int nbm = (a->M - a->m_off + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();
   hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, *a);
   {
@@ -1362,7 +1362,8 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   }
   if (a->gather == ME_GATHER_TCONV) {
     const int ftot = a->frames_total > 0 ? a->frames_total : a->frames;
-    if (a->frames <= 0 || a->npix <= 0 || a->chunk <= 0 || ftot % a->chunk || a->M % (a->frames * a->npix) || a->frame0 < 0 ||
+    // (a row-range launch, m_off > 0 or M cut short, ends where its caller says: rows must then be whole pixels' rows of the full problem, which the caller owns)
+    if (a->frames <= 0 || a->npix <= 0 || a->chunk <= 0 || ftot % a->chunk || (a->m_off == 0 && a->sel_rows <= a->M && a->M % (a->frames * a->npix)) || a->frame0 < 0 ||
         a->frame0 + a->frames > ftot) { me_set_error("me_gemm: bad tconv geometry"); return ME_EINVAL; }
   }
   if (a->rowvec && (a->rows_per_vec <= 0 || a->ldrv % 4 || ((uintptr_t)a->rowvec & 7))) { me_set_error("me_gemm: bad rowvec"); return ME_EINVAL; }
@@ -1372,6 +1373,7 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (a->act < 0 || a->act > 2) { me_set_error("me_gemm: bad activation"); return ME_EINVAL; }
   if (a->bias && ((uintptr_t)a->bias & 7)) { me_set_error("me_gemm: misaligned bias"); return ME_EINVAL; }
   if (a->geglu && (a->N % 32 || a->rowvec || a->res || a->res2 || a->act || a->alpha != 1.0f)) { me_set_error("me_gemm: geglu needs N % 32 == 0, alpha == 1 and no rowvec/res/act"); return ME_EINVAL; }
+  if (a->m_off < 0 || a->m_off >= a->M || (a->m_off > 0 && a->gather == ME_GATHER_CONV3)) { me_set_error("me_gemm: m_off must lie in [0, M) and is for dense / TemporalConv launches"); return ME_EINVAL; }
   if (a->C2 && (a->geglu || a->act || a->rowvec || a->res || a->res2 || a->c2_dh <= 0 || a->c2_dh % 8 || a->c2_col0 < 0 || a->c2_col0 % 16 || a->c2_col0 >= a->N ||
                 (a->N - a->c2_col0) % a->c2_dh || a->c2_hs % 8 || a->c2_hs < (int64_t)a->M * a->c2_dh || ((uintptr_t)a->C2 & 15) || a->gather == ME_GATHER_CONV3)) {
     me_set_error("me_gemm: head-major output (C2) needs a term-free epilogue, c2_dh % 8 == 0, c2_col0 % 16 == 0, whole heads, c2_hs % 8 == 0 and >= M * c2_dh, 16-byte alignment");

@@ -21,6 +21,7 @@ from ..weights import Packed
 HEADS = 8
 ADAPTER_CHUNK = 8  # hard-coded num_frames=8 in the reference adapter (controlnet_adapter.py:414,438,472)
 HEAD_MAJOR_KV = __import__("os").environ.get("ME_HEAD_MAJOR_KV", "1") != "0"   # attn1: K and V leave the fused q|k|v projection as per-head [rows, dh] panels (me_gemm_args.C2 / me_attn_args.hsk); A/B switch
+SPLIT_SHARDED_TCONV = __import__("os").environ.get("ME_SPLIT_TCONV", "1") != "0"   # frame-sharded TemporalConv: interior frames behind the posted halo exchange, boundary frames after it
 COND_EMBED_CACHE = True   # ControlNet conditioning embedding of an unchanged skeleton tensor is computed once per run (controlnet_forward)
 
 
@@ -197,6 +198,27 @@ def _tconv(P: Packed, name: str, h_ext: torch.Tensor, x: "Act", chunk: int, shar
     rows = x.B * x.f * x.N
     if shard is None:
         return ops.gemm(h_ext, P.mat(name + ".weight"), M=rows, bias=P.vec(name + ".bias"), tconv=(x.f, x.N, chunk), **epi)
+    if SPLIT_SHARDED_TCONV and x.f >= 3 and getattr(ops, "ROW_RANGE", False) and not ops.gemm_splits_k(rows, P.mat(name + ".weight").shape[0], h_ext.shape[1], 3):
+        # (launches that me_gemm splits along K -- the 8 x 8-latent level -- keep the one-launch form: a row-range piece is never split, and the
+        # summation orders must agree for the sharded step to stay bitwise equal to the plain one)
+        # Interior / boundary split: the halo exchange is POSTED, the frames that need no remote data (1 .. f - 2 of every batch entry) are computed
+        # while it travels, then the exchange is joined and the boundary frames follow -- consecutive batch entries' (last, first) frames are
+        # neighbouring rows and share a launch.  Same arithmetic per output row as the one-launch form (bitwise: the kernels accumulate taps and
+        # channel slabs in one order), 2 B + 1 launches instead of 1.
+        w, b = P.mat(name + ".weight"), P.vec(name + ".bias")
+        out = epi.pop("out", None)
+        if out is None:
+            out = torch.empty((rows, w.shape[0]), dtype=h_ext.dtype, device=h_ext.device)
+        handle = shard.exchange_halos(h_ext, x.B, x.N, ops.copy_rows, defer=True)
+        interior = (x.f, x.N, chunk, shard.frame0, shard.f_total, -1, -1)      # (never reads a halo row)
+        for bi in range(x.B):
+            ops.gemm(h_ext, w, M=rows, bias=b, tconv=interior, out=out, row_range=((bi * x.f + 1) * x.N, (bi * x.f + x.f - 1) * x.N), **epi)
+        hp, hn = shard.finish_halos(handle)
+        full = (x.f, x.N, chunk, shard.frame0, shard.f_total, hp, hn)
+        bounds = [(0, x.N)] + [((bi * x.f - 1) * x.N, (bi * x.f + 1) * x.N) for bi in range(1, x.B)] + [(rows - x.N, rows)]
+        for lo, hi in bounds:
+            ops.gemm(h_ext, w, M=rows, bias=b, tconv=full, out=out, row_range=(lo, hi), **epi)
+        return out
     hp, hn = shard.exchange_halos(h_ext, x.B, x.N, ops.copy_rows)
     return ops.gemm(h_ext, P.mat(name + ".weight"), M=rows, bias=P.vec(name + ".bias"),
                     tconv=(x.f, x.N, chunk, shard.frame0, shard.f_total, hp, hn), **epi)

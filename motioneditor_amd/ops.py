@@ -70,6 +70,7 @@ def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((rows, cols), dtype=F16, device=like.device)
 
 
+ROW_RANGE = True       # this backend implements gemm(row_range=...) (me_gemm_args.m_off)
 HEAD_MAJOR_KV = True   # this backend implements gemm(head_major=...) / 3-D k, v in attention (the CPU emulation and the autodiff recorder do not)
 
 
@@ -77,11 +78,14 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
          bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rows_per_vec: int = 0,
          res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
-         tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0, head_major: Optional[Tuple[int, int]] = None):
+         tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0, head_major: Optional[Tuple[int, int]] = None,
+         row_range: Optional[Tuple[int, int]] = None):
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
 
     w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
     3 for ``tconv=(frames, npix, chunk)``).  res_rows / res2_rows > 0: res / res2 holds that many rows, output row m reads row m % rows.
+    row_range = (lo, hi): only the output rows [lo, hi) of the M-row problem are computed (into `out`, which must be given and hold all M rows): the
+    interior / boundary launches of a frame-sharded TemporalConv (me_gemm_args.m_off).
     head_major = (col0, dh): the output columns from col0 on leave as a second tensor [(N - col0) / dh, M, dh] -- one contiguous [rows, dh]
     panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels)."""
     _chk2d(x, "gemm.x")
@@ -119,12 +123,20 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
         a.C2, a.c2_col0, a.c2_dh, a.c2_hs = panels.data_ptr(), col0, hdh, M * hdh
         n_out = col0
     if out is None:
+        if row_range is not None:
+            raise ValueError("gemm: row_range writes into a caller-provided `out` of all M rows")
         out = empty(M, n_out, x)
     _chk2d(out, "gemm.out")
     if out.shape[0] < M or out.shape[1] < n_out:
         raise ValueError("gemm: out too small")
     a.X, a.W, a.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     a.M, a.N, a.K = M, N, K
+    if row_range is not None:
+        lo, hi = row_range
+        if not (0 <= lo < hi <= M) or conv is not None:
+            raise ValueError("gemm: row_range must lie inside [0, M) (dense / TemporalConv launches)")
+        a.m_off, a.M = lo, hi
+        a.sel_rows = max(a.sel_rows, M)      # pick kernels as the whole launch would
     a.ldx, a.ldc = x.stride(0), out.stride(0)
     a.bias = _p(bias)
     if rowvec is not None:
@@ -159,6 +171,17 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
             f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
     out = out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
     return out if panels is None else (out, panels)
+
+
+def gemm_splits_k(M: int, N: int, K: int, taps: int = 1) -> bool:
+    """Would me_gemm split this launch along K (small grids at N >= 1280, me_gemm_work_bytes > 0)?  A split changes the fp32 summation order, so a caller that
+    wants row-range pieces (never split) to equal the one-launch form bit for bit asks first."""
+    if not (N >= 1280 and M <= 8192):
+        return False
+    a = GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.gather = capi.GATHER_TCONV if taps == 3 else (capi.GATHER_CONV3 if taps == 9 else capi.GATHER_DENSE)
+    return capi.lib().me_gemm_work_bytes(C.byref(a)) > 0
 
 
 def conv_small(inp: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], *, n_img: int, Cin: int, H: int, Wd: int,

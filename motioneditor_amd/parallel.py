@@ -220,7 +220,7 @@ class FrameShard:
         return ChunkHalo(self, chunk)
 
     # ---- one-frame halos for the temporal convolutions --------------------------------------------------
-    def exchange_halos(self, x_ext: torch.Tensor, B: int, npix: int, copy_rows) -> tuple:
+    def exchange_halos(self, x_ext: torch.Tensor, B: int, npix: int, copy_rows, defer: bool = False) -> tuple:
         """x_ext rows = [B*f_loc*npix local | B*npix halo of the previous rank | B*npix halo of the next rank].
         Sends this rank's first / last frame to its neighbours and receives theirs.  Returns (halo_prev_row,
         halo_next_row) with -1 where there is no neighbour."""
@@ -241,8 +241,17 @@ class FrameShard:
                 copy_rows(last[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
             _count("p2p(TemporalConv halo)", last)
             ops_ += [("send", last, self.rank + 1), ("recv", next_blk, self.rank + 1)]
-        self.x.finish(self.x.p2p_start(ops_))      # nothing independent sits between this layer's producer and its consumer: joined at once
-        return (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)
+        reqs = self.x.p2p_start(ops_)
+        hrows = (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)
+        if defer:      # the caller runs the interior frames (no remote data) while the halos travel, then joins: finish_halos(handle)
+            return (reqs, hrows, first, last)
+        self.x.finish(reqs)
+        return hrows
+
+    def finish_halos(self, handle) -> tuple:
+        reqs, hrows, _first, _last = handle      # (the send buffers stay alive until the exchange is joined)
+        self.x.finish(reqs)
+        return hrows
 
 
 class PrevFrameHalo:

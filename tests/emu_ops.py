@@ -21,12 +21,25 @@ def _f(t):
     return None if t is None else t.float()
 
 
+ROW_RANGE = True   # gemm(row_range=...) is emulated (the frame-sharded TemporalConv split)
+
+
+def gemm_splits_k(M, N, K, taps=1):
+    return False
+
+
 def empty(rows, cols, like):
     return torch.empty((rows, cols), dtype=like.dtype, device=like.device)
 
 
 def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=None, res2=None, geglu=False, act=0, alpha=1.0,
-         conv=None, tconv=None, res_rows=0, res2_rows=0):
+         conv=None, tconv=None, res_rows=0, res2_rows=0, row_range=None):
+    if row_range is not None:   # rows [lo, hi) of the full launch, written into `out`
+        lo, hi = row_range
+        full = gemm(x, w, M=M, bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res=res, res2=res2, geglu=geglu, act=act, alpha=alpha, conv=conv, tconv=tconv,
+                    res_rows=res_rows, res2_rows=res2_rows)
+        out[lo:hi, :full.shape[1]] = full[lo:hi]
+        return out[:full.shape[0], :full.shape[1]]
     N, taps, K = w.shape
     xf, wf = x.float()[:, :K], w.float()
     if conv is not None:

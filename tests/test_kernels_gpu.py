@@ -705,6 +705,33 @@ def test_gemm_tconv_sharded_with_halos(ops, C, f_loc, f_tot, frame0, chunk, npix
     check(got, emu.gemm(x, w, M=rows, bias=bias, tconv=tc, res=res), f"tconv sharded f_loc={f_loc} frame0={frame0} chunk={chunk}")
 
 
+@pytest.mark.parametrize("C,f_loc,f_tot,frame0,npix,nb", [(320, 6, 24, 6, 4096, 2), (640, 3, 24, 21, 1024, 4), (1280, 12, 24, 0, 256, 2), (320, 4, 16, 4, 100, 3), (1280, 6, 24, 12, 64, 2)])
+def test_gemm_row_range_pieces_of_a_sharded_tconv_equal_the_one_launch_form(ops, C, f_loc, f_tot, frame0, npix, nb):
+    """me_gemm_args.m_off: the interior launches (frames 1 .. f_loc - 2 of every batch entry, issued while the halo exchange travels) and the boundary
+    launches (first frame | (last, first) pairs of neighbouring batch entries | last frame) of a frame-sharded TemporalConv must reproduce the one-launch
+    result BIT FOR BIT -- with the time-embedding row vector and residual terms of temp_conv1 (absolute row indices) -- at the level-0 ... level-3
+    geometries of 4- and 8-way frame sharding."""
+    rows, hb = nb * f_loc * npix, nb * npix
+    x = rnd(rows + 2 * hb, C, seed=1).cuda()
+    w = (rnd(C, 3, C, seed=2, scale=(3 * C) ** -0.5)).cuda()
+    bias, res, rv = rnd(C, seed=3).cuda(), rnd(rows, C, seed=4).cuda(), rnd(nb, C, seed=5).cuda()
+    hp = rows if frame0 > 0 else -1
+    hn = rows + hb if frame0 + f_loc < f_tot else -1
+    epi = dict(bias=bias, res=res, rowvec=rv, rows_per_vec=f_loc * npix)
+    want = ops.gemm(x, w, M=rows, tconv=(f_loc, npix, f_tot, frame0, f_tot, hp, hn), **epi)
+    if ops.gemm_splits_k(rows, C, C, 3):   # the one-launch form MAY be split along K (another summation order): graph._tconv keeps it whole then
+        return
+    out = torch.full((rows, C), float("nan"), dtype=torch.float16, device="cuda")
+    for bi in range(nb):
+        ops.gemm(x, w, M=rows, tconv=(f_loc, npix, f_tot, frame0, f_tot, -1, -1), out=out, row_range=((bi * f_loc + 1) * npix, (bi * f_loc + f_loc - 1) * npix), **epi)
+    bounds = [(0, npix)] + [((bi * f_loc - 1) * npix, (bi * f_loc + 1) * npix) for bi in range(1, nb)] + [(rows - npix, rows)]
+    for lo, hi in bounds:
+        ops.gemm(x, w, M=rows, tconv=(f_loc, npix, f_tot, frame0, f_tot, hp, hn), out=out, row_range=(lo, hi), **epi)
+    assert torch.equal(out, want)
+    with pytest.raises(Exception):
+        ops.gemm(x, w, M=rows, tconv=(f_loc, npix, f_tot, frame0, f_tot, hp, hn), out=out, row_range=(rows, rows + 1))
+
+
 def test_groupnorm_with_cross_rank_statistic_reduction_hook(ops):
     """stats -> reduce hook -> apply with the global count: doubling the statistics and the count must be the identity."""
     C, rows, rpg = 640, 4 * 96, 96
