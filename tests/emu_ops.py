@@ -75,6 +75,8 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
                     src = loc[:, ls]
                 else:
                     h0 = hp if ls < 0 else hn
+                    if h0 < 0:      # no halo block given (me_gemm: the tap contributes nothing): a row-range launch over interior frames never needs one
+                        continue
                     src = xf[h0:h0 + nb * npix].reshape(nb, npix, K)
                 acc[:, fr] += src @ wf[:, tap].t()
         acc = acc.reshape(-1, N)
