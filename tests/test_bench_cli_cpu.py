@@ -39,3 +39,35 @@ def test_mode_resolution():
     assert bench.resolve_mode(a, 8) == ("frames", 1, 8, 1)
     a.parallel = "replicas"
     assert bench.resolve_mode(a, 4) == ("replicas", 1, 1, 4)
+
+
+def test_cpu_baseline_full_mode_prints_one_clocked_line_without_a_gpu():
+    """`bench.py --cpu-baseline full`: host-only, ONE oracle step at the requested workload, one JSON line (what is committed as
+    profiles/cpu_baseline_full.json at the bench workload) -- here at 8 frames x 8x8 latents."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--cpu-baseline", "full", "--frames", "8", "--latent", "8"], capture_output=True, text=True, timeout=900,
+                       cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])["cpu_baseline_full"]
+    assert d["extrapolated"] is False and d["seconds"] > 0 and d["kind"] == "port" and d["workload"].startswith("8 frames x 64x64 ")
+    # the committed full-config figure is the bench workload's and is what the default run reports as cpu_baseline.value
+    full = json.loads((ROOT / "profiles" / "cpu_baseline_full.json").read_text())["cpu_baseline_full"]
+    assert full["workload"].startswith("24 frames x 512x512 ") and full["extrapolated"] is False and full["seconds"] > 60
+
+
+def test_synthetic_weight_cache_returns_the_generated_tensors(tmp_path, monkeypatch):
+    import numpy as np
+    sys.path.insert(0, str(ROOT))
+    from motioneditor_amd import synth
+    schema = {"a.weight": (1024, 640), "b.bias": (640,), "c.weight": (640, 3, 320)}
+    monkeypatch.setenv("ME_SYNTH_CACHE", "0")
+    ref = synth.synth_state_dict(schema, seed=5, salt="t.")
+    monkeypatch.setenv("ME_SYNTH_CACHE", str(tmp_path))
+    first = synth.synth_state_dict(schema, seed=5, salt="t.")
+    assert len(list(tmp_path.iterdir())) == 1
+    again = synth.synth_state_dict(schema, seed=5, salt="t.")
+    for k in schema:
+        assert np.array_equal(ref[k], first[k]) and np.array_equal(ref[k], again[k]) and again[k].shape == tuple(schema[k])
+    other = synth.synth_state_dict(schema, seed=6, salt="t.")
+    assert not np.array_equal(other["a.weight"], ref["a.weight"]) and len(list(tmp_path.iterdir())) == 2
