@@ -80,6 +80,9 @@ def parse_args():
                     help="replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from Python -- "
                          "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
                          "measured neutral (the GPU, not the host, paces the step); across GPUs it could only be validated on a world-1 RCCL group")
+    ap.add_argument("--plan", action="store_true",
+                    help="single-GPU modes: execute the step behind the C ABI's step-level entry point (me_plan_* / me_denoise_step, csrc/plan.hip: the launch list "
+                         "recorded once, re-issued from C on the two live HIP streams; bitwise the eager result) instead of enqueueing its ~1100 launches from Python")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="who issues the data-path exchanges of the sharded modes: 'torch' = torch.distributed's nccl (= RCCL) process group; 'rccl' = RCCL called "
                          "directly on our own communicators (motioneditor_amd/rccl.py: no watchdog, capturable); auto = rccl with --graph, else torch")
@@ -379,6 +382,9 @@ def main():
         lat = lat[:1].contiguous()
 
     use_graph = args.graph and not (args.emulate or args.inversion)
+    use_plan = args.plan and not (args.emulate or args.inversion or use_graph)
+    if use_plan and (dist_on or shard is not None):
+        raise SystemExit("--plan covers the single-process steps (the sharded steps' RCCL exchanges are not library launches); use --graph there")
 
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
@@ -389,6 +395,8 @@ def main():
             emb1 = torch.cat([unc[i], cond[:1]])
             if use_graph and ops.PROFILE is None:
                 return pipe.denoise_step_graphed(lat, ts[i], emb1, None, 7.5)
+            if use_plan and ops.PROFILE is None:
+                return pipe.denoise_step_planned(lat, ts[i], emb1, None, 7.5)
             return pipe.denoise_step(lat, ts[i], emb1, None, 7.5)
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
         graphed = use_graph and ops.PROFILE is None
@@ -402,6 +410,8 @@ def main():
             return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=cfg_group)
         if graphed:
             return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5)
+        if use_plan and ops.PROFILE is None:
+            return pipe.denoise_step_planned(lat, ts[i], emb, images, 7.5)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
     sed.cur_step = ted.cur_step = 4 if args.editors == "active" else 0   # active: the steady-state step (46 of 50)
@@ -482,7 +492,7 @@ def main():
                           "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
-                          "hip_graph_replay": bool(use_graph), "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(use_plan), "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; ControlNet (diffusers, source not in the reference tree): TRUNK pinned "
                                          "against the reference's own 2-D-degenerate SD-1.5 blocks (tests/golden/controlnet_trunk.npz), its 8 conditioning-embedding convolutions and "
                                          "13 1x1 zero-convolutions self-pinned"},

@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 6
+#define ME_ABI_VERSION 7
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -418,6 +418,73 @@ int me_cast_rows_f16(void* dst, int32_t lddst, const float* src, int32_t ldsrc, 
  * prev_step + mse of p2p/null_text_optimization.py:26-36,150-151; the mse of train_adaptor.py:368 with ca = 0, cb = 1 */
 int me_mse_seed(float* diff, float* d_eps, int32_t ldd, const void* eps_u, int32_t ldu, const void* eps_c, int32_t ldc, const float* x, const float* target, int32_t nb,
                 int32_t C, int32_t frames, int32_t npix, float guidance, float ca, float cb, float coef, void* stream);
+
+/* ---- the denoising step as ONE call: launch list recorded once, re-issued from C (csrc/plan.hip) ------------------------------- *
+ * Replaces: one iteration of the reference's denoising loop body, pipeline_motion_editor.py:603-648 (ControlNet forward :613-625,
+ * UNet3D forward with the adapter :632-640, classifier-free guidance :643-645, DDIMScheduler.step :648) -- ~1100 kernel launches
+ * on two HIP streams.  SURVEY.md section 8(b) sketched `me_plan` / `me_denoise_step`; the launch graph itself (which kernel on which
+ * rows: models/graph.py) stays host logic, its execution moves behind this boundary:
+ *
+ *   me_plan_begin(&plan, stream)        this thread starts recording: every kernel a me_* entry point launches is executed as usual
+ *                                       AND appended to the plan {kernel, grid, block, LDS bytes, stream, argument bytes}
+ *   ... one eager step through the per-family entry points above, its per-step scalars read from DEVICE memory
+ *       (me_timestep_embed_dev / me_cfg_ddim_dev), cross-stream dependencies stated with me_plan_event_record / _wait ...
+ *   me_plan_end(plan)
+ *   me_plan_bind(plan, ...)             names the static buffers the recorded step reads (latents, text embeddings, step scalars)
+ *                                       and writes (updated latents)
+ *   me_denoise_step(plan, ...)          per timestep: copies the inputs in (when they are not the bound buffers themselves), writes
+ *                                       {t, guidance, ca, cb}, re-issues every launch / event in recorded order on the live streams
+ *
+ * The caller guarantees what a captured hipGraph also needs: every buffer whose address a recorded launch holds stays allocated
+ * and is not handed to anyone else while the plan lives (the Python mirror records inside a private allocator pool and keeps it),
+ * and the step's shapes, key-segment tables and editor gating are those of the recorded step.  A plan is bound to the device,
+ * the thread-independent streams and the buffers it was recorded on; stream index 0 (the stream given to me_plan_begin) is
+ * replaced by me_denoise_step's `stream` argument, side streams are used as recorded.  Not thread-safe per plan. */
+typedef struct me_plan me_plan;
+
+typedef struct me_plan_stats {
+  int64_t launches;      /* kernel launches in the plan                       */
+  int64_t event_records; /* cross-stream dependencies: events recorded ...    */
+  int64_t event_waits;   /* ... and waited on                                 */
+  int64_t arg_bytes;     /* bytes of recorded kernel arguments (16-byte aligned each) */
+  int64_t replays;       /* successful me_denoise_step calls so far           */
+  int32_t streams;       /* distinct streams the step used (1 or 2)           */
+} me_plan_stats;
+
+#define ME_PLAN_LAUNCH 0
+#define ME_PLAN_RECORD 1
+#define ME_PLAN_WAIT 2
+typedef struct me_plan_node_info {
+  int32_t kind;          /* ME_PLAN_LAUNCH / ME_PLAN_RECORD / ME_PLAN_WAIT    */
+  int32_t stream;        /* stream index (0 = main)                           */
+  int32_t event;         /* event id of a RECORD / WAIT node, -1 for launches */
+  uint32_t grid[3], block[3];
+  uint32_t lds_bytes;
+  int32_t n_args;
+  int64_t arg_bytes;     /* total bytes of the launch's arguments, densely packed */
+} me_plan_node_info;
+
+int me_plan_begin(me_plan** out, void* main_stream);
+/* states, while recording, what `hipEventRecord(ev, stream)` / `hipStreamWaitEvent(stream, ev)` state to the runtime (the caller still
+ * issues those itself for the recording pass; the plan owns the events it replays with) */
+int me_plan_event_record(void* stream, int32_t* event_id);
+int me_plan_event_wait(void* stream, int32_t event_id);
+int me_plan_end(me_plan* plan);
+/* 1 while this thread records a plan */
+int me_plan_recording(void);
+/* latents_in / latents_out: fp32 [nb, 4, f, h, w] of latents_bytes each; text_emb: the step's text-embedding buffer (text_bytes, may be
+ * 0 / NULL when the step reads none); step_params: fp32 [4] {t, guidance, ca, cb} in device memory, the buffer the recorded
+ * me_timestep_embed_dev / me_cfg_ddim_dev launches read */
+int me_plan_bind(me_plan* plan, void* latents_in, int64_t latents_bytes, void* text_emb, int64_t text_bytes, float* step_params, void* latents_out);
+/* One denoising step.  latents_in / text_emb: device buffers copied into the bound ones first (NULL, or the bound address itself: nothing is
+ * copied); latents_out likewise receives a copy of the bound output.  ca, cb: the DDIM update's coefficients for timestep t
+ * (prev = ca * x + cb * eps, schedulers.DDIMScheduler.coeffs).  Only enqueues; returns ME_EHIP naming the failing node otherwise. */
+int me_denoise_step(me_plan* plan, const void* latents_in, void* latents_out, const void* text_emb, float t, float guidance, float ca, float cb, void* stream);
+int me_plan_info(const me_plan* plan, me_plan_stats* out);
+/* node `index` of the plan (0 <= index < launches + event_records + event_waits, recorded order); arg_bytes_out (may be NULL) receives up to
+ * arg_bytes_cap bytes of the launch's arguments, densely packed in declaration order */
+int me_plan_node(const me_plan* plan, int64_t index, me_plan_node_info* out, void* arg_bytes_out, int64_t arg_bytes_cap);
+void me_plan_destroy(me_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 OBJ = PKG / "csrc" / "_obj"
 LIB = PKG / "libmotioned.so"
-SOURCES = ["capi.hip", "gemm.hip", "attn.hip", "tattn.hip", "norm.hip", "eltwise.hip", "bwd.hip", "attn_bwd.hip", "train.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "attn.hip", "tattn.hip", "norm.hip", "eltwise.hip", "bwd.hip", "attn_bwd.hip", "train.hip", "plan.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 # attn.hip: without nnan, every fmaxf on an MFMA result gets a canonicalising v_max_f32 in front of it (21 extra VALU per
 # 64-key tile in a kernel whose VALU time adds to its MFMA time); the kernel never produces or tests NaN / Inf.

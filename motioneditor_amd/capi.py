@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 6
+ABI_VERSION = 7
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -99,6 +99,17 @@ class LayerNormArgs(C.Structure):
     ]
 
 
+class PlanStats(C.Structure):
+    _fields_ = [("launches", _i64), ("event_records", _i64), ("event_waits", _i64), ("arg_bytes", _i64), ("replays", _i64), ("streams", _i32)]
+
+
+class PlanNodeInfo(C.Structure):
+    _fields_ = [("kind", _i32), ("stream", _i32), ("event", _i32), ("grid", C.c_uint32 * 3), ("block", C.c_uint32 * 3), ("lds_bytes", C.c_uint32),
+                ("n_args", _i32), ("arg_bytes", _i64)]
+
+
+PLAN_LAUNCH, PLAN_RECORD, PLAN_WAIT = 0, 1, 2
+
 # every symbol include/motioned.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "me_abi_version": (C.c_int, []),
@@ -151,6 +162,17 @@ SYMBOLS = {
     "me_mse_seed": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "me_nchw_to_rows": (C.c_int, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp]),
     "me_rows_to_nchw": (C.c_int, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _vp]),
+    # the step as one call (csrc/plan.hip); me_plan* is an opaque pointer
+    "me_plan_begin": (C.c_int, [C.POINTER(_vp), _vp]),
+    "me_plan_event_record": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "me_plan_event_wait": (C.c_int, [_vp, _i32]),
+    "me_plan_end": (C.c_int, [_vp]),
+    "me_plan_recording": (C.c_int, []),
+    "me_plan_bind": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "me_denoise_step": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "me_plan_info": (C.c_int, [_vp, C.POINTER(PlanStats)]),
+    "me_plan_node": (C.c_int, [_vp, _i64, C.POINTER(PlanNodeInfo), _vp, _i64]),
+    "me_plan_destroy": (None, [_vp]),
 }
 
 _lib = None

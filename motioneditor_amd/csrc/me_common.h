@@ -3,6 +3,41 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- launch hook (csrc/plan.hip) -----------------------------------------------------------------------------------
+// Every kernel of the library is launched through me_launch(): it converts the call's arguments to the kernel's own
+// parameter types, launches with hipLaunchKernel (what `kernel<<<...>>>(...)` compiles to) and -- while this thread is
+// recording a plan (me_plan_begin ... me_plan_end, include/motioned.h) -- appends {kernel, grid, block, LDS bytes, stream,
+// a copy of the argument bytes} to that plan, so that me_denoise_step() can re-issue the whole step from C.
+#ifndef __HIP_DEVICE_COMPILE__
+#include <tuple>
+#include <utility>
+#endif
+extern "C" int me_plan_recording(void);
+extern "C" void me_plan_append_launch(const void* fn, unsigned gx, unsigned gy, unsigned gz, unsigned bx, unsigned by, unsigned bz, unsigned lds_bytes, void* stream,
+                                      void* const* args, const unsigned* arg_bytes, int n_args);
+#ifndef __HIP_DEVICE_COMPILE__
+template <typename... P, size_t... I>
+inline void me_launch_impl(void (*k)(P...), dim3 g, dim3 b, unsigned lds, hipStream_t st, std::tuple<P...>& v, std::index_sequence<I...>) {
+  void* ptrs[sizeof...(P) + 1] = {static_cast<void*>(&std::get<I>(v))..., nullptr};
+  (void)hipLaunchKernel(reinterpret_cast<const void*>(k), g, b, ptrs, lds, st);   // an error stays in hipGetLastError() for the entry point's check
+  if (me_plan_recording()) {
+    static const unsigned sizes[sizeof...(P) + 1] = {(unsigned)sizeof(P)..., 0u};
+    me_plan_append_launch(reinterpret_cast<const void*>(k), g.x, g.y, g.z, b.x, b.y, b.z, lds, st, ptrs, sizes, (int)sizeof...(P));
+  }
+}
+template <typename... P, typename... A>
+inline void me_launch(void (*k)(P...), dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "me_launch: argument count differs from the kernel's parameter count");
+  std::tuple<P...> v(std::forward<A>(a)...);
+  me_launch_impl(k, g, b, (unsigned)lds, st, v, std::index_sequence_for<P...>{});
+}
+#else
+template <typename K, typename... A>
+inline void me_launch(K, dim3, dim3, size_t, hipStream_t, A&&...) {}
+#endif
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) me_launch(kernel, grid, block, lds, stream, __VA_ARGS__)
+
 typedef _Float16 f16;
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));

@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-from .. import ops, segments
+from .. import ops, plan, segments
 from ..weights import Packed
 
 HEADS = 8
@@ -417,6 +417,9 @@ UP_HAS_ATTN = (False, True, True, True)
 
 def text_rows(ehs: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
     """[B, 77, 768] (any float dtype, device) -> fp16 rows [B*77, 768]."""
+    if ehs.is_cuda and dtype == torch.float16 and getattr(ops, "NATIVE", False) and ehs.dtype in (torch.float16, torch.float32):
+        return ops.to_f16_rows(ehs)          # library cast / copy: a recorded step (plan.py) holds no torch kernel
+    plan.torch_fallback("text_rows")
     return ehs.to(dtype).reshape(-1, ehs.shape[-1]).contiguous()
 
 
@@ -469,8 +472,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     def push_skip(s: Act) -> None:
         skips.append(s)
         if side is not None:
-            s.t.record_stream(side)
-            side.wait_event(main.record_event())
+            plan.share(s.t, side)
+            plan.wait_stream(side, main)
             with torch.cuda.stream(side):
                 motion.append(adapter_for(len(skips) - 1, s))
 
@@ -505,9 +508,9 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     adapter_done = None
     if down_res is not None:
         if side is not None:
-            side.wait_stream(main)               # main is past its last read of every skip: safe to add the motion in place
+            plan.wait_stream(side, main)         # main is past its last read of every skip: safe to add the motion in place
         elif res_ready is not None:              # ControlNet residuals produced on another stream
-            torch.cuda.current_stream().wait_event(res_ready)
+            plan.wait_event(torch.cuda.current_stream(), res_ready)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             if side is None:
                 motion = [adapter_for(i, s) for i, s in enumerate(skips)]
@@ -517,7 +520,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             for i, (s, m) in enumerate(zip(skips, motion)):
                 tgt = s
                 if i == len(skips) - 1:  # the last skip is also the mid block's input: keep that one un-modified
-                    tgt = s.like(s.t.clone())
+                    tgt = s.like(ops.clone_rows(s.t) if getattr(ops, "NATIVE", False) and s.t.is_cuda else s.t.clone())
                 if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
                     n = s.f * s.N
                     for k, eb in enumerate(edit_rows):
@@ -529,8 +532,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 new_skips.append(tgt)
             skips = new_skips
         if side is not None:
-            adapter_done = side.record_event()
-            skips[-1].t.record_stream(main)      # the cloned last skip was allocated on the side stream
+            adapter_done = plan.record_event(side)
+            plan.share(skips[-1].t, main)        # the cloned last skip was allocated on the side stream
 
     n = "mid_block.resnets.0"
     x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
@@ -551,7 +554,7 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
         taps["mid"] = x.t.clone()
 
     if adapter_done is not None:
-        torch.cuda.current_stream().wait_event(adapter_done)
+        plan.wait_event(torch.cuda.current_stream(), adapter_done)
     cat = None   # torch.cat([hidden, res], dim=1) of the coming resnet, when its hidden half has already been written in place
     for i in range(4):
         for j in range(3):

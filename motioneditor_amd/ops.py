@@ -376,6 +376,55 @@ def copy_blocks(y: torch.Tensor, x: torch.Tensor, n0: int, n1: int, rows: int, *
     return y
 
 
+NATIVE = True   # this backend is libmotioned (tests/emu_ops.py, the torch emulation of the ABI, has no such flag): data movement below stays inside the library
+
+
+def clone_rows(x: torch.Tensor) -> torch.Tensor:
+    """x.clone() of an fp16 row tensor as a library copy (a torch kernel inside a step would be missing from a recorded plan's replays, plan.py)."""
+    return copy_rows(torch.empty_like(x), x)
+
+
+def _as_f16_row(t: torch.Tensor) -> torch.Tensor:
+    """A contiguous tensor's bytes as one fp16 row [1, n] (n a multiple of 8): what copy_rows moves."""
+    v = t.reshape(-1).view(F16)
+    if v.numel() % 8 or v.data_ptr() % 16:
+        raise ValueError("byte copy: size must be a multiple of 16 bytes and the address 16-byte aligned")
+    return v.reshape(1, -1)
+
+
+def repeat_batch(x: torch.Tensor, times: int) -> torch.Tensor:
+    """torch.cat([x] * times) along dim 0 of a contiguous tensor (the classifier-free-guidance duplication of the latents,
+    pipeline_motion_editor.py:605) as `times` library copies."""
+    if not x.is_contiguous():
+        raise ValueError("repeat_batch: contiguous input")
+    out = torch.empty((times * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    for k in range(times):
+        copy_rows(_as_f16_row(out[k * x.shape[0]:(k + 1) * x.shape[0]]), _as_f16_row(x))
+    return out
+
+
+def to_f16_rows(ehs: torch.Tensor) -> torch.Tensor:
+    """[B, n, C] (fp32 or fp16; contiguous, or batch entries that are each contiguous -- a `[1::2]` slice) -> fp16 rows [B * n, C]:
+    `ehs.to(float16).reshape(-1, C)` with the cast done by me_cast_f16 / the copy by me_copy_rows."""
+    Cc = ehs.shape[-1]
+    if ehs.dtype == F16 and ehs.is_contiguous():
+        return ehs.reshape(-1, Cc)
+    B = ehs.shape[0]
+    n = ehs[0].numel() // Cc
+    out = torch.empty((B * n, Cc), dtype=F16, device=ehs.device)
+    parts = [(out, ehs)] if ehs.is_contiguous() else [(out[b * n:(b + 1) * n], ehs[b]) for b in range(B)]
+    for dst, src in parts:
+        if not src.is_contiguous():
+            raise ValueError("to_f16_rows: batch entries must be contiguous")
+        if src.dtype == torch.float32:
+            cast_f16(dst, src)
+        elif src.dtype == F16:
+            copy_rows(dst, src.reshape(-1, Cc))
+        else:
+            raise ValueError(f"to_f16_rows: unsupported dtype {src.dtype}")
+    return out
+
+
 def silu(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(x)
     capi.check(capi.lib().me_silu(out.data_ptr(), x.data_ptr(), x.numel(), _stream()), "me_silu")

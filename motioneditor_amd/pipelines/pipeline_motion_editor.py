@@ -15,7 +15,7 @@ from typing import Callable, List, Optional, Union
 
 import torch
 
-from .. import ops
+from .. import ops, plan
 from ..schedulers import DDIMScheduler
 
 
@@ -65,6 +65,7 @@ class MotionEditorPipeline:
         self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
         self._side_stream = None
         self._graphs = {}               # denoise_step_graphed: (shapes, editor gating) -> captured step
+        self._plans = {}                # denoise_step_planned: (shapes, editor gating) -> recorded launch list (plan.StepPlan)
 
     @property
     def _execution_device(self):
@@ -259,7 +260,11 @@ class MotionEditorPipeline:
         """One iteration of the reference loop body (:603-648).  latents fp32 [2,4,f,h,w] = [recon, edit];
         text_embeddings_input [4,77,768] = [uncond, uncond, cond_recon, cond_edit]."""
         nb = latents.shape[0]
-        x4 = torch.cat([latents] * 2)                                     # :605 (scale_model_input is the identity for DDIM)
+        # :605 (scale_model_input is the identity for DDIM); on the GPU the duplication is two library copies, so that a recorded step holds no torch kernel
+        native = latents.is_cuda and getattr(ops, "NATIVE", False) and latents.dtype == torch.float32 and latents.is_contiguous()
+        if not native:
+            plan.torch_fallback("torch.cat([latents] * 2)")
+        x4 = ops.repeat_batch(latents, 2) if native else torch.cat([latents] * 2)
         down = mid = ready = None
         two = False
         if self.controlnet is not None and images is not None:
@@ -276,12 +281,12 @@ class MotionEditorPipeline:
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream()
                 main = torch.cuda.current_stream()
-                self._side_stream.wait_stream(main)
+                plan.wait_stream(self._side_stream, main)
                 with torch.cuda.stream(self._side_stream):
                     down, mid = run_controlnet()
-                ready = self._side_stream.record_event()
+                ready = plan.record_event(self._side_stream)
                 for r in list(down) + [mid]:
-                    r.record_stream(main)
+                    plan.share(r, main)
             else:
                 down, mid = run_controlnet()
             two = True                                                     # mid residual scattered as [0, m0, 0, m1] (:628-629)
@@ -376,6 +381,63 @@ class MotionEditorPipeline:
                 e.cur_step += 1
                 e.after_step()
         return ent["out"].clone()
+
+    # ---- the step as one C call: me_plan_* / me_denoise_step ----------------------------------------------------------------
+    @torch.no_grad()
+    def denoise_step_planned(self, latents: torch.Tensor, t: int, text_embeddings_input: torch.Tensor, images: Optional[torch.Tensor],
+                             guidance_scale: float, controlnet_conditioning_scale: float = 1.0) -> torch.Tensor:
+        """`denoise_step` with its execution behind the C ABI (csrc/plan.hip, plan.StepPlan): the first call per (shapes, editor gating) runs the step
+        eagerly once (warm-up: weight packing, tables, scratch, function attributes), records a second eager pass -- every kernel launch with its
+        arguments, both HIP streams, their event dependencies -- and from then on one `me_denoise_step` call re-issues the ~1100 launches of the
+        loop body (pipeline_motion_editor.py:603-648) on the live streams: same kernels, same arguments, same order, hence bit-for-bit the eager
+        result, with the host's share of a step down from ~11 ms of Python dispatch to the C loop over the launch list.  The per-step scalars
+        (timestep, guidance, DDIM coefficients) live in device memory (ops.STEP_PARAMS) exactly as for `denoise_step_graphed`; editors' counters
+        advance as in the eager step.  Single-process steps only (the sharded steps' RCCL exchanges are not library launches)."""
+        sed, ted = self.unet.spatial_editor, self.unet.temporal_editor
+        if not latents.is_cuda:
+            raise ValueError("denoise_step_planned: CUDA tensors only")
+        latents = latents.contiguous().float()
+        emb = text_embeddings_input.contiguous()
+        key = (tuple(latents.shape), tuple(emb.shape), emb.dtype, None if images is None else (tuple(images.shape), images.data_ptr(), images._version),
+               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter,
+               torch.cuda.current_stream().cuda_stream)
+        ca, cb = self.scheduler.coeffs(int(t))
+        ent = self._plans.get(key)
+        if ent is None:
+            editors = [e for e in (sed, ted) if e is not None]
+            counters = [(e.cur_step, e.cur_att_layer) for e in editors]
+
+            def rewind():
+                for e, (cs, cl) in zip(editors, counters):
+                    e.cur_step, e.cur_att_layer = cs, cl
+
+            st = dict(lat=latents.clone(), emb=emb.clone(), params=torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32).to(latents.device))
+            step = lambda: self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)   # noqa: E731
+            ops.STEP_PARAMS = st["params"]
+            try:
+                step()                                   # warm-up, eager
+                torch.cuda.synchronize()
+                rewind()
+                pl = plan.StepPlan()
+                with pl.recording():
+                    st["out"] = step()
+            finally:
+                ops.STEP_PARAMS = None
+            torch.cuda.synchronize()
+            pl.bind(st["lat"], st["emb"], st["params"], st["out"])
+            rewind()
+            st["plan"] = pl
+            st["images"] = images          # keep the conditioning tensor the recorded launches read alive ...
+            if self.controlnet is not None:   # ... and the conditioning embedding computed from it (graph.controlnet_forward's table may drop it later)
+                st["cond_embed"] = dict(self.controlnet.P.cache.get("cond_embed", {}))
+            ent = self._plans[key] = st
+        out = ent["plan"].step(latents, emb, float(t), float(guidance_scale), ca, cb)
+        for e in (sed, ted):
+            if e is not None:      # what MutualAttentionBase.__call__ does over the step's attention layers
+                e.cur_att_layer = 0
+                e.cur_step += 1
+                e.after_step()
+        return out
 
     @torch.no_grad()
     def __call__(self, prompt: Union[str, List[str]], video_length: Optional[int], height: Optional[int] = None, width: Optional[int] = None,

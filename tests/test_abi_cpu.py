@@ -20,7 +20,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(str(capi.LIB_PATH))
     for name in declared:
         getattr(L, name)
-    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 6
+    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 7
 
 
 def test_argument_validation_returns_einval_without_a_device():
@@ -50,6 +50,50 @@ def test_argument_validation_returns_einval_without_a_device():
     assert L.me_attn(ctypes.byref(t), None) == capi.ME_EINVAL and b"head dim" in L.me_last_error()
     with pytest.raises(ValueError):
         capi.check(capi.ME_EINVAL, "x")
+
+
+def test_plan_records_the_launches_of_this_thread_without_a_device():
+    """csrc/plan.hip: while a plan records, every kernel an entry point launches is appended with its grid, stream and argument bytes (the launch itself
+    fails here -- no device -- which the entry point reports as before); events are numbered in recording order; misuse is refused."""
+    import struct
+    from motioneditor_amd import capi
+    L = capi.lib()
+    assert L.me_plan_recording() == 0
+    ev = ctypes.c_int32(-1)
+    assert L.me_plan_event_record(None, ctypes.byref(ev)) == capi.ME_EINVAL and b"no plan" in L.me_last_error()
+    plan = ctypes.c_void_p()
+    main, side = 0x1000, 0x2000                 # stream handles are opaque to the recorder
+    assert L.me_plan_begin(ctypes.byref(plan), main) == capi.ME_OK and L.me_plan_recording() == 1
+    other = ctypes.c_void_p()
+    assert L.me_plan_begin(ctypes.byref(other), main) == capi.ME_EINVAL
+    n = 4096
+    rc = L.me_silu(0x10000, 0x20000, n, main)                                         # unary_kernel<0>(f16* Y, const f16* X, long n)
+    assert rc in (capi.ME_OK, capi.ME_EHIP)
+    assert L.me_plan_event_record(main, ctypes.byref(ev)) == capi.ME_OK and ev.value == 0
+    assert L.me_plan_event_wait(side, 0) == capi.ME_OK
+    assert L.me_plan_event_wait(side, 1) == capi.ME_EINVAL
+    rc = L.me_axpy_rows(0x30000, 64, 0x40000, 64, 0x50000, 64, 8, 64, 0.5, side)       # axpy_rows_kernel(Y, ldy, X, ldx, A, lda, long rows, cols, alpha)
+    assert rc in (capi.ME_OK, capi.ME_EHIP)
+    assert L.me_silu(None, None, 0, main) == capi.ME_EINVAL                            # refused before any launch: nothing recorded
+    st = capi.PlanStats()
+    assert L.me_plan_info(plan, ctypes.byref(st)) == capi.ME_OK
+    assert (st.launches, st.event_records, st.event_waits, st.streams) == (2, 1, 1, 2)
+    info, buf = capi.PlanNodeInfo(), ctypes.create_string_buffer(256)
+    assert L.me_plan_node(plan, 0, ctypes.byref(info), buf, 256) == capi.ME_OK
+    assert (info.kind, info.stream, info.n_args, info.arg_bytes) == (capi.PLAN_LAUNCH, 0, 3, 24) and tuple(info.block) == (256, 1, 1) and info.grid[0] >= 1
+    assert struct.unpack("<QQq", buf.raw[:24]) == (0x10000, 0x20000, n)
+    assert L.me_plan_node(plan, 1, ctypes.byref(info), None, 0) == capi.ME_OK and (info.kind, info.stream, info.event) == (capi.PLAN_RECORD, 0, 0)
+    assert L.me_plan_node(plan, 2, ctypes.byref(info), None, 0) == capi.ME_OK and (info.kind, info.stream, info.event) == (capi.PLAN_WAIT, 1, 0)
+    assert L.me_plan_node(plan, 3, ctypes.byref(info), buf, 256) == capi.ME_OK and (info.kind, info.stream, info.n_args, info.arg_bytes) == (capi.PLAN_LAUNCH, 1, 9, 52)
+    assert struct.unpack("<QiQiQiqif", buf.raw[:52]) == (0x30000, 64, 0x40000, 64, 0x50000, 64, 8, 64, 0.5)   # densely packed, declaration order
+    assert L.me_plan_node(plan, 4, ctypes.byref(info), None, 0) == capi.ME_EINVAL
+    assert L.me_denoise_step(plan, None, None, None, 1.0, 7.5, 1.0, 0.0, main) == capi.ME_EINVAL    # still recording
+    rc = L.me_plan_end(plan)                      # creates the replay events: needs a device
+    assert rc in (capi.ME_OK, capi.ME_EHIP) and L.me_plan_recording() == 0
+    assert L.me_denoise_step(plan, None, None, None, 1.0, 7.5, 1.0, 0.0, main) == capi.ME_EINVAL    # not bound (or, without a device, not completed)
+    assert L.me_plan_bind(plan, None, 0, None, 0, None, None) == capi.ME_EINVAL
+    L.me_plan_destroy(plan)
+    L.me_plan_destroy(None)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

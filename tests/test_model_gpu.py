@@ -238,6 +238,54 @@ def test_graph_replay_six_steps_equals_eager(unet, controlnet):
     assert e == 0.0, e
 
 
+def test_planned_step_six_steps_equals_eager(unet, controlnet):
+    """denoise_step_planned (csrc/plan.hip: the step's launch list recorded once per editor gating, re-issued by ONE me_denoise_step call on the two live
+    streams) over steps 0..5 -- across the editors' start at step 4, with a different unconditional embedding, timestep and latent every step -- must
+    reproduce the eager loop bit for bit.  Fresh inputs at every replay: a torch kernel hiding inside the recorded step (executed in the recording
+    pass, missing from the replays) would leave stale data behind and show up here."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    x = step_inputs()
+    f = x["latents"].shape[2]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64).cuda()
+    g = torch.Generator().manual_seed(5)
+    uncs = [x["uncond"] + 0.05 * i * torch.randn(x["uncond"].shape, generator=g) for i in range(6)]
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    pipe.scheduler.set_timesteps(50)
+    outs = {}
+    for mode in ("eager", "plan"):
+        sed, ted = editors(unet, x["masks"])
+        lat = x["latents"].cuda()
+        for i in range(6):
+            emb = torch.cat([uncs[i].expand(2, 77, 768), x["cond"]]).cuda()
+            fn = pipe.denoise_step if mode == "eager" else pipe.denoise_step_planned
+            lat = fn(lat, pipe.scheduler.timesteps[i], emb, images, 7.5)
+            assert sed.cur_step == ted.cur_step == i + 1 and sed.cur_att_layer == ted.cur_att_layer == 0
+        outs[mode] = lat.clone()
+    unet.spatial_editor = unet.temporal_editor = None
+    assert len(pipe._plans) == 2                      # editors inactive / active
+    for st in pipe._plans.values():
+        info = st["plan"].stats()
+        assert info["streams"] == 2 and info["launches"] > 500 and info["event_records"] >= info["event_waits"] >= 3 and info["replays"] >= 2, info
+        kinds = [n[0] for n in st["plan"].nodes()]
+        assert kinds.count(0) == info["launches"] and kinds[0] in (0, 1)
+    e = rel_l2(outs["plan"], outs["eager"])
+    record("planned_step_vs_eager_six_steps", e)
+    assert e == 0.0, e
+    # single-branch (no ControlNet, no editors: one stream, no events) and a second replay with new inputs
+    pipe1 = MotionEditorPipeline(unet=unet)
+    pipe1.scheduler.set_timesteps(50)
+    lat = x["latents"][:1].cuda()
+    emb = torch.cat([uncs[1][:1], x["cond"][:1]]).cuda()
+    for i in (7, 9):
+        a = pipe1.denoise_step(lat, pipe1.scheduler.timesteps[i], emb, None, 7.5)
+        b = pipe1.denoise_step_planned(lat, pipe1.scheduler.timesteps[i], emb, None, 7.5)
+        assert torch.equal(a, b), (i, rel_l2(a, b))
+        lat = a
+    (st,) = pipe1._plans.values()
+    assert st["plan"].stats()["streams"] == 1 and st["plan"].stats()["event_records"] == 0
+
+
 def test_high_gain_weights_step_vs_cpu_oracle():
     """A weight set that drives the activations to SD-like magnitudes (|x| ~ 1e2 - 1e3 after conv_in, large per-channel
     means in front of the GroupNorms): GroupNorm variance (fp64 statistics) and the fp16 range of the residual stream,
