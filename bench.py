@@ -81,8 +81,11 @@ def parse_args():
                          "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
                          "measured neutral (the GPU, not the host, paces the step); across GPUs it could only be validated on a world-1 RCCL group")
     ap.add_argument("--plan", action="store_true",
-                    help="single-GPU modes: execute the step behind the C ABI's step-level entry point (me_plan_* / me_denoise_step, csrc/plan.hip: the launch list "
-                         "recorded once, re-issued from C on the two live HIP streams; bitwise the eager result) instead of enqueueing its ~1100 launches from Python")
+                    help="execute the step behind the C ABI's step-level entry point (me_plan_* / me_denoise_step, csrc/plan.hip: the launch list recorded once, "
+                         "re-issued from C on the two live HIP streams; bitwise the eager result) instead of enqueueing its ~1100 launches from Python.  This is the "
+                         "DEFAULT of the single-process modes up to the benchmark's size (24 f x 64^2 latents); larger shapes keep the eager executor unless --plan "
+                         "is given (the plan holds one step's activations in a private pool beside the roofline pass's)")
+    ap.add_argument("--eager", action="store_true", help="A/B: enqueue the launches of the step from Python (the default before round 4's me_denoise_step)")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="who issues the data-path exchanges of the sharded modes: 'torch' = torch.distributed's nccl (= RCCL) process group; 'rccl' = RCCL called "
                          "directly on our own communicators (motioneditor_amd/rccl.py: no watchdog, capturable); auto = rccl with --graph, else torch")
@@ -382,9 +385,11 @@ def main():
         lat = lat[:1].contiguous()
 
     use_graph = args.graph and not (args.emulate or args.inversion)
-    use_plan = args.plan and not (args.emulate or args.inversion or use_graph)
-    if use_plan and (dist_on or shard is not None):
+    single_process = not dist_on and shard is None and n_cfg == 1
+    if args.plan and not single_process:
         raise SystemExit("--plan covers the single-process steps (the sharded steps' RCCL exchanges are not library launches); use --graph there")
+    plan_default = single_process and f * h * w <= 24 * 64 * 64 and not args.eager
+    use_plan = (args.plan or plan_default) and not (args.emulate or args.inversion or use_graph or args.null_text or args.vae_decode)
 
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
@@ -446,6 +451,10 @@ def main():
     prof = None
     if not args.no_profile and not args.emulate:
         ov = (pipe.overlap_controlnet, pipe.overlap_adapter)
+        for st in pipe._plans.values():      # the recorded step's private pool goes back to the allocator before the eager pass needs the memory
+            st["plan"].close()
+        pipe._plans.clear()
+        torch.cuda.empty_cache()
         pipe.overlap_controlnet = pipe.overlap_adapter = False
         if rank == 0:
             ops.PROFILE = []

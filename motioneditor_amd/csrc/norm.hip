@@ -8,6 +8,10 @@
 #include "me_common.h"
 #include "../../include/motioned.h"
 
+#ifndef ME_GN_UNROLL
+#define ME_GN_UNROLL 4   // independent 16-byte loads in flight per thread of the statistics pass (A/B: tools/build_abl.sh)
+#endif
+
 namespace {
 
 // Pass 1, deterministic and cancellation-free: every block reduces its row chunk to one (S1, S2) pair per channel group,
@@ -43,8 +47,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
         q[e] = 0.f;
         K[e] = (float)first[((vc * 8 + e) / cg) * cg];
       }
-#pragma unroll 4
-      for (int r = r0 + rl; r < r1; r += RL) {   // 4 independent 16-byte loads in flight per thread
+#pragma unroll ME_GN_UNROLL
+      for (int r = r0 + rl; r < r1; r += RL) {   // ME_GN_UNROLL independent 16-byte loads in flight per thread (the sums stay in row order)
         U128 u;
         u.u = ldg128(base + (long)r * ldx + vc * 8);
 #pragma unroll

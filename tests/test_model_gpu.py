@@ -284,6 +284,15 @@ def test_planned_step_six_steps_equals_eager(unet, controlnet):
         lat = a
     (st,) = pipe1._plans.values()
     assert st["plan"].stats()["streams"] == 1 and st["plan"].stats()["event_records"] == 0
+    # __call__'s loop on the planned executor (3 steps from given latents, no VAE): the eager loop's latents, bit for bit
+    res = {}
+    for ex in ("eager", "plan"):
+        pipe2 = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+        pipe2.step_executor = ex
+        res[ex] = pipe2(["a source prompt", "a target prompt"], video_length=f, height=64, width=64, num_inference_steps=3, guidance_scale=7.5,
+                        latents=x["latents"].cuda(), output_type="latent", text_embeddings=x["cond"].cuda(), negative_text_embeddings=x["uncond"].cuda(),
+                        skeleton=x["skeleton"].cuda()).images
+    assert torch.equal(res["eager"], res["plan"])
 
 
 def test_high_gain_weights_step_vs_cpu_oracle():
