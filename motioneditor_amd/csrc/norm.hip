@@ -8,8 +8,11 @@
 #include "me_common.h"
 #include "../../include/motioned.h"
 
+#ifndef ME_GN_APPLY_DEPTH
+#define ME_GN_APPLY_DEPTH 4   // 16-byte loads in flight per thread of the apply pass
+#endif
 #ifndef ME_GN_UNROLL
-#define ME_GN_UNROLL 4   // independent 16-byte loads in flight per thread of the statistics pass (A/B: tools/build_abl.sh)
+#define ME_GN_UNROLL 8   // independent 16-byte loads in flight per thread of the statistics pass (A/B: tools/build_abl.sh)
 #endif
 
 namespace {
@@ -47,16 +50,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ X
         q[e] = 0.f;
         K[e] = (float)first[((vc * 8 + e) / cg) * cg];
       }
-#pragma unroll ME_GN_UNROLL
-      for (int r = r0 + rl; r < r1; r += RL) {   // ME_GN_UNROLL independent 16-byte loads in flight per thread (the sums stay in row order)
-        U128 u;
-        u.u = ldg128(base + (long)r * ldx + vc * 8);
+      // ME_GN_UNROLL independent 16-byte loads in flight per thread, issued explicitly ahead of their use (left to `#pragma unroll`, hipcc guards every
+      // unrolled iteration with its own exit test and waits for each load by itself: one load in flight per thread); the sums stay in row order
+      auto acc = [&](const U128& u) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float v = (float)u.e[e] - K[e];
           s[e] += v;
           q[e] += v * v;
         }
+      };
+      int r = r0 + rl;
+      for (; r + (ME_GN_UNROLL - 1) * RL < r1; r += ME_GN_UNROLL * RL) {
+        U128 u[ME_GN_UNROLL];
+#pragma unroll
+        for (int k = 0; k < ME_GN_UNROLL; ++k) u[k].u = ldg128(base + (long)(r + k * RL) * ldx + vc * 8);
+        __builtin_amdgcn_sched_barrier(0);   // keep every load of the batch ahead of the first use (the scheduler otherwise sinks some of them between the sums)
+#pragma unroll
+        for (int k = 0; k < ME_GN_UNROLL; ++k) acc(u[k]);
+      }
+      for (; r < r1; r += RL) {
+        U128 u;
+        u.u = ldg128(base + (long)r * ldx + vc * 8);
+        acc(u);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[rl * (tprc * 8) + vc0 * 8 + e] = make_float2(s[e], q[e]);
@@ -172,16 +188,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* X, f16* Y, con
       *reinterpret_cast<uint4*>(Y + r * ldy + vc * 8) = o.u;
     };
     const long st = blockDim.y;
-    for (; row + 3 * st < seg_end; row += 4 * st) {   // X may alias Y: the four loads are issued explicitly ahead of the stores
-      U128 u0, u1, u2, u3;
-      u0.u = ldg128(X + row * ldx + vc * 8);
-      u1.u = ldg128(X + (row + st) * ldx + vc * 8);
-      u2.u = ldg128(X + (row + 2 * st) * ldx + vc * 8);
-      u3.u = ldg128(X + (row + 3 * st) * ldx + vc * 8);
-      emit(u0, row);
-      emit(u1, row + st);
-      emit(u2, row + 2 * st);
-      emit(u3, row + 3 * st);
+    for (; row + (ME_GN_APPLY_DEPTH - 1) * st < seg_end; row += ME_GN_APPLY_DEPTH * st) {   // X may alias Y: the loads are issued explicitly ahead of the stores
+      U128 u[ME_GN_APPLY_DEPTH];
+#pragma unroll
+      for (int k = 0; k < ME_GN_APPLY_DEPTH; ++k) u[k].u = ldg128(X + (row + k * st) * ldx + vc * 8);
+#pragma unroll
+      for (int k = 0; k < ME_GN_APPLY_DEPTH; ++k) emit(u[k], row + k * st);
     }
     for (; row < seg_end; row += st) {
       U128 u;

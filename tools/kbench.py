@@ -271,6 +271,23 @@ def bench_misc():
         del x, y
 
 
+def bench_gn():
+    """GroupNorm at the step's shapes (B = 4, 24 frames): the resnets' 5-D form (statistics across all frames of a batch row) on plain and skip-concat
+    widths, the transformers' per-frame form; statistics and apply passes timed separately as well."""
+    B, f = 4, 24
+    tot = 0.0
+    for C, hw, per_frame, count in [(320, 64, False, 7), (640, 64, False, 2), (960, 64, False, 1), (320, 64, True, 5), (640, 32, False, 5), (1280, 32, False, 1),
+                                    (1920, 32, False, 1), (640, 32, True, 5), (1280, 16, False, 5), (2560, 16, False, 2), (1280, 16, True, 5), (1280, 8, False, 8)]:
+        M = B * f * hw * hw
+        y, g, b = rnd(M, C), rnd(C), rnd(C)
+        rpg = hw * hw if per_frame else f * hw * hw
+        ms = timeit(lambda: ops.groupnorm(y, g, b, rows_per_group=rpg, eps=1e-5, silu=True))
+        tot += ms * count
+        print(f"groupnorm C={C:4d} {hw}x{hw} {'per-frame' if per_frame else '5-D      '} {ms:.3f} ms  {4.0*M*C/ms/1e6:.0f} GB/s (algorithmic, in + out)")
+        del y
+    print(f"groupnorm weighted sum (~ launches of a step) {tot:.3f} ms")
+
+
 def bench_bwd():
     """Backward kernels at the null-text / adapter-training geometry (batch 1, 24 frames x 512^2)."""
     f = 24
@@ -335,5 +352,7 @@ if __name__ == "__main__":
         bench_attn(True)
     if "misc" in what:
         bench_misc()
+    if "gn" in what:
+        bench_gn()
     if "bwd" in what:
         bench_bwd()
