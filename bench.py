@@ -449,9 +449,13 @@ def main():
     # region overlaps two streams (ControlNet + adapter beside the UNet),
     # which stretches every kernel's own duration by whatever shares the GPU with it.
     prof = None
+    plan_stats = None
+    for st in pipe._plans.values():
+        plan_stats = st["plan"].stats()
     if not args.no_profile and not args.emulate:
         ov = (pipe.overlap_controlnet, pipe.overlap_adapter)
         for st in pipe._plans.values():      # the recorded step's private pool goes back to the allocator before the eager pass needs the memory
+            plan_stats = st["plan"].stats()
             st["plan"].close()
         pipe._plans.clear()
         torch.cuda.empty_cache()
@@ -507,6 +511,8 @@ def main():
                                          "13 1x1 zero-convolutions self-pinned"},
                "step_tflop_reference_semantics": round(tf_ref, 2) if tf_ref else None, "step_tflop_is_baseline_md_figure": tf_exact,
                "achieved_tflops_reference_semantics": round(tf_ref * n_clips * args.steps / dt, 1) if tf_ref else None}
+        if plan_stats is not None:   # the recorded step behind me_denoise_step: launches, cross-stream event records / waits, argument bytes, replays so far
+            out["launch_plan"] = plan_stats
         out["host_enqueue_ms_per_step"] = round(host_dt * 1e3, 2)   # < ms_per_step: the GPU, not the Python launch loop, is the limit
         if comm is not None:
             out["comm"] = comm

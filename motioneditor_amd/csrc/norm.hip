@@ -12,7 +12,7 @@
 #define ME_GN_APPLY_DEPTH 4   // 16-byte loads in flight per thread of the apply pass
 #endif
 #ifndef ME_GN_UNROLL
-#define ME_GN_UNROLL 8   // independent 16-byte loads in flight per thread of the statistics pass (A/B: tools/build_abl.sh)
+#define ME_GN_UNROLL 4   // independent 16-byte loads in flight per thread of the statistics pass (A/B: tools/build_abl.sh)
 #endif
 
 namespace {
