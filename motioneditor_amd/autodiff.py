@@ -204,6 +204,7 @@ class Recorder:
     """Stands in for the `ops` module of models/graph.py while a tape records: same functions, same results, plus the log."""
 
     recording = True   # models/graph.py keeps single assignment while this is its `ops` (out-of-place residual adds)
+    NATIVE = False     # ... and keeps its torch-side data movement (text-embedding cast, clone): the library copies / casts that a recorded plan needs have no backward rule
 
     def __init__(self, backend, tape: Tape):
         self._b, self._t = backend, tape
