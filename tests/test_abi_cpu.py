@@ -137,3 +137,20 @@ def test_oracle_unet_matches_reference_golden(unet_sd_torch):
     with torch.no_grad():
         out = ref_cpu.unet_forward(unet_sd_torch, c["sample"], c["t"], c["ehs"])
     assert max_rel(out, torch.from_numpy(g["out"])) < 2e-4
+
+
+def test_plan_helpers_refuse_torch_kernels_inside_a_recorded_step(monkeypatch):
+    """motioneditor_amd/plan.py: a torch kernel inside a step that is being recorded would be missing from every replay -- the launch graph's torch-side
+    data-movement branches call `torch_fallback`, which must raise while a plan records and be silent otherwise; the autodiff recorder (which has no
+    backward rule for the library's copies / casts) keeps the torch branches by presenting NATIVE = False."""
+    from motioneditor_amd import autodiff, plan
+    from motioneditor_amd.models import graph
+    plan.torch_fallback("x")                                   # no plan recording: fine
+    monkeypatch.setattr(plan, "ACTIVE", object())
+    with pytest.raises(RuntimeError, match="missing from every replay"):
+        plan.torch_fallback("text_rows")
+    with pytest.raises(RuntimeError, match="missing from every replay"):
+        graph.text_rows(torch.zeros(2, 77, 768))               # CPU tensor -> the torch branch -> refused while recording
+    monkeypatch.setattr(plan, "ACTIVE", None)
+    assert graph.text_rows(torch.zeros(2, 77, 768)).shape == (154, 768)
+    assert autodiff.Recorder.NATIVE is False and autodiff.Recorder.recording is True
