@@ -1,20 +1,5 @@
-import ctypes
 import os
 import sys
-
-# glibc hands every allocation above 128 KB straight to mmap / munmap: the fp32 CPU emulation and the oracle allocate (and free) multi-megabyte tensors
-# by the thousand, and the page faults that follows cost more system time than the arithmetic costs user time (measured on test_step_cpu: 61 -> 31 s).
-# Keep big blocks on the heap: for this process through mallopt, for the ranks / bench runs the tests spawn through the environment.
-os.environ.setdefault("MALLOC_MMAP_THRESHOLD_", str(32 << 20))
-os.environ.setdefault("MALLOC_TRIM_THRESHOLD_", str((1 << 31) - 1))
-os.environ.setdefault("MALLOC_TOP_PAD_", str(256 << 20))
-try:
-    _libc = ctypes.CDLL("libc.so.6")
-    _libc.mallopt(-3, 32 << 20)          # M_MMAP_THRESHOLD
-    _libc.mallopt(-1, (1 << 31) - 1)     # M_TRIM_THRESHOLD
-    _libc.mallopt(-2, 256 << 20)         # M_TOP_PAD
-except OSError:
-    pass
 
 os.environ.setdefault("ME_GRAD_POISON", "1")   # never-zeroed gradient buffers of the autodiff tape start as NaN: a read before the first store fails a test
 from pathlib import Path
