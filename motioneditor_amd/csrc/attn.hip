@@ -27,14 +27,9 @@
 #include <type_traits>
 #include <utility>
 
-// Block order.  A block is one (item, head, query block); xcd_remap gives each XCD a contiguous run of them.  Long key lists (self-attention: a head's K | V
-// tiles are 0.6 - 1.3 MB per item) want the query blocks of ONE head next to each other, so that the K | V tiles stay in the XCD's L2 across them.  Short
-// key lists (cross-attention over 77 text rows) have no K | V to speak of; their traffic is Q and O, of which a block touches one head's 2 dh-byte slice of
-// every 16 dh-byte row -- there the eight heads of the SAME rows should run side by side, so that each 128-byte line is fetched and written back once
-// instead of once per head-round.  Same blocks, same arithmetic, another order.
-#ifndef ME_ATTN_HEAD_FASTEST
-#define ME_ATTN_HEAD_FASTEST(a) ((a).nk * (a).nseg <= 256)
-#endif
+// Block order: a block is one (item, head, query block), query blocks fastest; xcd_remap gives each XCD a contiguous run, so the query blocks of ONE head
+// sit next to each other and its K | V tiles stay in the XCD's L2.  (Heads fastest for the 77-key text cross-attention -- the eight heads of the same
+// query rows side by side, whole 128-byte lines of Q and O per XCD -- measured +-0: profiles/r04_attn_cross_order_ab.txt.)
 extern "C" void me_set_kernel(const char* name);
 
 namespace {
@@ -86,18 +81,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
 
   const int nqb = (a.nq + BQ - 1) / BQ;
   const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
-  int qb, h, item;
-  if (ME_ATTN_HEAD_FASTEST(a)) {   // short key lists (the 77 text keys): the blocks that share an XCD's L2 at one time are the heads of the SAME query rows (see "Block order" above)
-    h = w % a.heads;
-    const int rest = w / a.heads;
-    qb = rest % nqb;
-    item = rest / nqb;
-  } else {
-    qb = w % nqb;
-    const int rest = w / nqb;
-    h = rest % a.heads;
-    item = rest / a.heads;
-  }
+  const int qb = w % nqb;
+  const int rest = w / nqb;
+  const int h = rest % a.heads;
+  const int item = rest / a.heads;
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
   const f16* __restrict__ K = reinterpret_cast<const f16*>(a.K);
@@ -515,18 +502,10 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
 
   const int nqb = (a.nq + BQ - 1) / BQ;
   const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
-  int qb, h, item;
-  if (ME_ATTN_HEAD_FASTEST(a)) {   // short key lists (the 77 text keys): the blocks that share an XCD's L2 at one time are the heads of the SAME query rows (see "Block order" above)
-    h = w % a.heads;
-    const int rest = w / a.heads;
-    qb = rest % nqb;
-    item = rest / nqb;
-  } else {
-    qb = w % nqb;
-    const int rest = w / nqb;
-    h = rest % a.heads;
-    item = rest / a.heads;
-  }
+  const int qb = w % nqb;
+  const int rest = w / nqb;
+  const int h = rest % a.heads;
+  const int item = rest / a.heads;
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
   const char* __restrict__ K = reinterpret_cast<const char*>(a.K);
