@@ -308,7 +308,9 @@ def synth_state_dict(schema: Dict[str, Shape], seed: int = 33, salt: str = "") -
         path = os.path.join(cache, f"w_{key:08x}_{total}.npy")
         if os.path.exists(path):
             try:
-                flat = np.load(path)
+                # copy-on-write map: the pages are the file's page-cache pages, shared by every process of the machine that maps the same weights (the
+                # gloo test ranks, `bench.py --gpus N`) until someone writes to them -- 6.7 GB once instead of once per process
+                flat = np.asarray(np.load(path, mmap_mode="c"))
                 if flat.shape == (total,) and flat.dtype == np.float32:
                     out, o = OrderedDict(), 0
                     for k, shp in schema.items():
