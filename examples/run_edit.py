@@ -85,8 +85,12 @@ def main():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--inv-steps", type=int, default=10)
+    ap.add_argument("--executor", choices=["eager", "plan"], default="plan",
+                    help="who issues the ~1100 launches of a denoising step: 'plan' = one me_denoise_step call per step (the launch list is recorded at the first step of "
+                         "each editor gating, csrc/plan.hip), 'eager' = Python, launch by launch; the results are bitwise the same")
     a = ap.parse_args()
     pipe = build_pipeline()
+    pipe.step_executor = a.executor
     x = {k: v.cuda() for k, v in harness_inputs(a.frames, a.size, a.size).items()}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
