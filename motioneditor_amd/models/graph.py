@@ -22,6 +22,7 @@ HEADS = 8
 ADAPTER_CHUNK = 8  # hard-coded num_frames=8 in the reference adapter (controlnet_adapter.py:414,438,472)
 HEAD_MAJOR_KV = __import__("os").environ.get("ME_HEAD_MAJOR_KV", "1") != "0"   # attn1: K and V leave the fused q|k|v projection as per-head [rows, dh] panels (me_gemm_args.C2 / me_attn_args.hsk); A/B switch
 SPLIT_SHARDED_TCONV = __import__("os").environ.get("ME_SPLIT_TCONV", "1") != "0"   # frame-sharded TemporalConv: interior frames behind the posted halo exchange, boundary frames after it
+INPLACE_SKIPS = __import__("os").environ.get("ME_INPLACE_SKIPS", "1") != "0"   # the down path writes its skips straight into the up path's concat buffers (unet_forward); A/B switch
 COND_EMBED_CACHE = True   # ControlNet conditioning embedding of an unchanged skeleton tensor is computed once per run (controlnet_forward)
 
 
@@ -33,6 +34,7 @@ class Act:
     f: int
     h: int
     w: int
+    cat: Optional[torch.Tensor] = None   # a skip that was produced in place: the up path's concat buffer [rows, C_hidden + C] whose right columns `t` is
 
     @property
     def N(self) -> int:
@@ -478,11 +480,30 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
                 motion.append(adapter_for(len(skips) - 1, s))
 
     skips: List[Act] = []
+    # Skips produced in place (exact; -12 copies of 16 ... 252 MB per step): `torch.cat([hidden, skip], 1)` of up resnet (i, j) (unet_2d_blocks.py) is one
+    # buffer [rows, C_hidden + C_skip]; its right columns are allocated HERE, on the way down, and the op that produces skip k -- the 12 skips are consumed
+    # in reverse order, skip k by up resnet number 11 - k -- writes them directly (a strided `out=`), the next down layer, the adapter and the motion
+    # update read / update them where they lie, and the up path later writes the hidden half beside them.  Not while sharded / recording a tape / tapping
+    # (other allocation rules), not for skip 0 without the CFG prefix (conv_small has no strided output) and not for the last skip when the adapter
+    # updates it (it is also the mid block's un-updated input: its updated clone goes into the slot instead, below).
+    inplace_skips = INPLACE_SKIPS and shard is None and taps is None and not getattr(ops, "recording", False)
+
+    def skip_slot(c_skip: int, rows: int):
+        """(concat buffer, its right-hand column view) for the skip about to be produced, or (None, None)."""
+        k = len(skips)
+        if not inplace_skips or (k == 11 and down_res is not None):
+            return None, None
+        c_all = P.mat(f"up_blocks.{(11 - k) // 3}.resnets.{(11 - k) % 3}.conv1.weight").shape[2]
+        buf = torch.empty((rows, c_all), dtype=P.dtype, device=dev)
+        return buf, buf[:, c_all - c_skip:]
+
     if share:   # skip 0 (the up path's last concat and the adapter's first block read all B entries): the shared rows, twice
-        full = torch.empty((B * f * h * w, x.C), dtype=x.t.dtype, device=dev)
+        buf, full = skip_slot(x.C, B * f * h * w)
+        if full is None:
+            full = torch.empty((B * f * h * w, x.C), dtype=x.t.dtype, device=dev)
         ops.copy_rows(full[:x.t.shape[0]], x.t)
         ops.copy_rows(full[x.t.shape[0]:], x.t)
-        push_skip(Act(full, B, f, h, w))
+        push_skip(Act(full, B, f, h, w, buf))
     else:
         push_skip(x)
     for i in range(4):
@@ -492,15 +513,19 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             if prefix:   # the shared sub-batch: me_gemm picks its kernels as for the full batch, so that the rows are bitwise those of the duplicated execution
                 ops.SELECT_ROWS_SCALE = 2
             try:
-                x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard)
+                buf, slot = skip_slot(P.vec(n + ".conv1.bias").shape[0], x.t.shape[0] * (2 if prefix else 1))
+                x = resnet_block(P, n, x, temb, toff[n], per_frame_stats=False, shard=shard, out=None if DOWN_HAS_ATTN[i] else slot)
                 if DOWN_HAS_ATTN[i]:
-                    x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", expand=2 if prefix else 1, **kw)
+                    x = transformer2d(P, f"down_blocks.{i}.attentions.{j}", x, text, tseg, place="down", expand=2 if prefix else 1, out=slot, **kw)
             finally:
                 if prefix:
                     ops.SELECT_ROWS_SCALE = 1
+            x.cat = buf
             push_skip(x)
         if i < 3:
-            x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
+            buf, slot = skip_slot(x.C, x.t.shape[0] // 4)
+            x = conv3x3(P, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, **({} if slot is None else {"out": slot}))
+            x.cat = buf
             push_skip(x)
     if taps is not None:
         taps["skips"] = [s.t.clone() for s in skips]
@@ -520,7 +545,13 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             for i, (s, m) in enumerate(zip(skips, motion)):
                 tgt = s
                 if i == len(skips) - 1:  # the last skip is also the mid block's input: keep that one un-modified
-                    tgt = s.like(ops.clone_rows(s.t) if getattr(ops, "NATIVE", False) and s.t.is_cuda else s.t.clone())
+                    if inplace_skips:    # ... and put its updated clone where the up path's first concat wants it
+                        c_all = P.mat("up_blocks.0.resnets.0.conv1.weight").shape[2]
+                        buf = torch.empty((s.t.shape[0], c_all), dtype=P.dtype, device=dev)
+                        tgt = s.like(ops.copy_rows(buf[:, c_all - s.C:], s.t))
+                        tgt.cat = buf
+                    else:
+                        tgt = s.like(ops.clone_rows(s.t) if getattr(ops, "NATIVE", False) and s.t.is_cuda else s.t.clone())
                 if two_branch:           # [0, m0, 0, m1] (unet_2d_condition.py:481)
                     n = s.f * s.N
                     for k, eb in enumerate(edit_rows):
@@ -559,10 +590,13 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     for i in range(4):
         for j in range(3):
             s = skips.pop()
-            if cat is None:
-                cat = torch.empty((x.t.shape[0], x.C + s.C), dtype=P.dtype, device=dev)
+            if cat is None:     # the first concat: the mid block's output is copied in (a level-3 tensor)
+                cat = s.cat if s.cat is not None else torch.empty((x.t.shape[0], x.C + s.C), dtype=P.dtype, device=dev)
                 ops.copy_rows(cat[:, :x.C], x.t)
-            ops.copy_rows(cat[:, x.C:], s.t)
+            if s.cat is None:   # a skip that was not produced in place
+                ops.copy_rows(cat[:, x.C:], s.t)
+            elif s.cat is not cat or cat.shape[1] != x.C + s.C:
+                raise RuntimeError("unet_forward: a skip's concat buffer does not match the up path's layout")
             # the LAST op of this block (resnet / transformer / upsampler) writes its result straight into the left columns of
             # the next block's concat buffer: one copy per concat instead of two
             n = f"up_blocks.{i}.resnets.{j}"
@@ -570,7 +604,11 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             ups = j == 2 and i < 3
             nxt = None
             if skips:
-                nxt = torch.empty((x.t.shape[0] * (4 if ups else 1), cout + skips[-1].C), dtype=P.dtype, device=dev)
+                nxt = skips[-1].cat     # the next skip sits in its concat buffer already: this block's result goes into the columns beside it
+                if nxt is None:
+                    nxt = torch.empty((x.t.shape[0] * (4 if ups else 1), cout + skips[-1].C), dtype=P.dtype, device=dev)
+                elif nxt.shape != (x.t.shape[0] * (4 if ups else 1), cout + skips[-1].C):
+                    raise RuntimeError("unet_forward: a skip's concat buffer does not match the up path's layout")
             tgt = None if nxt is None else nxt[:, :cout]
             last = "ups" if ups else ("attn" if UP_HAS_ATTN[i] else "res")
             x = resnet_block(P, n, x.like(cat), temb, toff[n], per_frame_stats=False, shard=shard, out=tgt if last == "res" else None)

@@ -119,3 +119,29 @@ def test_zero_temporal_conv_is_skipped_and_equals_running_it(emu, unet_sd_np, mo
         want = ref_cpu.unet_forward({k: torch.from_numpy(v) for k, v in sd0.items()}, c["sample"], c["t"], c["ehs"])
     assert max_rel(out, want) < 2e-4
 
+
+
+@pytest.mark.parametrize("kind", ["single", "two"])
+def test_skips_produced_in_place_equal_the_copied_form(emu, monkeypatch, unet_sd_np, kind):
+    """unet_forward writes the down path's skips straight into the up path's concat buffers (graph.INPLACE_SKIPS): the same launches on the same values --
+    bitwise the output of the form that copies every skip into its concat -- with 11 fewer row copies: every skip but skip 0 (conv_small has no strided
+    output; under the shared classifier-free-guidance prefix of a pipeline step that one is in place too).  Two-branch: the last skip's motion-updated
+    clone lands in its slot -- on this emulation the copied form's clone is torch's, not a copy_rows call, hence 10 counted."""
+    c = synth.make_case_inputs(kind, B=4 if kind == "two" else 2, f=8, h=8, w=8)
+    unet = UNet2DConditionModel(unet_sd_np, device="cpu", dtype=torch.float32)
+    kw = dict(down_block_additional_residuals=c["down_res"], mid_block_additional_residual=c["mid_res"]) if kind == "two" else {}
+    real = emu_ops.copy_rows
+    outs, copies = {}, {}
+    for flag in (False, True):
+        monkeypatch.setattr(graph, "INPLACE_SKIPS", flag)
+        n = [0]
+
+        def counting(y, x, n=n):
+            n[0] += 1
+            return real(y, x)
+
+        monkeypatch.setattr(emu_ops, "copy_rows", counting)
+        outs[flag] = unet(c["sample"], c["t"], c["ehs"], **kw).sample
+        copies[flag] = n[0]
+    assert torch.equal(outs[True], outs[False])
+    assert copies[False] - copies[True] == (10 if kind == "two" else 11), copies
