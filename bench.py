@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--main-priority", type=int, default=0, choices=[-1, 0],
                     help="A/B: HIP priority of the stream the step runs on (-1 = high: the side stream's ControlNet / adapter kernels then only take what the main "
                          "stream's kernels leave idle; 0 = torch's default stream)")
+    ap.add_argument("--side-priority", type=int, default=0, choices=[-1, 0], help="A/B: HIP priority of the side stream (ControlNet + adapter)")
     ap.add_argument("--comm", choices=["auto", "torch", "rccl"], default="auto",
                     help="who issues the data-path exchanges of the sharded modes: 'torch' = torch.distributed's nccl (= RCCL) process group; 'rccl' = RCCL called "
                          "directly on our own communicators (motioneditor_amd/rccl.py: no watchdog, capturable); auto = rccl with --graph, else torch")
@@ -424,6 +425,7 @@ def main():
 
     sed.cur_step = ted.cur_step = 4 if args.editors == "active" else 0   # active: the steady-state step (46 of 50)
     i0 = 4
+    pipe.side_stream_priority = args.side_priority
     if args.main_priority != 0 and not args.emulate:
         sync()
         torch.cuda.set_stream(torch.cuda.Stream(priority=args.main_priority))
@@ -511,7 +513,7 @@ def main():
                           "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
-                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(use_plan), "main_stream_priority": args.main_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(use_plan), "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; ControlNet (diffusers, source not in the reference tree): TRUNK pinned "
                                          "against the reference's own 2-D-degenerate SD-1.5 blocks (tests/golden/controlnet_trunk.npz), its 8 conditioning-embedding convolutions and "
                                          "13 1x1 zero-convolutions self-pinned"},

@@ -64,6 +64,7 @@ class MotionEditorPipeline:
         self.overlap_controlnet = True
         self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
         self._side_stream = None
+        self.side_stream_priority = 0   # HIP priority of the side stream (-1 = high); A/B switch, measured in DESIGN.md section 3.1
         self._graphs = {}               # denoise_step_graphed: (shapes, editor gating) -> captured step
         self._plans = {}                # denoise_step_planned: (shapes, editor gating) -> recorded launch list (plan.StepPlan)
         # who issues the launches of a step inside __call__'s loop: "eager" = this Python process, launch by launch (denoise_step);
@@ -282,7 +283,7 @@ class MotionEditorPipeline:
 
             if self.overlap_controlnet and x4.is_cuda and taps is None:
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream()
+                    self._side_stream = torch.cuda.Stream(priority=self.side_stream_priority)
                 main = torch.cuda.current_stream()
                 plan.wait_stream(self._side_stream, main)
                 with torch.cuda.stream(self._side_stream):
