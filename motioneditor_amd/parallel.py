@@ -43,9 +43,10 @@ def stats_summary(steps: int = 1) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# Exchange backends.  Every data-path exchange of this module goes through one of these two adapters (same interface):
+# Exchange backends.  Every data-path exchange of this module goes through one of these adapters (same interface):
 #   TorchExchange -- torch.distributed's process group ("gloo" in the CPU tests, "nccl" = RCCL for eager multi-GPU runs): collectives run on the
 #                    group's own stream under its watchdog; asynchronous forms return the Work objects.
+#   HostStagedExchange -- verification only: several ranks on ONE GPU, exchanges staged through host memory and a CPU process group.
 #   RcclExchange  -- RCCL called directly (motioneditor_amd/rccl.py): no watchdog, enqueued on the caller's stream or on the communicator's
 #                    side stream behind an event -- the form a captured hipGraph can hold (MotionEditorPipeline.denoise_step_graphed).
 # p2p peers are ranks INSIDE the group.
@@ -113,6 +114,44 @@ class RcclExchange:
             self.comm.join(handle[0])
 
 
+class HostStagedExchange(TorchExchange):
+    """VERIFICATION adapter, not a data path: every exchange goes device -> host -> (a CPU process group, i.e. gloo) -> host -> device.  It lets several
+    ranks share ONE GPU -- RCCL refuses two ranks on a device -- so that the real kernels meet the real, non-degenerate exchange pattern of the
+    frame-sharded step (remote halos, the frame<->pixel all-to-all over R > 1 parts, statistics summed over ranks) on a one-GPU box
+    (tests/test_frame_shard_gpu.py).  Blocking: `.cpu()` waits for the producing kernels, the copy back is ordered on the current stream; the
+    asynchronous forms complete before they return."""
+    kind = "staged"
+
+    def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> None:
+        c = t.cpu()
+        super().all_reduce_(c, op)
+        t.copy_(c)
+
+    def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor) -> None:
+        co = torch.empty(out.shape, dtype=out.dtype)
+        super().all_gather_into(co, inp.cpu().contiguous())
+        out.copy_(co)
+
+    def all_gather_start(self, out: torch.Tensor, inp: torch.Tensor):
+        self.all_gather_into(out, inp)
+        return None
+
+    def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
+        cr = torch.empty(recv.shape, dtype=recv.dtype)
+        super().all_to_all(cr, send.cpu().contiguous())
+        recv.copy_(cr)
+
+    def p2p_start(self, ops_):
+        if not ops_:
+            return None
+        staged = [(k, t, (t.cpu().contiguous() if k == "send" else torch.empty(t.shape, dtype=t.dtype)), peer) for k, t, peer in ops_]
+        super().finish(super().p2p_start([(k, c, peer) for k, _t, c, peer in staged]))
+        for k, t, c, _peer in staged:
+            if k == "recv":
+                t.copy_(c)
+        return None
+
+
 _exchanges = {}
 
 
@@ -123,7 +162,7 @@ def exchange(group=None, kind: str = "torch"):
     key = (id(group) if group is not None else None, kind)
     x = _exchanges.get(key)
     if x is None:
-        x = _exchanges[key] = (RcclExchange if kind == "rccl" else TorchExchange)(group)
+        x = _exchanges[key] = {"rccl": RcclExchange, "staged": HostStagedExchange}.get(kind, TorchExchange)(group)
     return x
 
 

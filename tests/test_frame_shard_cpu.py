@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a", adapter="halo"):
+def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a", adapter="halo", comm="torch"):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -60,7 +60,9 @@ def _worker(rank, world, port, f, out_path, hybrid=False, temporal="a2a", adapte
             if rank % 2 == k:
                 shard_group = g
     parallel.reset_stats()
-    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter)
+    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter, comm=comm)
+    if comm == "staged" and cfg_group is not None:
+        cfg_group = parallel.exchange(cfg_group, "staged")
     lo, hi = shard.frame0, shard.frame0 + shard.f_loc
     ted.cur_step = sed.cur_step = step
     got = pipe.denoise_step_frame_sharded(x["latents"][:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_group)
@@ -96,6 +98,17 @@ def test_frame_sharded_step_equals_single_process(tmp_path, f, temporal):
     out = tmp_path / "r.pt"
     port = 29700 + (os.getpid() % 2000) + f + (3 if temporal == "gather" else 0)
     mp.spawn(_worker, args=(2, port, f, str(out), False, temporal, "halo" if temporal == "a2a" else "gather"), nprocs=2, join=True)
+    err = torch.load(out)["err"]
+    assert err < 1e-4, err
+
+
+def test_host_staged_exchange_adapter_carries_the_sharded_step(tmp_path):
+    """parallel.HostStagedExchange (the verification adapter behind tests/test_frame_shard_gpu.py: several ranks on ONE GPU, exchanges staged through host
+    memory and gloo) on the emulated ABI, hybrid layout: halos into strided row blocks, all-to-all, all-gathers, statistics all-reduce, the CFG pair's
+    all-gather -- the result must be the single-process step, as with the plain adapter."""
+    out = tmp_path / "r.pt"
+    port = 29700 + (os.getpid() % 2000) + 91
+    mp.spawn(_worker, args=(4, port, 16, str(out), True, "a2a", "halo", "staged"), nprocs=4, join=True)
     err = torch.load(out)["err"]
     assert err < 1e-4, err
 

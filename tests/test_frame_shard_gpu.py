@@ -1,0 +1,114 @@
+"""The frame-sharded step with REAL kernels and REAL (non-degenerate) exchanges on a one-GPU box: several ranks share cuda:0 -- RCCL refuses two
+ranks on one device, so the exchanges are staged through host memory and a gloo group (parallel.HostStagedExchange, a verification adapter) -- and each
+runs `denoise_step_frame_sharded` on its own frames through libmotioned: remote one-frame K|V halos for attn1, the frame<->pixel all-to-all of temporal
+attention over R > 1 parts (me_copy_blocks + me_tattn with q_parts = kv_parts = R), the adapter's two-frame halos across a straddling 8-frame chunk,
+TemporalConv halos with the interior / boundary row-range launches, GroupNorm statistics summed over ranks.  The gathered latents must be those of the
+single-process step on the same GPU (the CPU tests prove the same pattern on the emulated ABI; the world-1 RCCL test proves the real kernels on
+degenerate exchanges; this one closes the gap between them)."""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from motioneditor_amd import parallel, synth
+    from motioneditor_amd.attn_control import (FullySelfAttentionControlMask, TemporalSelfAttentionControl,
+                                               regiter_fully_attention_editor_diffusers, regiter_temporal_attention_editor_diffusers)
+    from motioneditor_amd.models.controlnet import ControlNetModel
+    from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    x = step_inputs(f=f, h=8, w=8)
+    unet = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cuda")
+    cn = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
+    pipe = MotionEditorPipeline(unet=unet, controlnet=cn)
+    ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
+    regiter_temporal_attention_editor_diffusers(pipe, ted)
+    sed = FullySelfAttentionControlMask(start_step=4, start_layer=10, source_masks=x["masks"])
+    regiter_fully_attention_editor_diffusers(pipe, sed)
+    pipe.scheduler.set_timesteps(50)
+    step = 4
+    t = pipe.scheduler.timesteps[step]
+    H = x["skeleton"].shape[-1]
+    images = x["skeleton"].reshape(f, 3, H, H).cuda()
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    lat = x["latents"].cuda()
+    cfg_x = shard_group = None
+    if hybrid:   # rank = shard * 2 + cfg half (bench.py's layout): CFG pairs {0,1},{2,3}; frame-shard groups {0,2},{1,3}
+        ns = world // 2
+        for s_ in range(ns):
+            g = dist.new_group([2 * s_, 2 * s_ + 1])
+            if rank // 2 == s_:
+                cfg_x = parallel.exchange(g, "staged")
+        for k in range(2):
+            g = dist.new_group([2 * s_ + k for s_ in range(ns)])
+            if rank % 2 == k:
+                shard_group = g
+    parallel.reset_stats()
+    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter, comm="staged")
+    lo, hi = shard.frame0, shard.frame0 + shard.f_loc
+    ted.cur_step = sed.cur_step = step
+    got = pipe.denoise_step_frame_sharded(lat[:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_x)
+    torch.cuda.synchronize()
+    assert (sed.cur_step, ted.cur_step, sed.cur_att_layer, ted.cur_att_layer) == (step + 1, step + 1, 0, 0)
+    st = parallel.stats_summary()
+    assert st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
+    if shard.world > 1:
+        assert st.get("p2p(TemporalConv halo)", {"calls_per_step": 0})["calls_per_step"] > 0, st
+        if temporal == "a2a":
+            assert st["all_to_all(temporal in)"]["calls_per_step"] == st["all_to_all(temporal out)"]["calls_per_step"] == 24, st
+    parts = [torch.empty(got.shape, dtype=got.dtype) for _ in range(world)]
+    dist.all_gather(parts, got.cpu())
+    if hybrid:
+        assert torch.equal(parts[rank], parts[rank ^ 1])     # both members of a CFG pair hold the same frames and must agree exactly
+        parts = parts[0::2]
+    full = torch.cat(parts, dim=2)
+    if rank == 0:   # the single-process step of the same inputs on the same GPU
+        ted.reset(); sed.reset()
+        ted.cur_step = sed.cur_step = step
+        want = pipe.denoise_step(lat, t, emb, torch.cat([images] * 2), 7.5).cpu()
+        err = float((full.double() - want.double()).norm() / want.double().norm())
+        torch.save({"err": err, "stats": st}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(tmp_path, world, f, hybrid=False, temporal="a2a", adapter="halo"):
+    from motioneditor_amd import synth
+    synth.synth_state_dict(synth.unet_schema())                               # fill the per-machine weight cache once: the ranks map it instead of
+    synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")     # generating 1.7 G parameters each
+    out = tmp_path / "r.pt"
+    port = 29100 + (os.getpid() % 2000) + world * 7 + f + (3 if hybrid else 0)
+    mp.spawn(_worker, args=(world, port, f, str(out), hybrid, temporal, adapter), nprocs=world, join=True)
+    return torch.load(out)
+
+
+def test_two_ranks_on_one_gpu_frame_sharded_step_equals_the_plain_step(tmp_path):
+    """24 frames over 2 ranks (the 8-frame chunk [8, 16) straddles the boundary at frame 12).  Not bitwise: a rank's launches are half as tall (other
+    tile shapes on some layers) and the GroupNorm statistics are summed in another order -- the yardstick is the per-kernel fp16 tolerance."""
+    r = _run(tmp_path, 2, 24)
+    from test_model_gpu import record
+    record("frame_shard_two_ranks_one_gpu", r["err"])
+    assert r["err"] < 2e-3, r
+
+
+def test_hybrid_cfg_x_frames_four_ranks_on_one_gpu(tmp_path):
+    """The 8-GPU default layout at half size (CFG pair x 2 frame shards = 4 ranks on the one GPU): every frame-shard exchange at batch 2, the pair's
+    all-gather of the noise prediction, K|V all-gathers instead of halos (`--shard-exchange gather`, the flavour BASELINE configs[3] names)."""
+    r = _run(tmp_path, 4, 16, hybrid=True, temporal="gather", adapter="gather")
+    from test_model_gpu import record
+    record("frame_shard_hybrid_four_ranks_one_gpu", r["err"])
+    assert r["err"] < 2e-3, r
