@@ -112,3 +112,13 @@ def test_hybrid_cfg_x_frames_four_ranks_on_one_gpu(tmp_path):
     from test_model_gpu import record
     record("frame_shard_hybrid_four_ranks_one_gpu", r["err"])
     assert r["err"] < 2e-3, r
+
+
+def test_four_frame_shards_on_one_gpu_the_layout_of_baseline_configs3(tmp_path):
+    """BASELINE configs[3] as written -- 24 frames sharded 6 per rank over 4 ranks -- at 8 x 8 latents: the frame<->pixel all-to-all over 4 parts, the
+    adapter's chunk-first / previous frames fetched from other ranks for every rank but the first (ranges start at frames 6, 12, 18 of chunks that start
+    at 0, 8, 16), TemporalConv halos on both sides of the two middle ranks."""
+    r = _run(tmp_path, 4, 24)
+    from test_model_gpu import record
+    record("frame_shard_four_ranks_one_gpu_config3_layout", r["err"])
+    assert r["err"] < 2e-3, r
