@@ -1,0 +1,204 @@
+// Ring-buffered K <= 640 GEMM, a MODEL of what gemm8p_kernel could become for the level-0 / level-1 dense layers (gfx950).  NOT part of the library.
+//
+// Hypothesis (tools/ubench_fill.hip measures the fill alone): with two 73.7 KB LDS buffers the 256 x 320 tile at K = 320 has ONE slab
+// in flight per CU, and since a slab's MFMA work (1.3 us) is shorter than its load (latency ~2 us + 73.7 KB / 37 GB/s ~ 2 us), every slab pays the full
+// latency: 5 x 4.6 us = the 23 us the "loads only" ablation measured per tile.  A ring of D = 4 slots of BK = 32 (36.9 KB of operands each, padded to 40 KB: 160 KB) keeps THREE slabs
+// (110 KB) in flight while the fourth is consumed; if the fill then streams at the 37 GB/s per CU the attention kernel sees, a tile's loads take ~10 us.
+//
+//   Y[M, N] fp16 = X[M, K] fp16 . W[N, K]^T, fp32 accumulation; 256 x 320 tiles, 8 waves as 2 (M) x 4 (N), wave tile 128 x 80 = 8 x 5 MFMA tiles of
+//   v_mfma_f32_16x16x32_f16 with the WEIGHT fragment as operand A (so that a lane ends up with 4 consecutive output columns of one row), operands staged by
+//   `buffer_load_dwordx4 ... lds` with an XOR source swizzle (LDS piece (row, slot) holds k-chunk slot ^ ((row >> 2) & 3): conflict-free ds_read_b128 fragment
+//   reads at the 64-byte row pitch), one barrier per slab, counted vmcnt.  PERSIST: one block per CU walks tiles, the slab sequence runs on across tile
+//   borders (the next tile's first slabs travel under the current tile's last MFMAs and its epilogue).
+//
+// Self-checking: a sample of outputs is recomputed on the host.  Prints ms and TFLOP/s per variant; compare with tools/kbench.py gemm ("L0 qkv" etc.).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_bin/ubench_ring_gemm tools/ubench_ring_gemm.hip && tools/_bin/ubench_ring_gemm
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BM = 256, BN = 320, BK = 32;
+constexpr int MT = 8, NT = 5;                         // MFMA tiles per wave: 128 rows x 80 columns
+constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2;                             // 16 KB + 20 KB
+constexpr int NIA = A_BYTES / 8192, NIW = (W_BYTES + 8191) / 8192, NI = NIA + NIW;    // DMA instructions per wave and slab: 2 + 3 (the last one half masked)
+// every wave issues all NI instructions (one vmcnt arithmetic for all waves); the masked lanes of the last W instruction still WRITE zeros to LDS, so a slot
+// is padded to whole instructions: 16 + 24 = 40 KB, four slots = the CU's 160 KB exactly
+constexpr int SLOT = A_BYTES + NIW * 8192;
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ int xcd_remap(int bid, int total) {   // as me_common.h: each XCD (block id % 8) gets a contiguous run of work items
+  const int q = total >> 3, r = total & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+template <int REM>
+__device__ __forceinline__ void wait_younger() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REM * NI)); }
+
+template <int D, int PERSIST, int STORE>
+__global__ __launch_bounds__(512) void ring_gemm(const f16* __restrict__ X, const f16* __restrict__ W, f16* __restrict__ Y, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nbn = N / BN, ntiles = (M / BM) * nbn, S = K / BK;
+  const int my_tiles = PERSIST ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 1;
+  const long total = (long)my_tiles * S;
+
+  // DMA source offsets (bytes inside the tile's A / W row block): LDS piece p = j * 64 + lane of a part holds (row p >> 2, k-chunk (p & 3) ^ ((row >> 2) & 3))
+  unsigned aoff[NIA], woff[NIW];
+#pragma unroll
+  for (int t = 0; t < NIA; ++t) {
+    const int p = (wave + 8 * t) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+    aoff[t] = (unsigned)(row * K * 2 + c * 16);
+  }
+#pragma unroll
+  for (int t = 0; t < NIW; ++t) {
+    const int p = (wave + 8 * t) * 64 + lane, row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+    woff[t] = row < BN ? (unsigned)(row * K * 2 + c * 16) : OOB;
+  }
+  auto tile_of = [&](int seq) {    // the seq-th tile of this block (wave-uniform: forced into an SGPR so that the descriptors below stay scalar)
+    return __builtin_amdgcn_readfirstlane(PERSIST ? xcd_remap((int)blockIdx.x + seq * (int)gridDim.x, ntiles) : xcd_remap((int)blockIdx.x, ntiles));
+  };
+  int iss_seq = 0, iss_kc = 0, iss_slot = 0;   // the next slab to issue: tile of the sequence, slab of the tile, ring slot (no divisions in the loop)
+  auto issue = [&]() {
+    const int w = tile_of(iss_seq);
+    const int tile_n = w % nbn, tile_m = w / nbn;
+    const auto xsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(X + (long)tile_m * BM * K), 0, (unsigned)(BM * K * 2), 0x00020000);
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W + (long)tile_n * BN * K), 0, (unsigned)(BN * K * 2), 0x00020000);
+    char* dst = smem + iss_slot * SLOT + wave * 1024;
+#pragma unroll
+    for (int t = 0; t < NIA; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lptr_t)(dst + t * 8192), 16, (int)aoff[t], iss_kc * BK * 2, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NIW; ++t) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lptr_t)(dst + A_BYTES + t * 8192), 16, (int)woff[t], iss_kc * BK * 2, 0, 0);
+    if (++iss_kc == S) { iss_kc = 0; ++iss_seq; }
+    if (++iss_slot == D) iss_slot = 0;
+  };
+
+  // fragment addresses inside a slot: row (lane & 15) of the 16-row block, k-chunk (lane >> 4) at slot (lane >> 4) ^ ((row >> 2) & 3); block offsets are
+  // multiples of 16 rows, so the swizzle term depends on the lane alone
+  const int frow = lane & 15, fslot = (lane >> 4) ^ ((frow >> 2) & 3);
+  const int xbase = ((wm * 128 + frow) * 4 + fslot) * 16, wbase = A_BYTES + ((wn * 80 + frow) * 4 + fslot) * 16;
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int issued = 0, q_seq = 0, q_kc = 0, q_slot = 0;
+  const int total_i = (int)total;
+  for (int d = 0; d < D - 1 && issued < total_i; ++d, ++issued) issue();
+  for (int q = 0; q < total_i; ++q) {
+    // slab q must have landed; slabs q + 1 .. issued - 1 (at most D - 2 of them) may stay in flight
+    const int younger = issued - 1 - q;
+    if (D >= 4 && younger >= 2) wait_younger<2>();
+    else if (D >= 3 && younger >= 1) wait_younger<1>();
+    else wait_younger<0>();
+    __builtin_amdgcn_s_barrier();          // all waves' pieces of slab q are in LDS, and every wave is done reading the slot of slab q - 1
+    if (issued < total_i) { issue(); ++issued; }   // ... which slab q + D - 1 now refills
+    const char* sl = smem + q_slot * SLOT;
+    f16x8 fx[MT], fw[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fx[i] = *reinterpret_cast<const f16x8*>(sl + xbase + i * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fw[j] = *reinterpret_cast<const f16x8*>(sl + wbase + j * 16 * 64);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+    if (++q_slot == D) q_slot = 0;
+    const bool last = q_kc == S - 1;
+    if (++q_kc == S) q_kc = 0;
+    if (last) {                            // the tile is complete: lane holds Y[m0 + (lane & 15)][n0 + (lane >> 4) * 4 + 0..3] of every (j, i) MFMA tile
+      const int w = tile_of(q_seq++);
+      const int tile_n = w % nbn, tile_m = w / nbn;
+      const long m0 = (long)tile_m * BM + wm * 128 + (lane & 15);
+      const int n0 = tile_n * BN + wn * 80 + (lane >> 4) * 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const f32x4 a = acc[j][i];
+          const f16x4 h = {(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+          if (STORE || a[0] == 1.2345e30f) *reinterpret_cast<f16x4*>(Y + (m0 + i * 16) * N + n0 + j * 16) = h;
+          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  }
+}
+
+static float h2f(f16 h) { return (float)h; }
+
+template <int D, int PERSIST, int STORE>
+void run(const f16* X, const f16* W, f16* Y, int M, int N, int K, const std::vector<f16>& hx, const std::vector<f16>& hw) {
+  const size_t lds = (size_t)D * SLOT;
+  const int ntiles = (M / BM) * (N / BN);
+  const int grid = PERSIST ? 256 : ntiles;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&ring_gemm<D, PERSIST, STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipMemset(Y, 0, (size_t)M * N * 2);
+  hipLaunchKernelGGL((ring_gemm<D, PERSIST, STORE>), dim3(grid), dim3(512), lds, 0, X, W, Y, M, N, K);
+  (void)hipDeviceSynchronize();
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { printf("D %d persist %d: HIP error %s\n", D, PERSIST, hipGetErrorString(e)); return; }
+  double worst = 0.0;
+  if (STORE) {   // sample check against a host dot product of the same fp16 inputs
+    std::vector<f16> row(N);
+    for (int s = 0; s < 24; ++s) {
+      const long m = ((long)s * 1000003L + 17) % M;
+      (void)hipMemcpy(row.data(), Y + m * N, (size_t)N * 2, hipMemcpyDeviceToHost);
+      for (int n = (s * 7) % 13; n < N; n += 29) {
+        double ref = 0.0;
+        for (int k = 0; k < K; ++k) ref += (double)h2f(hx[(size_t)m * K + k]) * (double)h2f(hw[(size_t)n * K + k]);
+        const double err = fabs((double)h2f(row[n]) - ref) / (fabs(ref) + 1.0);
+        if (err > worst) worst = err;
+      }
+    }
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((ring_gemm<D, PERSIST, STORE>), dim3(grid), dim3(512), lds, 0, X, W, Y, M, N, K);
+  (void)hipEventRecord(e1);
+  (void)hipDeviceSynchronize();
+  float ms;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  ms /= 10;
+  printf("M %d N %4d K %d  ring %d x %.1f KB (%d in flight)  %s  stores %d : %7.3f ms  %7.1f TF/s  %5.1f us per tile%s\n", M, N, K, D, SLOT / 1024.0, D - 1,
+         PERSIST ? "persistent " : "one tile/blk", STORE, ms, 2.0 * M * N * K / ms / 1e9, ms * 1e3 / ((double)ntiles / 256.0),
+         STORE ? (worst < 2e-2 ? "  [check ok]" : "  [CHECK FAILED]") : "");
+  if (STORE && worst >= 2e-2) printf("   worst relative error of the sample: %.3e\n", worst);
+}
+
+int main() {
+  const int M = 393216, K = 320, NMAX = 2560;
+  std::vector<f16> hx((size_t)M * K), hw((size_t)NMAX * K);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 9) & 0x7fff) / 32768.0f - 0.5f; };
+  for (auto& v : hx) v = (f16)rnd();
+  for (auto& v : hw) v = (f16)(rnd() * 0.2f);
+  f16 *X, *W, *Y;
+  (void)hipMalloc(&X, hx.size() * 2);
+  (void)hipMalloc(&W, hw.size() * 2);
+  (void)hipMalloc(&Y, (size_t)M * NMAX * 2);
+  (void)hipMemcpy(X, hx.data(), hx.size() * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+  for (int N : {960, 320, 2560}) {
+    run<2, 0, 1>(X, W, Y, M, N, K, hx, hw);   // one slab in flight (the library kernel's depth, at half the slab size)
+    run<3, 0, 1>(X, W, Y, M, N, K, hx, hw);
+    run<4, 0, 1>(X, W, Y, M, N, K, hx, hw);   // three in flight
+    run<4, 1, 1>(X, W, Y, M, N, K, hx, hw);   // ... and the sequence continues across tiles
+    run<4, 1, 0>(X, W, Y, M, N, K, hx, hw);   // ... without the epilogue's stores: the main loop alone
+    run<2, 1, 0>(X, W, Y, M, N, K, hx, hw);
+  }
+  return 0;
+}
