@@ -41,8 +41,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {   // as me_common
   return base + slot;
 }
 
-template <int REM>
-__device__ __forceinline__ void wait_younger() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REM * NI)); }
+// vmcnt counts loads AND stores on gfx9-family parts and retires them in issue order: "slab q has landed" = at most `younger` DMA slabs plus -- for the
+// D - 1 slabs that were already in flight when a tile's epilogue issued its MT * NT stores -- those stores may still be outstanding.  Without the store
+// credit the first waits of the next tile would drain the whole epilogue before the MFMAs restart (what a persistent walk is supposed to avoid).
+template <int REM, int STORES>
+__device__ __forceinline__ void wait_younger() {
+  static_assert(REM * NI + STORES <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(REM * NI + STORES));
+}
 
 template <int D, int PERSIST, int STORE>
 __global__ __launch_bounds__(512) void ring_gemm(const f16* __restrict__ X, const f16* __restrict__ W, f16* __restrict__ Y, int M, int N, int K) {
@@ -94,15 +100,22 @@ __global__ __launch_bounds__(512) void ring_gemm(const f16* __restrict__ X, cons
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int issued = 0, q_seq = 0, q_kc = 0, q_slot = 0;
+  int issued = 0, q_seq = 0, q_kc = 0, q_slot = 0, store_credit = 0;
   const int total_i = (int)total;
   for (int d = 0; d < D - 1 && issued < total_i; ++d, ++issued) issue();
   for (int q = 0; q < total_i; ++q) {
     // slab q must have landed; slabs q + 1 .. issued - 1 (at most D - 2 of them) may stay in flight
     const int younger = issued - 1 - q;
-    if (D >= 4 && younger >= 2) wait_younger<2>();
-    else if (D >= 3 && younger >= 1) wait_younger<1>();
-    else wait_younger<0>();
+    if (STORE && store_credit > 0) {       // slab q was issued BEFORE the last epilogue's stores: they are younger than it, too
+      --store_credit;
+      if (D >= 4 && younger >= 2) wait_younger<2, MT * NT>();
+      else if (D >= 3 && younger >= 1) wait_younger<1, MT * NT>();
+      else wait_younger<0, MT * NT>();
+    } else {
+      if (D >= 4 && younger >= 2) wait_younger<2, 0>();
+      else if (D >= 3 && younger >= 1) wait_younger<1, 0>();
+      else wait_younger<0, 0>();
+    }
     __builtin_amdgcn_s_barrier();          // all waves' pieces of slab q are in LDS, and every wave is done reading the slot of slab q - 1
     if (issued < total_i) { issue(); ++issued; }   // ... which slab q + D - 1 now refills
     const char* sl = smem + q_slot * SLOT;
@@ -132,6 +145,7 @@ __global__ __launch_bounds__(512) void ring_gemm(const f16* __restrict__ X, cons
           if (STORE || a[0] == 1.2345e30f) *reinterpret_cast<f16x4*>(Y + (m0 + i * 16) * N + n0 + j * 16) = h;
           acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+      store_credit = issued - 1 - q;       // the slabs in flight right now were issued before these stores: their waits carry the credit
     }
   }
 }
