@@ -9,6 +9,7 @@
 //   SEG   bytes per row and slab: 128 (BK = 64, the kernel's) or 64 (BK = 32: half-size slabs, so that up to 4 fit the 160 KB of LDS),
 //   SRC   0: A streams through a [393216, 320] matrix once per pass (first touch: HBM), W = one [320, 320] matrix (L2);  1: A confined to 4 MB (L2 hits),
 //   ST    1: every tile ends with the epilogue's stores (20 global_store_dwordx4 per wave: 16 rows x 64 B each) -- do fills and stores share a bottleneck?
+//         2: the same, with the stores credited in the counted waits (they drain under the next fills)
 // If GB/s grows with D at equal SEG the fill is latency-bound and a deeper ring (4 x BK = 32 instead of 2 x BK = 64: 110 KB in flight instead of 74) pays;
 // if it is flat the path is throughput-bound and only fewer bytes per FLOP help.
 //   hipcc --offload-arch=gfx950 -O3 -o tools/_bin/ubench_fill tools/ubench_fill.hip && tools/_bin/ubench_fill
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* A, const char* W,
     woff[i] = row < ROWS_W ? (unsigned)(row * KBYTES + (piece % LPR) * 16) : OOB;
   }
   long issued = 0, total = (long)tiles * SLABS;
+  int store_credit = 0;
   auto issue = [&](long s) {      // slab s of this block's sequence -> ring slot s % D
     const long tile_seq = s / SLABS;
     const int kc = (int)(s % SLABS);
@@ -61,8 +63,14 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* A, const char* W,
   const uint4 v = make_uint4(tid, blockIdx.x, 3, 7);
   for (long s = 0; s < total; ++s) {
     // wait for the OLDEST slab in flight: at most (D - 1) * NI younger DMA instructions of this wave may remain
-    if (D == 1) __builtin_amdgcn_s_waitcnt(0x0f70 | 0);   // vmcnt(0)
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI < 63 ? (D - 1) * NI : 63));
+    // (vmcnt counts stores too and retires in issue order: ST == 2 adds the epilogue's 20 stores to the allowance for the D slabs that were already in flight
+    //  when they were issued, so that the stores drain under the following fills instead of ahead of them; ST == 1 is the naive counted wait)
+    if (ST == 2 && store_credit > 0) {
+      --store_credit;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI + 20 < 63 ? (D - 1) * NI + 20 : 63));
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI < 63 ? (D - 1) * NI : 63));
+    }
     __builtin_amdgcn_s_barrier();                          // (no fence: __syncthreads would drain vmcnt to 0 and with it the slabs in flight) every wave's pieces of the slab have landed (the consumer would read it here)
     if (issued < total) issue(issued++);                   // refill the slot
     if (ST && (s % SLABS) == SLABS - 1) {                  // the tile's epilogue: this wave's 64 rows x 160 columns, 16 rows x 64 B per instruction
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* A, const char* W,
       if (r0 + 64 <= rows_total) {
 #pragma unroll
         for (int q = 0; q < 20; ++q) out[(r0 + (q / 5) * 16 + (lane & 15)) * 40 + c0 + (q % 5) * 4 + (lane >> 4)] = v;
+        store_credit = D;
       }
     }
   }
@@ -123,6 +132,9 @@ int main() {
   }
   run<1, 128, 1>(A, W, out, rows, 0);   // the real kernel's in-flight depth, with the epilogue's stores
   run<2, 128, 1>(A, W, out, rows, 0);
+  run<2, 128, 2>(A, W, out, rows, 0);
   run<3, 64, 1>(A, W, out, rows, 0);
+  run<3, 64, 2>(A, W, out, rows, 0);
+  run<4, 64, 2>(A, W, out, rows, 0);
   return 0;
 }
