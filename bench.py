@@ -136,6 +136,21 @@ def make_pipeline(device, usd, csd, masks, dtype=None):
     return pipe, sed, ted
 
 
+def planned_or_eager(pipe, state, lat, t, emb, images, guidance=7.5):
+    """One step through me_denoise_step (pipe.denoise_step_planned); if RECORDING the plan fails -- before anything was ever replayed -- the run falls back to
+    the Python-enqueued step for good and says so in the JSON (`launch_plan_error`): the recorded executor changes who issues the launches, not what is
+    computed, and must never cost the measurement.  A plan that has been recorded and then fails to replay is a fault and propagates."""
+    if state["on"]:
+        try:
+            return pipe.denoise_step_planned(lat, t, emb, images, guidance)
+        except Exception as e:   # noqa: BLE001
+            if pipe._plans:
+                raise
+            state["on"], state["error"] = False, f"{type(e).__name__}: {e}"
+            print(f"[bench] recording the step's launch plan failed ({state['error']}); continuing with the eager executor", file=sys.stderr, flush=True)
+    return pipe.denoise_step(lat, t, emb, images, guidance)
+
+
 def step_tflop(f, h, w):
     """Reference-semantics TFLOP of one two-branch step: BASELINE.md's figure for the three configurations it lists, else
     scaled from config 3 by token count (attention scales super-linearly in h*w: approximate, labelled so)."""
@@ -394,6 +409,7 @@ def main():
         raise SystemExit("--plan covers the single-process steps (the sharded steps' RCCL exchanges are not library launches); use --graph there")
     plan_default = single_process and f * h * w <= 24 * 64 * 64 and not args.eager
     use_plan = (args.plan or plan_default) and not (args.emulate or args.inversion or use_graph or args.null_text or args.vae_decode)
+    plan_state = {"on": bool(use_plan), "error": None}
 
     def run_step(i, lat):
         if args.inversion:   # one body of util.ddim_loop (reference util.py:118-123)
@@ -404,8 +420,8 @@ def main():
             emb1 = torch.cat([unc[i], cond[:1]])
             if use_graph and ops.PROFILE is None:
                 return pipe.denoise_step_graphed(lat, ts[i], emb1, None, 7.5)
-            if use_plan and ops.PROFILE is None:
-                return pipe.denoise_step_planned(lat, ts[i], emb1, None, 7.5)
+            if plan_state["on"] and ops.PROFILE is None:
+                return planned_or_eager(pipe, plan_state, lat, ts[i], emb1, None)
             return pipe.denoise_step(lat, ts[i], emb1, None, 7.5)
         emb = torch.cat([unc[i].expand(2, 77, 768), cond])
         graphed = use_graph and ops.PROFILE is None
@@ -419,8 +435,8 @@ def main():
             return pipe.denoise_step_cfg_parallel(lat, ts[i], emb, images, 7.5, group=cfg_group)
         if graphed:
             return pipe.denoise_step_graphed(lat, ts[i], emb, images, 7.5)
-        if use_plan and ops.PROFILE is None:
-            return pipe.denoise_step_planned(lat, ts[i], emb, images, 7.5)
+        if plan_state["on"] and ops.PROFILE is None:
+            return planned_or_eager(pipe, plan_state, lat, ts[i], emb, images)
         return pipe.denoise_step(lat, ts[i], emb, images, 7.5)
 
     sed.cur_step = ted.cur_step = 4 if args.editors == "active" else 0   # active: the steady-state step (46 of 50)
@@ -513,7 +529,7 @@ def main():
                           "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
-                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(use_plan), "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(plan_state["on"]), "launch_plan_error": plan_state["error"], "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; ControlNet (diffusers, source not in the reference tree): TRUNK pinned "
                                          "against the reference's own 2-D-degenerate SD-1.5 blocks (tests/golden/controlnet_trunk.npz), its 8 conditioning-embedding convolutions and "
                                          "13 1x1 zero-convolutions self-pinned"},

@@ -71,3 +71,37 @@ def test_synthetic_weight_cache_returns_the_generated_tensors(tmp_path, monkeypa
         assert np.array_equal(ref[k], first[k]) and np.array_equal(ref[k], again[k]) and again[k].shape == tuple(schema[k])
     other = synth.synth_state_dict(schema, seed=6, salt="t.")
     assert not np.array_equal(other["a.weight"], ref["a.weight"]) and len(list(tmp_path.iterdir())) == 2
+
+
+def test_planned_or_eager_falls_back_only_while_nothing_was_replayed():
+    """bench.planned_or_eager: a failure while RECORDING the step's launch plan (nothing replayed yet) switches the run to the eager executor for good and
+    is reported; a failure of a plan that exists propagates."""
+    import bench
+
+    class Pipe:
+        def __init__(self, fail):
+            self._plans, self.fail, self.calls = {}, fail, []
+
+        def denoise_step_planned(self, lat, t, emb, images, g):
+            self.calls.append("plan")
+            if self.fail:
+                raise RuntimeError("no MemPool here")
+            self._plans["k"] = object()
+            return lat + 1
+
+        def denoise_step(self, lat, t, emb, images, g):
+            self.calls.append("eager")
+            return lat + 1
+
+    st = {"on": True, "error": None}
+    p = Pipe(fail=True)
+    assert bench.planned_or_eager(p, st, 1, 0, None, None) == 2 and p.calls == ["plan", "eager"]
+    assert st == {"on": False, "error": "RuntimeError: no MemPool here"}
+    assert bench.planned_or_eager(p, st, 2, 0, None, None) == 3 and p.calls == ["plan", "eager", "eager"]      # stays eager
+    st = {"on": True, "error": None}
+    p = Pipe(fail=False)
+    assert bench.planned_or_eager(p, st, 1, 0, None, None) == 2 and st["on"] and p.calls == ["plan"]
+    p.fail = True                                                                                                  # a recorded plan that fails to replay
+    import pytest as _pt
+    with _pt.raises(RuntimeError):
+        bench.planned_or_eager(p, st, 1, 0, None, None)
