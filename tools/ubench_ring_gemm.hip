@@ -12,7 +12,8 @@
 //   the 16 lanes of a group must hit 16 distinct 16-byte bank quads; slot ^ ((row >> 2) & 3) does NOT, checked by enumeration), one barrier per slab, counted vmcnt.  PERSIST: one block per CU walks tiles, the slab sequence runs on across tile
 //   borders (the next tile's first slabs travel under the current tile's last MFMAs and its epilogue).
 //
-// Self-checking: a sample of outputs is recomputed on the host.  Prints ms and TFLOP/s per variant; compare with tools/kbench.py gemm ("L0 qkv" etc.).
+// The index arithmetic (DMA piece mapping, fragment addresses, MFMA lane semantics, epilogue scatter) and the bank-conflict claim are checked on the CPU by
+// tools/sim_ring_gemm.py (numpy, literal mirror of the formulas below).  Self-checking on the GPU: a sample of outputs is recomputed on the host.  Prints ms and TFLOP/s per variant; compare with tools/kbench.py gemm ("L0 qkv" etc.).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/_bin/ubench_ring_gemm tools/ubench_ring_gemm.hip && tools/_bin/ubench_ring_gemm
 #include <hip/hip_runtime.h>
 #include <math.h>
