@@ -146,6 +146,8 @@ def planned_or_eager(pipe, state, lat, t, emb, images, guidance=7.5):
         except Exception as e:   # noqa: BLE001
             if pipe._plans:
                 raise
+            # denoise_step_planned has put the editors' step / layer counters back where they were before its warm-up / recording pass
+            # (and dropped the half-built plan), so the eager step below IS this step.
             state["on"], state["error"] = False, f"{type(e).__name__}: {e}"
             print(f"[bench] recording the step's launch plan failed ({state['error']}); continuing with the eager executor", file=sys.stderr, flush=True)
     return pipe.denoise_step(lat, t, emb, images, guidance)
@@ -480,9 +482,7 @@ def main():
         ov = (pipe.overlap_controlnet, pipe.overlap_adapter)
         for st in pipe._plans.values():      # the recorded step's private pool goes back to the allocator before the eager pass needs the memory
             plan_stats = st["plan"].stats()
-            st["plan"].close()
-        pipe._plans.clear()
-        torch.cuda.empty_cache()
+        pipe.release_plans()
         pipe.overlap_controlnet = pipe.overlap_adapter = False
         if rank == 0:
             ops.PROFILE = []

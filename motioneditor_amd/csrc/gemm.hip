@@ -1264,7 +1264,10 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   int S = 1;
   if (STAGE == STAGE_BUF && a->work) {
     const int nit = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
-    S = choose_split(a, (long)nbm * nbn, nit);
+    // (the split decision looks at the grid of the launch the caller SELECTS by -- sel_rows: a row-range piece or a sub-batch must sum in the order of
+    // the full launch)
+    const int Msel = a->sel_rows > a->M ? a->sel_rows : a->M;
+    S = choose_split(a, (long)((Msel + BM - 1) / BM) * nbn, nit);
     if ((int64_t)S * a->M * a->N * 4 > a->work_bytes || a->N % 4 || ((uintptr_t)a->work & 15)) S = 1;
   }
   if (S > 1) {
@@ -1385,6 +1388,8 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   const bool wide = a->N % 128 == 0 || a->N % 64 != 0;
   if (stage_impl() == STAGE_GLDS) {
     // big tile when the grid still fills the chip: every model width is a multiple of 320
+    // EVERY tile-count heuristic below uses Msel (round-4 advisor finding: only the big-tile and halo choices did, so the interior and boundary
+    // pieces of a row-range TemporalConv could land on different kernel families than the unsplit launch).
     // kernel selection looks at the grid the launch WOULD have with sel_rows rows (> 0: the caller computes a sub-batch of a larger launch once -- the
     // classifier-free-guidance prefix of the UNet graph -- and wants the rows it gets to be bitwise those of the full launch: the halo kernel and the
     // gather kernels add the (tap, channel slab) products in different orders)
@@ -1401,20 +1406,20 @@ extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
       // tiles with 4 column tiles per wave (every GEGLU width of the model, 2560 ... 10240, is a multiple of 256)
       if (buf && use_8p() > 0 && nit8 >= use_8p()) {
         if (!a->geglu) return dense ? launch_gemm8p<256, 320, false>(a, st) : launch_gemm8p<256, 320, true>(a, st);
-        if (dense && a->N % 256 == 0 && (long)((a->M + 255) / 256) * (a->N / 256) >= big_min_blocks()) return launch_gemm8p<256, 256, false>(a, st);
+        if (dense && a->N % 256 == 0 && (long)((Msel + 255) / 256) * (a->N / 256) >= big_min_blocks()) return launch_gemm8p<256, 256, false>(a, st);
       }
       return buf ? launch_gemm<256, 320, STAGE_BUF>(a, st) : launch_gemm<256, 320, STAGE_GLDS>(a, st);
     }
     // grids of 256 < tiles < 512 (the M = 24576 level at N = 1280: 384 tiles = 1.5 rounds of the 256 CUs): 192-row tiles of the 8-phase kernel
     // make it 512 = 2 full rounds
     // (K >= 512 only: the K = 320 projections of this size are bound by their residual / output traffic and measured 7 % slower)
-    if (a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= 8 && nit8 >= use_8p() && (long)((a->M + 191) / 192) * (a->N / 320) >= min_tiles_192())
+    if (a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= 8 && nit8 >= use_8p() && (long)((Msel + 191) / 192) * (a->N / 320) >= min_tiles_192())
       return dense ? launch_gemm8p<192, 320, false>(a, st) : launch_gemm8p<192, 320, true>(a, st);
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
-    const long blocks160 = (long)((a->M + 127) / 128) * ((a->N + 159) / 160);
+    const long blocks160 = (long)((Msel + 127) / 128) * ((a->N + 159) / 160);
     {   // grids that leave more than half of the 256 CUs without a 128 x 128 tile (the M = 1536 level: 120 tiles): 64-wide tiles double the block count
-      const long blocks128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+      const long blocks128 = (long)((Msel + 127) / 128) * ((a->N + 127) / 128);
       if (a->N % 64 == 0 && blocks128 < n64_below()) return buf ? launch_gemm<128, 64, STAGE_BUF>(a, st) : launch_gemm<128, 64, STAGE_GLDS>(a, st);
     }
     if (a->N % 128 == 0 && blocks160 < 512) return buf ? launch_gemm<128, 128, STAGE_BUF>(a, st) : launch_gemm<128, 128, STAGE_GLDS>(a, st);

@@ -720,6 +720,14 @@ def _work(nbytes: int, device, tag: str) -> torch.Tensor:
     return t
 
 
+def scratch_trim() -> int:
+    """Free the retired scratch blocks.  Safe only when no captured / recorded step that may hold their addresses is alive -- the caller
+    (MotionEditorPipeline.release_plans) has just dropped all of them.  Returns the number of blocks released."""
+    n = len(_scratch_retired)
+    _scratch_retired.clear()
+    return n
+
+
 def gemm_dw(dy, x, *, dst, taps, K, M, alpha=1.0, conv=None, tconv=None):
     """dst (fp32 [N, taps, K]) += dW of me_gemm's y = alpha * gather(x) @ w^T for dense and TemporalConv layers (the adapter has no 3x3
     convolution): the token axis is the MFMA contraction, per-split fp32 partial tiles are folded in a fixed order."""

@@ -11,6 +11,7 @@ null-text optimisation live in ``motioneditor_amd/util.py``.
 from __future__ import annotations
 
 from dataclasses import dataclass
+import collections
 from typing import Callable, List, Optional, Union
 
 import torch
@@ -65,8 +66,12 @@ class MotionEditorPipeline:
         self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
         self._side_stream = None
         self.side_stream_priority = 0   # HIP priority of the side stream (-1 = high); A/B switch, measured in DESIGN.md section 3.1
-        self._graphs = {}               # denoise_step_graphed: (shapes, editor gating) -> captured step
-        self._plans = {}                # denoise_step_planned: (shapes, editor gating) -> recorded launch list (plan.StepPlan)
+        # denoise_step_graphed / _planned: (shapes, conditioning tensor, editor gating) -> captured / recorded step.  Every entry pins one step's
+        # activations (a private memory pool: GBs at 24 f x 64^2), so both tables are LRU-bounded (`max_cached_steps`; two gatings -- editors inactive /
+        # active -- of one clip are the working set of a 50-step run) and `release_plans()` returns everything.
+        self._graphs = collections.OrderedDict()
+        self._plans = collections.OrderedDict()
+        self.max_cached_steps = 4
         # who issues the launches of a step inside __call__'s loop: "eager" = this Python process, launch by launch (denoise_step);
         # "plan" = one me_denoise_step call per step on CUDA inputs (denoise_step_planned: bitwise the eager result, ~4 x less host time)
         self.step_executor = "eager"
@@ -74,6 +79,37 @@ class MotionEditorPipeline:
     @property
     def _execution_device(self):
         return self.device
+
+    def _cache_get(self, table, key):
+        ent = table.get(key)
+        if ent is not None:
+            table.move_to_end(key)
+        return ent
+
+    def _cache_put(self, table, key, ent):
+        """Insert as most recent; evict the least recently used entries beyond `max_cached_steps` (their plan handle / graph and private pool are released)."""
+        table[key] = ent
+        while len(table) > max(1, int(self.max_cached_steps)):
+            _, old = table.popitem(last=False)
+            self._release_entry(old)
+        return ent
+
+    @staticmethod
+    def _release_entry(ent):
+        pl = ent.pop("plan", None)
+        if pl is not None:
+            pl.close()
+        ent.clear()          # graph, static inputs / outputs, the conditioning tensor and its embedding: dropped with their pool
+
+    def release_plans(self):
+        """Drop every recorded launch plan and captured graph (and the memory pools they pin).  The next planned / graphed step records again."""
+        for table in (self._plans, self._graphs):
+            while table:
+                _, old = table.popitem(last=False)
+                self._release_entry(old)
+        ops.scratch_trim()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
 
     def enable_vae_slicing(self):        # reference pipeline :93-94 (inference.py:197); the VAE here decodes per image already
         if self.vae is not None and hasattr(self.vae, "enable_slicing"):
@@ -342,21 +378,29 @@ class MotionEditorPipeline:
                self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter)
         ca, cb = self.scheduler.coeffs(int(t))
         host = torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32)
-        ent = self._graphs.get(key)
+        ent = self._cache_get(self._graphs, key)
         if ent is None:
             editors = [e for e in (sed, ted) if e is not None]
             counters = [(e.cur_step, e.cur_att_layer) for e in editors]
+
+            def rewind():
+                for e, (cs, cl) in zip(editors, counters):
+                    e.cur_step, e.cur_att_layer = cs, cl
+
             st = dict(lat=latents.clone(), emb=text_embeddings_input.clone(), params=host.to(latents.device))
-            step(st["lat"], st["emb"])                      # warm-up, eager
-            torch.cuda.synchronize()
-            for e, (cs, cl) in zip(editors, counters):
-                e.cur_step, e.cur_att_layer = cs, cl
             before = {k: list(v) for k, v in parallel.STATS.items()}
-            g = torch.cuda.CUDAGraph()
-            ops.STEP_PARAMS = st["params"]
             try:
+                step(st["lat"], st["emb"])                      # warm-up, eager
+                torch.cuda.synchronize()
+                rewind()
+                before = {k: list(v) for k, v in parallel.STATS.items()}
+                g = torch.cuda.CUDAGraph()
+                ops.STEP_PARAMS = st["params"]
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     st["out"] = step(st["lat"], st["emb"])
+            except BaseException:
+                rewind()        # a failed warm-up / capture must leave the editors where the caller had them: its fallback step is THIS step
+                raise
             finally:
                 ops.STEP_PARAMS = None
             # the exchanges of the captured step, for bench.py's `comm` accounting: added again at every replay
@@ -368,9 +412,8 @@ class MotionEditorPipeline:
             st["images"] = images      # keep the captured conditioning tensor alive
             if self.controlnet is not None:   # ... and the conditioning embeddings the graph may have baked in (graph.controlnet_forward's table may drop them later)
                 st["cond_embed"] = dict(self.controlnet.P.cache.get("cond_embed", {}))
-            for e, (cs, cl) in zip(editors, counters):
-                e.cur_step, e.cur_att_layer = cs, cl
-            ent = self._graphs[key] = st
+            rewind()
+            ent = self._cache_put(self._graphs, key, st)
         ent["lat"].copy_(latents)
         ent["emb"].copy_(text_embeddings_input)
         ent["params"].copy_(host, non_blocking=False)
@@ -403,10 +446,10 @@ class MotionEditorPipeline:
         latents = latents.contiguous().float()
         emb = text_embeddings_input.contiguous()
         key = (tuple(latents.shape), tuple(emb.shape), emb.dtype, None if images is None else (tuple(images.shape), images.data_ptr(), images._version),
-               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter,
-               torch.cuda.current_stream().cuda_stream)
+               self._editor_gate(), float(controlnet_conditioning_scale), self.dedup_controlnet, self.dedup_cfg_prefix, self.overlap_controlnet, self.overlap_adapter)
+        # (the caller's stream is NOT part of the key: me_denoise_step substitutes the live stream for the recorded main stream)
         ca, cb = self.scheduler.coeffs(int(t))
-        ent = self._plans.get(key)
+        ent = self._cache_get(self._plans, key)
         if ent is None:
             editors = [e for e in (sed, ted) if e is not None]
             counters = [(e.cur_step, e.cur_att_layer) for e in editors]
@@ -418,6 +461,7 @@ class MotionEditorPipeline:
             st = dict(lat=latents.clone(), emb=emb.clone(), params=torch.tensor([float(t), float(guidance_scale), ca, cb], dtype=torch.float32).to(latents.device))
             step = lambda: self.denoise_step(st["lat"], t, st["emb"], images, guidance_scale, controlnet_conditioning_scale)   # noqa: E731
             ops.STEP_PARAMS = st["params"]
+            pl = None
             try:
                 step()                                   # warm-up, eager
                 torch.cuda.synchronize()
@@ -425,16 +469,24 @@ class MotionEditorPipeline:
                 pl = plan.StepPlan()
                 with pl.recording():
                     st["out"] = step()
+                torch.cuda.synchronize()
+                pl.bind(st["lat"], st["emb"], st["params"], st["out"])
+            except BaseException:
+                # the warm-up or the recording pass raised part-way through a step: the editors' (cur_step, cur_att_layer) counters have advanced by a
+                # partial step.  Put them back where the caller had them -- whoever catches this and retries eagerly (bench.planned_or_eager,
+                # run_edit) must compute THIS step, not one with shifted layer gating -- and drop the half-built plan with its pool.
+                rewind()
+                if pl is not None:
+                    pl.close()
+                raise
             finally:
                 ops.STEP_PARAMS = None
-            torch.cuda.synchronize()
-            pl.bind(st["lat"], st["emb"], st["params"], st["out"])
             rewind()
             st["plan"] = pl
             st["images"] = images          # keep the conditioning tensor the recorded launches read alive ...
             if self.controlnet is not None:   # ... and the conditioning embedding computed from it (graph.controlnet_forward's table may drop it later)
                 st["cond_embed"] = dict(self.controlnet.P.cache.get("cond_embed", {}))
-            ent = self._plans[key] = st
+            ent = self._cache_put(self._plans, key, st)
         out = ent["plan"].step(latents, emb, float(t), float(guidance_scale), ca, cb)
         for e in (sed, ted):
             if e is not None:      # what MutualAttentionBase.__call__ does over the step's attention layers

@@ -296,18 +296,26 @@ def synth_tensor(name: str, shape: Shape, seed: int = 33) -> np.ndarray:
 def synth_state_dict(schema: Dict[str, Shape], seed: int = 33, salt: str = "") -> "OrderedDict[str, np.ndarray]":
     """The deterministic synthetic weights of a schema.  Generating the 1.3 G parameters of the UNet takes a minute of one core, and the tests / bench /
     multi-process launches of one session each want them: the flat fp32 image is kept in a per-machine cache file (ME_SYNTH_CACHE, default
-    <tmp>/me_synth_cache; ME_SYNTH_CACHE=0 disables), keyed by the schema, the seed, the salt and the generator's own source text."""
+    <tmp>/me_synth_cache_<uid>, mode 0700; ME_SYNTH_CACHE=0 disables), keyed by a sha1 over the ORDERED schema, the seed, the salt and this
+    module's source text; a cached image is used only if this user owns it and its first / last tensors equal what the generator makes now."""
+    import hashlib
     import inspect
     import os
     import tempfile
-    cache = os.environ.get("ME_SYNTH_CACHE", os.path.join(tempfile.gettempdir(), "me_synth_cache"))
+    uid = os.getuid() if hasattr(os, "getuid") else 0
+    cache = os.environ.get("ME_SYNTH_CACHE", os.path.join(tempfile.gettempdir(), f"me_synth_cache_{uid}"))   # per user, created 0700
     total = sum(int(np.prod(shp)) for shp in schema.values())
     path = None
     if cache != "0" and total >= 1 << 20:
-        key = zlib.crc32(repr((sorted(schema.items()), seed, salt, inspect.getsource(synth_tensor))).encode())
-        path = os.path.join(cache, f"w_{key:08x}_{total}.npy")
+        # the key covers the schema IN ITS ORDER (the flat image is sliced in insertion order), the seed, the salt and the text of this whole module
+        # (synth_tensor and whatever it calls); sha1, not a 32-bit CRC
+        key = hashlib.sha1(repr((list(schema.items()), seed, salt)).encode() + inspect.getsource(inspect.getmodule(synth_tensor)).encode()).hexdigest()[:20]
+        path = os.path.join(cache, f"w_{key}_{total}.npy")
         if os.path.exists(path):
             try:
+                st = os.stat(path)
+                if hasattr(os, "getuid") and st.st_uid != uid:      # someone else's file in a shared tmp: never trusted
+                    raise PermissionError(path)
                 # copy-on-write map: the pages are the file's page-cache pages, shared by every process of the machine that maps the same weights (the
                 # gloo test ranks, `bench.py --gpus N`) until someone writes to them -- 6.7 GB once instead of once per process
                 flat = np.asarray(np.load(path, mmap_mode="c"))
@@ -317,13 +325,16 @@ def synth_state_dict(schema: Dict[str, Shape], seed: int = 33, salt: str = "") -
                         n = int(np.prod(shp))
                         out[k] = flat[o:o + n].reshape(shp)
                         o += n
-                    return out
-            except Exception:   # a torn or foreign file: regenerate
+                    # spot check against the generator: the first and the last tensor of the image must be what synth_tensor makes now
+                    ends = [next(iter(schema)), next(reversed(schema))] if isinstance(schema, OrderedDict) or hasattr(schema, "__reversed__") else [next(iter(schema))]
+                    if all(np.array_equal(out[k], synth_tensor(salt + k, schema[k], seed)) for k in ends):
+                        return out
+            except Exception:   # a torn, stale or foreign file: regenerate
                 pass
     out = OrderedDict((k, synth_tensor(salt + k, shp, seed)) for k, shp in schema.items())
     if path is not None:
         try:
-            os.makedirs(cache, exist_ok=True)
+            os.makedirs(cache, mode=0o700, exist_ok=True)
             tmp = f"{path}.{os.getpid()}.tmp"
             with open(tmp, "wb") as fh:
                 np.save(fh, np.concatenate([v.reshape(-1) for v in out.values()]))

@@ -114,8 +114,6 @@ def test_hybrid_cfg_x_frames_four_ranks_on_one_gpu(tmp_path):
     assert r["err"] < 2e-3, r
 
 
-@pytest.mark.skipif(not os.environ.get("ME_GPU_EXTRA"), reason="written in round 4 after the GPU minutes ran out: never executed on a GPU box yet (ME_GPU_EXTRA=1 runs it); "
-                                                               "its CPU twin is test_frame_shard_cpu.py::test_four_frame_shards_equal_single_process")
 def test_four_frame_shards_on_one_gpu_the_layout_of_baseline_configs3(tmp_path):
     """BASELINE configs[3] as written -- 24 frames sharded 6 per rank over 4 ranks -- at 8 x 8 latents: the frame<->pixel all-to-all over 4 parts, the
     adapter's chunk-first / previous frames fetched from other ranks for every rank but the first (ranges start at frames 6, 12, 18 of chunks that start

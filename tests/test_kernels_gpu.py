@@ -705,7 +705,10 @@ def test_gemm_tconv_sharded_with_halos(ops, C, f_loc, f_tot, frame0, chunk, npix
     check(got, emu.gemm(x, w, M=rows, bias=bias, tconv=tc, res=res), f"tconv sharded f_loc={f_loc} frame0={frame0} chunk={chunk}")
 
 
-@pytest.mark.parametrize("C,f_loc,f_tot,frame0,npix,nb", [(320, 6, 24, 6, 4096, 2), (640, 3, 24, 21, 1024, 4), (1280, 12, 24, 0, 256, 2), (320, 4, 16, 4, 100, 3), (1280, 6, 24, 12, 64, 2)])
+@pytest.mark.parametrize("C,f_loc,f_tot,frame0,npix,nb", [(320, 6, 24, 6, 4096, 2), (640, 3, 24, 21, 1024, 4), (1280, 12, 24, 0, 256, 2), (320, 4, 16, 4, 100, 3), (1280, 6, 24, 12, 64, 2),
+                                                   # shapes whose FULL launch takes the 192-row 8-phase tiles / 128 x 128 tiles / 128 x 64 tiles while a piece by itself
+                                                   # would count fewer tiles (every tile-count heuristic of me_gemm now selects by sel_rows, round-4 advisor finding)
+                                                   (640, 6, 24, 6, 4096, 2), (640, 6, 24, 6, 256, 4), (640, 3, 24, 3, 256, 4)])
 def test_gemm_row_range_pieces_of_a_sharded_tconv_equal_the_one_launch_form(ops, C, f_loc, f_tot, frame0, npix, nb):
     """me_gemm_args.m_off: the interior launches (frames 1 .. f_loc - 2 of every batch entry, issued while the halo exchange travels) and the boundary
     launches (first frame | (last, first) pairs of neighbouring batch entries | last frame) of a frame-sharded TemporalConv must reproduce the one-launch

@@ -295,6 +295,54 @@ def test_planned_step_six_steps_equals_eager(unet, controlnet):
     assert torch.equal(res["eager"], res["plan"])
 
 
+def test_planned_step_failure_rewinds_editors_and_plan_cache_is_bounded(unet, controlnet):
+    """(1) A step that raises during the warm-up / recording pass of denoise_step_planned must leave the editors' (cur_step, cur_att_layer) where the
+    caller had them and no half-built plan behind, so that the caller's eager retry computes THIS step (round-4 advisor finding).  (2) The plan table is
+    an LRU of `max_cached_steps` entries: re-uploaded conditioning tensors do not pin one memory pool each; `release_plans()` empties it."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    x = step_inputs()
+    f = x["latents"].shape[2]
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 64, 64).cuda()
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    pipe.scheduler.set_timesteps(50)
+    sed, ted = editors(unet, x["masks"])
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    lat = x["latents"].cuda()
+    t = pipe.scheduler.timesteps[0]
+    ref = pipe.denoise_step(lat, t, emb, images, 7.5)
+    assert sed.cur_step == 1
+    sed.cur_step = ted.cur_step = 0
+    real, calls = pipe.denoise_step, []
+
+    def flaky(*a, **k):
+        calls.append(1)
+        if len(calls) == 2:         # the RECORDING pass: advance the counters by a partial step, then fail
+            sed.cur_att_layer, ted.cur_att_layer = 7, 3
+            sed.cur_step += 1
+            raise RuntimeError("injected")
+        return real(*a, **k)
+
+    pipe.denoise_step = flaky
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            pipe.denoise_step_planned(lat, t, emb, images, 7.5)
+    finally:
+        pipe.denoise_step = real
+    assert (sed.cur_step, sed.cur_att_layer, ted.cur_step, ted.cur_att_layer) == (0, 0, 0, 0) and not pipe._plans
+    assert torch.equal(pipe.denoise_step(lat, t, emb, images, 7.5), ref)      # the eager retry is the same step
+    # LRU: three conditioning tensors through a table of two
+    pipe.max_cached_steps = 2
+    for k in range(3):
+        sed.cur_step = ted.cur_step = 0
+        out = pipe.denoise_step_planned(lat, t, emb, images.clone(), 7.5)
+        assert torch.equal(out, ref), k
+        assert len(pipe._plans) == min(k + 1, 2)
+    pipe.release_plans()
+    assert not pipe._plans and not pipe._graphs
+    unet.spatial_editor = unet.temporal_editor = None
+
+
 def test_high_gain_weights_step_vs_cpu_oracle():
     """A weight set that drives the activations to SD-like magnitudes (|x| ~ 1e2 - 1e3 after conv_in, large per-channel
     means in front of the GroupNorms): GroupNorm variance (fp64 statistics) and the fp16 range of the residual stream,

@@ -60,3 +60,30 @@ def test_call_two_steps_with_vae_decode_matches_oracle_loop(monkeypatch, unet_sd
     lat = pipe(["a", "b"], video_length=f, height=64, width=64, num_inference_steps=2, latents=lat0, uncond_embeddings=uncs,
                skeleton=x["skeleton"], text_embeddings=x["cond"], output_type="latent").images
     assert float((lat - want).abs().max() / want.abs().mean()) < 2e-4
+
+
+def test_step_cache_is_an_lru_that_closes_what_it_evicts():
+    """MotionEditorPipeline._plans / _graphs (round-4 advisor finding): every entry pins one step's activations, so the tables are LRU-bounded by
+    `max_cached_steps`, an evicted entry's plan is closed, a hit refreshes its recency, and release_plans() empties both."""
+    class Unet:
+        device = torch.device("cpu")
+        spatial_editor = temporal_editor = None
+    closed = []
+
+    class Plan:
+        def __init__(self, n):
+            self.n = n
+
+        def close(self):
+            closed.append(self.n)
+
+    pipe = MotionEditorPipeline(unet=Unet())
+    pipe.max_cached_steps = 2
+    for n in range(3):
+        pipe._cache_put(pipe._plans, ("k", n), dict(plan=Plan(n), lat=torch.zeros(1)))
+        if n == 1:
+            assert pipe._cache_get(pipe._plans, ("k", 0)) is not None      # 0 becomes the most recent: 1 is evicted next
+    assert closed == [1] and list(pipe._plans) == [("k", 0), ("k", 2)]
+    pipe._cache_put(pipe._graphs, "g", dict(graph=object()))
+    pipe.release_plans()
+    assert sorted(closed) == [0, 1, 2] and not pipe._plans and not pipe._graphs

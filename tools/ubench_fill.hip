@@ -50,6 +50,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* A, const char* W,
     const long tile_seq = s / SLABS;
     const int kc = (int)(s % SLABS);
     long tile = (long)blockIdx.x + tile_seq * gridDim.x;
+    tile %= rows_total / ROWS_A;                              // the three column passes of the N = 960 projection re-read every row block
     if (src_window_tiles > 0) tile = (long)blockIdx.x % src_window_tiles + (tile_seq % 2) * src_window_tiles;   // SRC 1: a window that stays in L2
     const auto asrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(A + tile * ROWS_A * KBYTES), 0, (unsigned)(ROWS_A * KBYTES), 0x00020000);
     char* dst = smem + (s % D) * SLOT + wave * 1024;
@@ -74,12 +75,12 @@ __global__ __launch_bounds__(512) void fill_kernel(const char* A, const char* W,
     __builtin_amdgcn_s_barrier();                          // (no fence: __syncthreads would drain vmcnt to 0 and with it the slabs in flight) every wave's pieces of the slab have landed (the consumer would read it here)
     if (issued < total) issue(issued++);                   // refill the slot
     if (ST && (s % SLABS) == SLABS - 1) {                  // the tile's epilogue: this wave's 64 rows x 160 columns, 16 rows x 64 B per instruction
-      const long tile = (long)blockIdx.x + (s / SLABS) * gridDim.x;
-      const long r0 = tile * 256 + (wave >> 1) * 64;
-      const int c0 = (wave & 1) * 20, lane = tid & 63;
-      if (r0 + 64 <= rows_total) {
+      const long tile = (long)blockIdx.x + (s / SLABS) * gridDim.x, nrb = rows_total / ROWS_A;
+      const long r0 = (tile % nrb) * 256 + (wave >> 1) * 64;
+      const int c0 = (int)(tile / nrb) * 40 + (wave & 1) * 20, lane = tid & 63;      // column pass -> its 320 of the 960 output columns (120 uint4 per row)
+      if (r0 + 64 <= rows_total && tile / nrb < 3) {
 #pragma unroll
-        for (int q = 0; q < 20; ++q) out[(r0 + (q / 5) * 16 + (lane & 15)) * 40 + c0 + (q % 5) * 4 + (lane >> 4)] = v;
+        for (int q = 0; q < 20; ++q) out[(r0 + (q / 5) * 16 + (lane & 15)) * 120 + c0 + (q % 5) * 4 + (lane >> 4)] = v;
         store_credit = D;
       }
     }
@@ -119,7 +120,7 @@ int main() {
   uint4* out;
   hipMalloc(&A, rows * KBYTES + (1 << 20));
   hipMalloc(&W, ROWS_W * KBYTES + 4096);
-  hipMalloc(&out, rows * KBYTES + 4096);
+  hipMalloc(&out, rows * 3 * KBYTES + 4096);
   hipMemset(A, 1, rows * KBYTES);
   hipMemset(W, 2, ROWS_W * KBYTES);
   for (int src = 0; src < 2; ++src) {
