@@ -227,7 +227,8 @@ def main():
         csd = synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")
         cdt, cores, cf, ch, cw = cpu_baseline(usd, csd, args.frames, args.latent, args.latent)
         ctf, exact = step_tflop(cf, ch, cw)
-        print(json.dumps({"cpu_baseline_full": {"seconds": round(cdt, 1), "steps_per_s": round(1.0 / cdt, 6), "cores": cores, "cpu": cpu_model(), "host": socket.gethostname(),
+        import hashlib
+        print(json.dumps({"cpu_baseline_full": {"oracle_sha16": hashlib.sha1((ROOT / "oracle" / "ref_cpu.py").read_bytes()).hexdigest()[:16], "seconds": round(cdt, 1), "steps_per_s": round(1.0 / cdt, 6), "cores": cores, "cpu": cpu_model(), "host": socket.gethostname(),
                                                 "threads_available": os.cpu_count(), "workload": f"{cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents), two-branch + ControlNet + adapter, editors active",
                                                 "tflop_reference_semantics": ctf, "tflops": round(ctf / cdt, 3), "kind": "port", "extrapolated": False,
                                                 "what": "oracle/ref_cpu.denoise_step (fp32 torch CPU restatement of pipeline_motion_editor.py:603-648), one step, wall clock"}}), flush=True)
@@ -603,15 +604,18 @@ def main():
                             f"configs[0] = {cf} frames x {8*ch}x{8*cw} ({ch}x{cw} latents, {ctf} TFLOP): {cdt:.1f} s on {cores} threads = {ctf / cdt:.2f} TFLOP/s; "
                             f"scaled to the bench workload by the reference-semantics FLOP ratio x{scale:.1f}",
                   "sample_seconds": round(cdt, 2), "sample_steps_per_s": round(1.0 / cdt, 5), "sample_extrapolated_steps_per_s": round(1.0 / (cdt * scale), 6)}
-            # the bench workload itself, clocked once per round on a GPU box's host cores (python bench.py --cpu-baseline full) and committed: when the file covers
-            # this workload, `value` is that MEASUREMENT and the bounded sample of this run stands next to it
+            # `value` is ALWAYS what this run measured (the bounded sample, scaled by the FLOP ratio).  The bench workload itself clocked once on a GPU box's
+            # host cores (python bench.py --cpu-baseline full, committed under profiles/) is reported NEXT to it, never in its place (round-4 advisor finding:
+            # a file from another host / day must not silently become the headline CPU number), with the hash of the oracle it was taken with.
             full = ROOT / "profiles" / "cpu_baseline_full.json"
             if full.exists():
                 fj = json.loads(full.read_text()).get("cpu_baseline_full", {})
                 if fj.get("workload", "").startswith(f"{f} frames x {8*h}x{8*w} "):
-                    cb.update(value=fj["steps_per_s"], extrapolated=False, cores=fj.get("cores", cores), cpu=fj.get("cpu", cb["cpu"]), full_config=fj,
-                              value_source="profiles/cpu_baseline_full.json: one oracle step at this very workload clocked on a GPU box's host cores (not in this run: it takes "
-                                           f"{fj.get('seconds')} s); the sample_* fields are this run's bounded configs[0] sample and its FLOP-ratio extrapolation")
+                    import hashlib
+                    now = hashlib.sha1((ROOT / "oracle" / "ref_cpu.py").read_bytes()).hexdigest()[:16]
+                    cb["full_config_measurement"] = dict(fj, source="profiles/cpu_baseline_full.json: one oracle step at this very workload clocked on a GPU box's host cores "
+                                                                    "(NOT in this run)", oracle_sha16_now=now,
+                                                         oracle_unchanged=(fj.get("oracle_sha16") == now) if fj.get("oracle_sha16") else None)
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if dist_on:

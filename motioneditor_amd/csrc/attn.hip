@@ -38,6 +38,7 @@ __device__ unsigned long long g_fallback_blocks;   // blocks of the fixed-offset
 
 
 constexpr float NEG_BIG = -1.0e30f;
+constexpr int ATTN_HEAD_SLOWEST = 1 << 4;   // private bit of me_attn_args.general_dual inside attn2 launches (me_attn sets it; the field is 0 / 1 at the ABI)
 // Ablation builds (tools/build_abl.sh, never the shipped library): bit 0 = no K/V DMA inside the sweep (the stage buffers keep the first stage),
 // bit 1 = no barrier / vmcnt wait inside the sweep, bit 2 = no exp (P = cvt(S)), bit 3 = no tile arithmetic (DMA + barriers only), bit 4 = no re-basing test
 #ifndef ME_ATTN_ABL
@@ -504,8 +505,13 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
   const int qb = w % nqb;
   const int rest = w / nqb;
-  const int h = rest % a.heads;
-  const int item = rest / a.heads;
+  // HEAD_SLOWEST (round 5, multi-segment launches): blocks ordered (head, item, query block) -- with 8 heads an XCD's contiguous run is ONE head over all
+  // items, so the frame that item f reads as `cur` is still in that XCD's L2 when item f + 1 reads it as `prev` (4 items of a head run at a time on the
+  // XCD's 32 CUs: 5 frames x 655 KB of K | V at dh = 40, N = 4096 -- inside the 4 MB).  In the (item, head) order the XCD ran 4 (item, head) pairs of
+  // 2 x 2 frames = 5.2 MB and met every K | V frame twice, a dozen block rounds apart: the 1.55 - 1.67 x HBM traffic of the round-3 / round-4 PMC passes.
+  const bool head_slowest = (a.general_dual & ATTN_HEAD_SLOWEST) != 0;
+  const int h = head_slowest ? rest / a.n_items : rest % a.heads;
+  const int item = head_slowest ? rest % a.n_items : rest / a.heads;
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
   const char* __restrict__ K = reinterpret_cast<const char*>(a.K);
@@ -1230,7 +1236,12 @@ int launch_attn2(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 16 * QT * NW;
   const int nqb = (a->nq + BQ - 1) / BQ;
   const long total = (long)a->n_items * a->heads * nqb;
-  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD>), dim3((unsigned)total), dim3(64 * NW), 0, st, *a);
+  me_attn_args b = *a;
+  {   // block order (see attn2_kernel): heads slowest for launches whose items share K | V frames with their neighbours (>= 2 segments); ME_ATTN_ORDER=0: A/B
+    const char* e = getenv("ME_ATTN_ORDER");
+    if (a->nseg >= 2 && !(e && e[0] == '0')) b.general_dual |= ATTN_HEAD_SLOWEST;
+  }
+  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD>), dim3((unsigned)total), dim3(64 * NW), 0, st, b);
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d,%s>", DH, QT, NW, FOLD ? "fold" : "classic");   // (the two variants of a shape are different kernels: bench.py / pmc_summary.py key on this)

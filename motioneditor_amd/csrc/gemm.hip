@@ -45,6 +45,7 @@ constexpr int BK = 64;
 #define WIDE_TERMS 0
 #endif
 constexpr int STAGE_REG = 0, STAGE_GLDS = 1, STAGE_BUF = 2;
+constexpr int ROWEPI_FLAG = 1 << 30;   // me_gemm_args.splits_ (private to me_gemm): the 8-phase kernel takes the row-contiguous epilogue
 
 // epilogue stores.  NT = non-temporal: used by the GEGLU epilogue only (a [rows, 4C] tensor that the next GEMM streams once: L0 0.832 -> 0.805 ms,
 // L2 0.576 -> 0.560); on epilogues that read a residual -- usually the very lines they then write -- non-temporal stores cost 20-50 %.
@@ -317,6 +318,158 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
       if (sC) *reinterpret_cast<uint2*>(lrow + 16 * j) = o[i][j].u;
       else st8(crow + 16 * j, o[i][j].u);
     }
+  }
+}
+
+// Row-contiguous epilogue of the 8-phase kernels (round 5; `ME_GEMM_ROWEPI=0` restores epilogue_rows for the A/B).
+//
+// Measured (tools/ubench_epi.hip, tools/ubench_fill.hip, profiles/r05_epi_fill.txt): the output stores of a 256 x 320 tile cost as much as its whole
+// main loop at K = 320 (24.4 us per tile with, 13.4 without), they do not overlap with the next tile's fills whatever the ring depth or the
+// counted-wait credit (the CU's memory pipeline takes fills and stores in order), staggering the CUs changes nothing, and even stores into an
+// L2-resident window keep 8 of the 11 us: the cost is the store INSTRUCTIONS -- about 53 cycles per 1 KB instruction plus 1.8 per distinct
+// output row it touches (tools/ubench_store.hip).  The direct epilogue writes 16 rows x 64 B per instruction (16 rows x 32 B with terms).
+// Here a wave parks its fp16 tile, 32 rows at a time, in a PRIVATE LDS scratch (the staging buffers are dead by then; no block barrier) and
+// reads it back row-major, so that every 16-byte store / term load of a lane continues its neighbour's: 160 contiguous bytes per output row
+// and wave, 6.4 rows per instruction.  The ring-GEMM model went 24.0 -> 19.7 us per tile with it.
+//
+// Arithmetic is exactly epilogue_rows': the tile is packed to fp16 (acc * alpha, bias already inside), then rowvec / res / res2 are added
+// with packed fp16 adds in that order -- the results are bitwise those of the direct epilogue (test_gemm_8phase_kernel compares the two).
+// vmcnt retires in order: the term loads of chunk c + 1 are issued BEFORE the stores of chunk c.
+//   mw0 / nw0: first output row / column of this wave's MT*16 x WN tile;  scr: 32 * WN * 2 bytes of LDS owned by this wave.
+template <int F, int NT, int MT, int WN>
+__device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int mw0, int nw0, int lane, char* scr) {
+  static_assert(F >= 0 && (F & 1) == 0 && MT % 2 == 0 && WN % 16 == 0, "row-pass epilogue");
+  constexpr bool has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
+    // a chunk = two 16-row MFMA row blocks = 32 rows x WN columns = 32 * WN / 8 16-byte pieces, IT per lane (5 at WN = 80: no masked piece)
+  constexpr int NCHK = MT / 2, ROWS = 32, CH = WN / 8, PIECES = ROWS * CH, IT = PIECES / 64, PITCH = WN * 2;
+  static_assert(PIECES % 64 == 0, "whole instructions per chunk");
+  const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
+  const f16* res = reinterpret_cast<const f16*>(a.res);    // may alias C (in-place residual): a piece is read and written by the same lane
+  const f16* res2 = reinterpret_cast<const f16*>(a.res2);
+  f16* C = reinterpret_cast<f16*>(a.C);
+  union P4 { f16x2 h[2]; uint2 u; };
+  union P8 { f16x2 h[4]; uint4 u; };
+  P4 o[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      o[i][j].h[0] = __builtin_convertvector((f32x2){acc[j][i][0] * a.alpha, acc[j][i][1] * a.alpha}, f16x2);
+      o[i][j].h[1] = __builtin_convertvector((f32x2){acc[j][i][2] * a.alpha, acc[j][i][3] * a.alpha}, f16x2);
+    }
+  // this lane's pieces: piece t of a chunk = 16-byte piece p = 64 t + lane = (row p / CH, columns 8 (p % CH) ...) -- the same in every chunk
+  int prow[IT], pcol[IT];
+#pragma unroll
+  for (int t = 0; t < IT; ++t) {
+    const int p = t * 64 + lane;
+    prow[t] = p / CH;
+    pcol[t] = nw0 + (p - prow[t] * CH) * 8;
+  }
+  // row maps of the terms without a division per piece: a wave tile spans at most two row vectors / one wrap of a shared residual whenever those
+  // periods are at least the tile height (every launch of the model); the general forms stay behind a wave-uniform test
+  constexpr int TH = MT * 16;
+  int v0 = 0, vb = 0x7fffffff, r0 = 0, q0 = 0;
+  if constexpr (has_rv) { v0 = mw0 / a.rows_per_vec; vb = (v0 + 1) * a.rows_per_vec; }
+  if constexpr (has_res) r0 = a.res_rows > 0 ? mw0 % a.res_rows : 0;
+  if constexpr (has_res2) q0 = a.res2_rows > 0 ? mw0 % a.res2_rows : 0;
+  auto vrow = [&](int m) { return a.rows_per_vec >= TH ? v0 + (m >= vb ? 1 : 0) : m / a.rows_per_vec; };
+  auto wrap = [&](int m, int period, int first) {
+    if (period <= 0) return m;
+    if (period < TH) return m % period;
+    const int x = first + (m - mw0);
+    return x >= period ? x - period : x;
+  };
+  // The row vector (the time embedding of temp_conv1 / conv1: one row per batch entry) depends on the column alone while the wave tile lies inside one
+  // vector row -- every tile but the few that straddle two batch entries: its IT pieces are then fetched ONCE per tile, not once per chunk (wave-uniform
+  // test; the straddling tiles fetch per chunk like a residual).  The residuals are the pipelined terms: NRES of them per chunk.
+  constexpr int NRES = (has_res ? 1 : 0) + (has_res2 ? 1 : 0), NRV = NRES > 0 ? NRES : 1;
+  bool rv_once = false;
+  P8 rvp[has_rv ? IT : 1];
+  if constexpr (has_rv) {
+    const int mlast = min(mw0 + TH, a.M) - 1;
+    rv_once = vrow(mw0) == vrow(mlast);
+    if (rv_once) {
+#pragma unroll
+      for (int t = 0; t < IT; ++t) rvp[t].u = *reinterpret_cast<const uint4*>(rowvec + (long)vrow(mw0) * a.ldrv + pcol[t]);
+    }
+  }
+  auto load_rv = [&](int c) {     // a tile that straddles two vector rows: per chunk
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      int m = mw0 + c * ROWS + prow[t];
+      if (m >= a.M) m = mw0;
+      rvp[t].u = *reinterpret_cast<const uint4*>(rowvec + (long)vrow(m) * a.ldrv + pcol[t]);
+    }
+  };
+  auto load_terms = [&](int c, P8 (&tv)[NRV][IT]) {
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      int m = mw0 + c * ROWS + prow[t];
+      if (m >= a.M) m = mw0;     // a row that exists: the value is never stored
+      int k = 0;
+      if constexpr (has_res) tv[k++][t].u = *reinterpret_cast<const uint4*>(res + (long)wrap(m, a.res_rows, r0) * a.ldr + pcol[t]);
+      if constexpr (has_res2) tv[k++][t].u = *reinterpret_cast<const uint4*>(res2 + (long)wrap(m, a.res2_rows, q0) * a.ldr2 + pcol[t]);
+    }
+  };
+  const int wrow = lane & 15, wq = lane >> 4;
+  auto park = [&](int c, P8 (&d)[IT]) {     // MFMA layout -> this wave's LDS scratch -> row-major 16-byte pieces (piece p = scratch bytes [16 p, 16 p + 16): PITCH = 16 CH)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) *reinterpret_cast<uint2*>(scr + (ii * 16 + wrow) * PITCH + (j * 16 + wq * 4) * 2) = o[c * 2 + ii][j].u;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) d[t].u = *reinterpret_cast<const uint4*>(scr + (t * 64 + lane) * 16);
+  };
+  auto add_rv = [&](P8 (&d)[IT]) {          // order of the packed fp16 adds as in epilogue_rows: rowvec, res, res2
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[t].h[q] += rvp[t].h[q];
+  };
+  auto add_terms = [&](P8 (&d)[IT], P8 (&tv)[NRV][IT]) {
+#pragma unroll
+    for (int k = 0; k < NRES; ++k)
+#pragma unroll
+      for (int t = 0; t < IT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[t].h[q] += tv[k][t].h[q];
+  };
+  // head-major second output (F == 0 only): element offset of a piece's 8 columns inside C2's row block, or -1 (the columns stay in C)
+  long hoff[IT];
+  const bool c2 = F == 0 && a.C2 != nullptr;
+  if (c2) {
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const int n2 = pcol[t] - a.c2_col0, hh = n2 / a.c2_dh;
+      hoff[t] = n2 >= 0 ? (long)hh * a.c2_hs + (n2 - hh * a.c2_dh) : -1;
+    }
+  }
+  auto store = [&](int c, P8 (&d)[IT]) {
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      const int m = mw0 + c * ROWS + prow[t];
+      if (m >= a.M) continue;
+      f16* dst = C + (long)m * a.ldc + pcol[t];
+      if (c2 && hoff[t] >= 0) dst = reinterpret_cast<f16*>(a.C2) + (long)m * a.c2_dh + hoff[t];
+      st16(dst, d[t].u);
+    }
+  };
+  // software pipeline over the chunks: the residual pieces of chunk c + 1 are requested before chunk c is stored
+  P8 tv[2][NRV][IT];
+  if constexpr (NRES > 0) load_terms(0, tv[0]);
+#pragma unroll
+  for (int c = 0; c < NCHK; ++c) {
+    P8 d[IT];
+    if constexpr (has_rv) {
+      if (!rv_once) load_rv(c);       // (wave-uniform, rare)
+    }
+    park(c, d);
+    if constexpr (has_rv) add_rv(d);
+    if constexpr (NRES > 0) {
+      add_terms(d, tv[c & 1]);
+      if (c + 1 < NCHK) load_terms(c + 1, tv[(c + 1) & 1]);
+    }
+    store(c, d);
   }
 }
 
@@ -1092,6 +1245,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #undef ME_BAR
 #undef ME_LGKM0
 
+  if constexpr (BN == 320) {
+    if (a.splits_ & ROWEPI_FLAG) {   // wave-uniform; me_gemm has checked alignments, N % 320 == 0, no activation / GEGLU
+      // every wave's DMAs have landed (its own vmcnt(0) above + this barrier): the staging buffers are dead, each wave takes 32 x 160 B of them
+      __builtin_amdgcn_s_barrier();
+      char* scr = smem + wave * (32 * WN * 2);
+      const int mw0 = m0 + wr * GR, nw0 = n0 + wc * WN;
+      switch ((a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0)) {
+        case 0: return epilogue_rowpass<0, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
+        case 2: return epilogue_rowpass<2, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
+        case 4: return epilogue_rowpass<4, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
+        case 6: return epilogue_rowpass<6, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
+        case 12: return epilogue_rowpass<12, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
+        default: break;
+      }
+    }
+  }
   auto rowfn = [&](int i) {
     const int m = m0 + wr * GR + i * 16 + (lane & 15);
     return m < a.M ? m : -1;
@@ -1218,6 +1387,11 @@ int use_8p() {   // ME_GEMM_8P=0: every big-tile GEMM stays on the one-barrier-p
   return e ? atoi(e) : 2;
 }
 
+bool row_epilogue() {   // ME_GEMM_ROWEPI=0: the 8-phase kernels keep the direct epilogue (A/B; read per call so that tests can flip it in-process)
+  const char* e = getenv("ME_GEMM_ROWEPI");
+  return !(e && e[0] == '0');
+}
+
 long min_tiles_192() {   // ME_GEMM_8P_192: smallest grid (in 192 x 320 tiles) that takes the 192-row 8-phase kernel (0 = never)
   const char* e = getenv("ME_GEMM_8P_192");
   const long v = e ? atol(e) : 448;
@@ -1306,7 +1480,16 @@ static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
   }
   const int nbm = (a->M - a->m_off + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
   (void)hipGetLastError();
-  hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, *a);
+  me_gemm_args b = *a;
+  b.splits_ = 0;
+  {   // row-contiguous epilogue (epilogue_rowpass): 16-byte pieces of every tensor it touches, one of the specialised term sets
+    auto al = [](const void* p, int ld) { return p == nullptr || (ld % 8 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0); };
+    const int f = (a->rowvec ? 2 : 0) | (a->res ? 4 : 0) | (a->res2 ? 8 : 0);
+    if (BN == 320 && row_epilogue() && !a->geglu && a->act == 0 && a->N % 320 == 0 && (f == 0 || f == 2 || f == 4 || f == 6 || f == 12) && al(a->C, a->ldc) &&
+        al(a->rowvec, a->ldrv) && al(a->res, a->ldr) && al(a->res2, a->ldr2) && (!a->C2 || f == 0))
+      b.splits_ = ROWEPI_FLAG;
+  }
+  hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, b);
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "gemm8p_kernel<%d,%d,%s>", BM, BN, GATHER ? "true" : "false");

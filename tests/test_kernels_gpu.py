@@ -205,6 +205,54 @@ def test_gemm_8phase_kernel(ops, case, monkeypatch):
     check(got[sub], want[sub], f"8-phase gemm {case}")
 
 
+@pytest.mark.parametrize("terms", ["none", "head_major", "rowvec", "res", "rowvec+res", "res+res2", "res shared small", "res shared wrap", "rowvec short", "alpha"])
+@pytest.mark.parametrize("shape", ["256-row", "256-row tail", "192-row"])
+def test_gemm_row_contiguous_epilogue_equals_the_direct_epilogue(ops, terms, shape, monkeypatch):
+    """epilogue_rowpass (round 5: the 8-phase kernels park their fp16 tile in wave-private LDS and store / read terms as 16-byte pieces of
+    160-byte row segments) against the direct epilogue (ME_GEMM_ROWEPI=0): BITWISE for every specialised term set -- no terms, the head-major
+    second output, rowvec, res, rowvec + res, res + res2 -- with shared residual rows shorter than a wave tile (general modulo path) and wrapping
+    inside a tile, a row-vector period shorter than a wave tile, alpha != 1, ragged last row tiles (M % 256 != 0) and the 192-row tiles."""
+    M, N, K = {"256-row": (256 * 520, 320, 128), "256-row tail": (256 * 519 + 77, 640, 128), "192-row": (24576 - 40, 1280, 512)}[shape]
+    if terms == "head_major" and shape == "192-row":
+        pytest.skip("the q|k|v widths (3 C) never land on the 192-row tiles")
+    x, w = rnd(M, K, seed=1).cuda(), rnd(N, 1, K, seed=2, scale=K ** -0.5).cuda()
+    kw = dict(bias=rnd(N, seed=3).cuda())
+    if terms == "head_major":
+        if N % 960:
+            N = 960
+            w = rnd(N, 1, K, seed=2, scale=K ** -0.5).cuda()
+            kw = dict(bias=rnd(N, seed=3).cuda())
+        kw["head_major"] = (N // 3, N // 24)
+    if "rowvec" in terms:
+        rpv = 100 if terms == "rowvec short" else (M + 5) // 6 + 1
+        kw.update(rowvec=rnd((M + rpv - 1) // rpv, N, seed=6).cuda(), rows_per_vec=rpv)
+    if terms in ("res", "rowvec+res", "res+res2", "alpha"):
+        kw["res"] = rnd(M, N, seed=4).cuda()
+    if terms == "res+res2":
+        kw["res2"] = rnd(M, N, seed=5).cuda()
+    if terms.startswith("res shared"):
+        rr = 96 if "small" in terms else 256 * 3 + 50
+        kw.update(res=rnd(rr, N, seed=4).cuda(), res_rows=rr)
+    if terms == "alpha":
+        kw["alpha"] = 0.125 * 3
+    monkeypatch.setenv("ME_GEMM_ROWEPI", "0")
+    ref = ops.gemm(x, w, **kw)
+    want_kernel = "gemm8p_kernel<192" if shape == "192-row" else "gemm8p_kernel<256"
+    assert ops._last_kernel().startswith(want_kernel), ops._last_kernel()
+    monkeypatch.setenv("ME_GEMM_ROWEPI", "1")
+    got = ops.gemm(x, w, **kw)
+    assert ops._last_kernel().startswith(want_kernel), ops._last_kernel()
+    if terms == "head_major":
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    else:
+        assert torch.equal(got, ref), f"{int((got != ref).sum())} elements differ"
+    # in place: the residual aliases the output
+    if terms == "res":
+        buf = kw["res"].clone()
+        ops.gemm(x, w, bias=kw["bias"], res=buf, out=buf)
+        assert torch.equal(buf, ref)
+
+
 def test_gemm_8phase_kernel_views_inplace_and_shared_residual(ops, monkeypatch):
     """The 8-phase kernel on what the launch graph actually hands it: X as a column slice of a wider tensor (ldx > K), the output as a column
     slice, the residual aliased to the output (in place), and a residual shared by several batch entries (res_rows)."""
@@ -266,13 +314,15 @@ def test_gemm_split_k_small_grids(ops, case, monkeypatch):
     check(got, emu.gemm(x, w, **ekw), f"split-K gemm {case}")
 
 
-def test_full_size_properties_of_the_level0_kernels(ops):
-    """Size-independent properties at the benchmarked geometry (24 frames x 64 x 64 latents, batch 4: 393216 rows), where no reference
+@pytest.mark.parametrize("f,N", [(24, 4096), (48, 9216)])
+def test_full_size_properties_of_the_level0_kernels(ops, f, N):
+    """(48, 9216): the same at BASELINE configs[4]'s level-0 size -- 48 frames x 96 x 96 latents, batch 4: 1 769 472 rows, 18 query blocks per (item, head).
+    Size-independent properties at the benchmarked geometry (24 frames x 64 x 64 latents, batch 4: 393216 rows), where no reference
     can be computed in the test: (1) a GEMM is linear in its activations and exact on one-hot activations; (2) an attention whose values are
     all equal returns that value whatever the scores, and whose V is the one-hot of the key index returns rows that sum to 1 (the softmax
     weights); (3) LayerNorm output rows have zero mean and unit variance; (4) GroupNorm output groups likewise."""
     from motioneditor_amd import segments
-    M, C = 4 * 24 * 4096, 320
+    M, C = 4 * f * N, 320
     g = torch.Generator(device="cuda").manual_seed(3)
     x1 = (torch.randn(M, C, device="cuda", generator=g) * 0.5).half()
     # (1a) exactness on one-hot rows: row m selects column (m % C) of W^T
@@ -289,7 +339,7 @@ def test_full_size_properties_of_the_level0_kernels(ops):
     normal = y1.abs() >= 2.0 ** -13
     assert torch.equal(y2[normal], (y1 * 2)[normal]) and float((y2.float() - 2 * y1.float()).abs().max()) <= 2.0 ** -23
     # (2) attention, [prev | cur] segments, dh = 40
-    f, B, N, dh = 24, 4, 4096, 40
+    B, dh = 4, 40
     qkv = (torch.randn(M, 3 * C, device="cuda", generator=g) * 0.7).half()
     si, sm = segments.prev_cur(B, f, "cuda")
     args = dict(heads=8, dh=dh, n_items=B * f, nq=N, nk=N, seg_item=si, seg_mode=sm)
@@ -300,8 +350,8 @@ def test_full_size_properties_of_the_level0_kernels(ops):
     ln = ops.layernorm(x1, torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda")).float()
     assert float(ln.mean(1).abs().max()) < 2e-3 and float((ln.var(1, unbiased=False) - 1).abs().max()) < 5e-3
     # (4) GroupNorm over (frames x pixels x 10 channels) per batch entry
-    gn = ops.groupnorm(x1, torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda"), rows_per_group=24 * 4096, eps=1e-5,
-                       silu=False).float().reshape(4, 24 * 4096, 32, 10)
+    gn = ops.groupnorm(x1, torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda"), rows_per_group=f * N, eps=1e-5,
+                       silu=False).float().reshape(4, f * N, 32, 10)
     assert float(gn.mean((1, 3)).abs().max()) < 1e-3 and float((gn.var((1, 3), unbiased=False) - 1).abs().max()) < 2e-3
 
 

@@ -750,6 +750,51 @@ def _step_vs_golden(tag):
     assert torch.isfinite(got).all() and e_np <= NOISE_PRED_TOL and e <= STEP_TOL, (e_np, e)
 
 
+def test_full_size_properties_configs4(unet, controlnet):
+    """BASELINE configs[4] AS WRITTEN on one GPU -- 48 frames x 768^2 (96 x 96 latents), batch 4, two-branch + ControlNet + adapter, both editors --
+    the 918-TFLOP workload no reference can be computed for in a test.  Size-independent properties of the whole step (pipeline_motion_editor.py:597-654
+    at video_length = 48): (1) finite; (2) run-to-run bitwise; (3) the planned executor (me_denoise_step) reproduces the eager step bit for bit at this
+    size; (4) K/V injection is one-way -- switching the editors on changes the EDIT row and leaves the reconstruction row where it was (to the fp16 noise
+    floor: the edited launches batch their items differently); (5) classifier-free guidance + DDIM are affine in the guidance scale: the step at
+    g = 4.75 is the midpoint of the steps at g = 2 and g = 7.5 (fp32 latents: to rounding).  The 96 x 96 geometry at 8 frames and the 48-frame count
+    at 16 x 16 latents have oracle goldens of their own (test_step_96x96_latents_vs_golden, test_denoise_step_baseline_config0_and_48_frames_vs_cpu_oracle)."""
+    from motioneditor_amd.pipelines import MotionEditorPipeline
+    from test_step_cpu import step_inputs
+    f, h = 48, 96
+    x = step_inputs(f=f, h=h, w=h)
+    pipe = MotionEditorPipeline(unet=unet, controlnet=controlnet)
+    pipe.scheduler.set_timesteps(50)
+    sed, ted = editors(unet, x["masks"])
+    lat = x["latents"].cuda()
+    images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * h).cuda()
+    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    t = pipe.scheduler.timesteps[4]
+
+    def run(step, g=7.5, fn=None):
+        sed.reset(); ted.reset()
+        sed.cur_step = ted.cur_step = step
+        return (fn or pipe.denoise_step)(lat, t, emb, images, g)
+
+    a1 = run(4)
+    a2 = run(4)
+    assert torch.isfinite(a1).all() and float(a1.abs().max()) < 50.0
+    assert torch.equal(a1, a2)                                             # (2)
+    p1 = run(4, fn=pipe.denoise_step_planned)
+    p2 = run(4, fn=pipe.denoise_step_planned)                              # the second call replays the recorded launch list
+    assert torch.equal(p1, a1) and torch.equal(p2, a1)                     # (3)
+    pipe.release_plans()
+    off = run(0)                                                           # editors registered but before their start step: plain attention everywhere
+    e_recon, e_edit = rel_l2(a1[0], off[0]), rel_l2(a1[1], off[1])
+    record("configs4_full_size_recon_row_editors_on_vs_off", e_recon)
+    record("configs4_full_size_edit_row_editors_on_vs_off", e_edit)
+    assert e_recon < 3e-3 and e_edit > 5 * e_recon and e_edit > 1e-3, (e_recon, e_edit)     # (4)
+    lo, mid = run(4, g=2.0), run(4, g=4.75)
+    e_aff = float(((lo.double() + a1.double()) / 2 - mid.double()).abs().max() / mid.double().abs().max())
+    record("configs4_full_size_guidance_affinity", e_aff)
+    assert e_aff < 1e-5, e_aff                                             # (5)
+    unet.spatial_editor = unet.temporal_editor = None
+
+
 def test_step_config3_full_size_vs_golden():
     """BASELINE configs[2] at FULL size -- the benchmarked workload itself (24 frames x 64x64 latents, batch 4, ControlNet + adapter, both editors
     active, bench.py's inputs and weights) -- against tests/golden/step_config3.npz, which oracle/make_golden.py --only-config3 generated in the

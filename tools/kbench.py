@@ -114,6 +114,53 @@ def bench_gemm_8p():
     os.environ.pop("ME_GEMM_8P", None)
 
 
+def bench_gemm_rowepi():
+    """Row-contiguous epilogue (epilogue_rowpass, round 5) vs the direct epilogue on the launches that take the 8-phase 256/192 x 320 tiles
+    (ME_GEMM_ROWEPI flips per call): same process, same data, bitwise check."""
+    import os
+    B, f = 4, 24
+    cases = []
+    for li, (hw, C) in enumerate([(64, 320), (32, 640), (16, 1280)]):
+        M = B * f * hw * hw
+        cases += [(f"L{li} qkv", M, 3 * C, C, None, None, "", None), (f"L{li} qkv head-major", M, 3 * C, C, None, None, "", (C, C // 8)), (f"L{li} proj +b", M, C, C, None, None, "b", None),
+                  (f"L{li} out +b+res", M, C, C, None, None, "br", None), (f"L{li} ff2 +b+res", M, C, 4 * C, None, None, "br", None),
+                  (f"L{li} tconv +b+rv+res", M, C, C, None, (f, hw * hw, f), "bvr", None), (f"L{li} tconv +b+res+res2", M, C, C, None, (f, hw * hw, f), "brs", None)]
+    cases += [("L1->L0 ups conv 640 +b", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, "b", None), ("L0->L1 s2 conv 320 +b", B * f * 1024, 320, 320, (64, 64, 32, 32, 2, 0), None, "b", None),
+              ("L2 conv 2560->1280 +b+rv", B * f * 256, 1280, 2560, (16, 16, 16, 16, 1, 0), None, "bv", None), ("cn L0 out +b+res", 2 * f * 4096, 320, 320, None, None, "br", None)]
+    print(f"{'gemm':30s} {'M':>8s} {'N':>6s} {'K':>6s} {'direct ms':>9s} {'TF/s':>7s} {'rows ms':>8s} {'TF/s':>7s} {'x':>5s}  bitwise", flush=True)
+    tot = [0.0, 0.0]
+    for name, M, N, K, conv, tconv, terms, hm in cases:
+        taps = 9 if conv else (3 if tconv else 1)
+        rows_in = M if not conv else (M // (conv[2] * conv[3])) * conv[0] * conv[1]
+        x, w = rnd(rows_in, K), rnd(N, taps, K) * (0.05 if K * taps > 2000 else 0.2)
+        kw = dict(M=M, conv=conv, tconv=tconv)
+        if "b" in terms:
+            kw["bias"] = rnd(N)
+        if "v" in terms:
+            kw["rowvec"], kw["rows_per_vec"] = rnd(B, N), M // B
+        if "r" in terms:
+            kw["res"] = rnd(M, N)
+        if "s" in terms:
+            kw["res2"] = rnd(M, N)
+        if hm:
+            kw["head_major"] = hm
+        os.environ["ME_GEMM_ROWEPI"] = "0"
+        ref = ops.gemm(x, w, **kw)
+        k_old = ops._last_kernel()
+        t_old = timeit(lambda: ops.gemm(x, w, **kw))
+        os.environ["ME_GEMM_ROWEPI"] = "1"
+        y = ops.gemm(x, w, **kw)
+        ok = all(torch.equal(a_, b_) for a_, b_ in zip(y, ref)) if hm else torch.equal(y, ref)
+        t_new = timeit(lambda: ops.gemm(x, w, **kw))
+        fl = 2.0 * M * N * K * taps
+        tot[0] += t_old
+        tot[1] += t_new
+        print(f"{name:30s} {M:8d} {N:6d} {K*taps:6d} {t_old:9.3f} {fl/t_old/1e9:7.1f} {t_new:8.3f} {fl/t_new/1e9:7.1f} {t_old/t_new:5.2f}  {'equal' if ok else 'DIFFERENT'}  {k_old}", flush=True)
+        del x, w, ref, y, kw
+    print(f"sum: direct {tot[0]:.3f} ms, row-contiguous {tot[1]:.3f} ms ({tot[0] / tot[1]:.3f} x)")
+    os.environ.pop("ME_GEMM_ROWEPI", None)
+
+
 def bench_gemm_cached():
     """Same dense shapes with every X row aliased to row 0 (stride-0 view): X comes from L2, only the output streams.
     The gap to the normal run = what HBM latency / bandwidth on the activation stream costs."""
@@ -220,6 +267,34 @@ def bench_attn(only_first=False):
             ms = timeit(fn)
             print(f"{name + ' (keys grow 60 nats)':28s} {ms:8.3f} {4.0*8*N*nk*units*dh/ms/1e9:9.1f}   blocks that fell back: {ops.attention_fallback_blocks()}")
         del q
+
+
+def bench_attn_order():
+    """Block order of the multi-segment attention launches (ME_ATTN_ORDER flips per call): heads slowest (round 5: an XCD's run is one head over all items,
+    the `cur` frame of item f is still in its L2 when item f + 1 reads it as `prev`) vs items slowest.  Same process, alternating, bitwise check.
+    Head-major K | V panels as the model's q|k|v projection writes them."""
+    import os
+    B, f = 4, 24
+    print(f"{'attn':28s} {'items-slowest ms':>17s} {'heads-slowest ms':>17s} {'x':>6s}  bitwise")
+    for name, dh, N, seg, mask in [("L0 prev|cur", 40, 4096, "pc", False), ("L0 edited", 40, 4096, "ed", True), ("L1 prev|cur", 80, 1024, "pc", False), ("L1 edited", 80, 1024, "ed", True)]:
+        C = 8 * dh
+        items = B * f
+        q = rnd(items * N, C)
+        kv = rnd(16, items * N, dh)          # head-major panels: K heads 0..7, V heads 8..15
+        si, sm = {"pc": lambda: segments.prev_cur(B, f, dev), "ed": lambda: segments.edited_spatial(f, dev, True)}[seg]()
+        mk = (torch.rand(8, N, device=dev) > 0.5).half() if mask else None
+        fn = lambda: ops.attention(q, kv[:8], kv[8:], heads=8, dh=dh, n_items=items, nq=N, nk=N, seg_item=si, seg_mode=sm, mask=mk)
+        res = {}
+        for rep in range(2):
+            for order in ("0", "1"):
+                os.environ["ME_ATTN_ORDER"] = order
+                out = fn()
+                res.setdefault(order, []).append(timeit(fn))
+                res["out" + order] = out
+        t0, t1 = min(res["0"]), min(res["1"])
+        print(f"{name:28s} {t0:17.3f} {t1:17.3f} {t0 / t1:6.3f}  {'equal' if torch.equal(res['out0'], res['out1']) else 'DIFFERENT'}", flush=True)
+        del q, kv
+    os.environ.pop("ME_ATTN_ORDER", None)
 
 
 def bench_attn_headmajor():
@@ -342,8 +417,12 @@ if __name__ == "__main__":
         bench_gemm_8p()
     if "gemmabl" in what:
         bench_gemm_abl()
+    if "rowepi" in what:
+        bench_gemm_rowepi()
     if "gemmc" in what:
         bench_gemm_cached()
+    if "attnorder" in what:
+        bench_attn_order()
     if "attnhm" in what:
         bench_attn_headmajor()
     if "attnhmp" in what:
