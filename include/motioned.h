@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 7
+#define ME_ABI_VERSION 8
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -179,6 +179,11 @@ typedef struct me_attn_args {
   /* ABI 6: head-major K / V (me_gemm_args.C2).  hsk / hsv > 0: element (row, head, d) of K / V lies at row * ldk + head * hsk + d (ldk = dh for
    * contiguous per-head panels); 0: at row * ldk + head * dh + d (heads are column slices of the rows, as Q and O always are). */
   int64_t hsk, hsv;
+  /* ABI 8: head-major Q.  hsq > 0: element (row, head, d) of Q lies at row * ldq + head * hsq + d (the fused q|k|v projection writes all three as
+   * per-head [rows, dh] panels, me_gemm_args.c2_col0 = 0); 0: at row * ldq + head * dh + d.  With the heads-slowest block order of the multi-segment
+   * launches (each XCD owns one head) a head's 80-byte slices of 640-byte Q rows cost 2.4 x their bytes in cache lines per XCD; panels cost 1 x.
+   * O stays a row tensor (the out-projection reads it as its A operand).  Not served by the general-dual kernel. */
+  int64_t hsq;
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);

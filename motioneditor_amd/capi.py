@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 7
+ABI_VERSION = 8
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -51,7 +51,7 @@ class AttnArgs(C.Structure):
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
         ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
         ("vsum", _vp), ("n_kv_items", _i32), ("q_items", _i32), ("lse", _vp),
-        ("hsk", _i64), ("hsv", _i64),
+        ("hsk", _i64), ("hsv", _i64), ("hsq", _i64),
     ]
 
 

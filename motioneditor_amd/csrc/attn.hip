@@ -531,6 +531,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   }
   const float c = a.scale * 1.4426950408889634f;  // fold log2(e): softmax via exp2
 
+  const long hq = a.hsq > 0 ? a.hsq : DH;   // head-major Q panels (ABI 8), or heads as column slices of the rows
   // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8], zero beyond dh.
   // scaled: pre-multiplied by c, so the MFMA result is the logit in log2 units and needs no VALU pass before exp2.
   f16x8 fq[QT][D32];
@@ -545,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
       for (int ks = 0; ks < D32; ++ks) {
         const int d = ks * 32 + g * 8;
         U128 u;
-        u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + qsrc * a.ldq + h * DH + d) : zero128();
+        u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + qsrc * a.ldq + h * hq + d) : zero128();
         if constexpr (decltype(scaled_c)::value) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) u.e[e] = (f16)((float)u.e[e] * c);
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
     for (int ks = 0; ks < 3; ++ks) {
       const int d = ks * 16 + hi32 * 8;
       U128 u;
-      u.u = (q < a.nq && d < DH) ? ldg128(Q + qsrc * a.ldq + h * DH + d) : zero128();
+      u.u = (q < a.nq && d < DH) ? ldg128(Q + qsrc * a.ldq + h * hq + d) : zero128();
 #pragma unroll
       for (int e = 0; e < 8; ++e) u.e[e] = (f16)((float)u.e[e] * c);
       fqw[ks] = u.h;
@@ -1290,7 +1291,8 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V) & 15 || ((uintptr_t)a->O & 7)) { me_set_error("me_attn: misaligned pointer"); return ME_EINVAL; }
   if (a->q_items < 0 || (a->general_dual && (a->q_items > 0 || a->lse))) { me_set_error("me_attn: q_items / lse are not served by the general-dual kernel"); return ME_EINVAL; }
   if (a->lse && a->vsum) { me_set_error("me_attn: lse is written for plain segments only"); return ME_EINVAL; }
-  if (a->hsk < 0 || a->hsv < 0 || a->hsk % 8 || a->hsv % 8) { me_set_error("me_attn: head strides must be non-negative multiples of 8"); return ME_EINVAL; }
+  if (a->hsk < 0 || a->hsv < 0 || a->hsq < 0 || a->hsk % 8 || a->hsv % 8 || a->hsq % 8) { me_set_error("me_attn: head strides must be non-negative multiples of 8"); return ME_EINVAL; }
+  if (a->hsq > 0 && a->general_dual) { me_set_error("me_attn: head-major Q is not served by the general-dual kernel"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (a->general_dual) {   // non-binary masks: the mask-reading kernel

@@ -20,6 +20,7 @@ from ..weights import Packed
 
 HEADS = 8
 ADAPTER_CHUNK = 8  # hard-coded num_frames=8 in the reference adapter (controlnet_adapter.py:414,438,472)
+HEAD_MAJOR_Q = __import__("os").environ.get("ME_HEAD_MAJOR_Q", "1") != "0"     # ... and Q (me_attn_args.hsq, ABI 8); A/B switch
 HEAD_MAJOR_KV = __import__("os").environ.get("ME_HEAD_MAJOR_KV", "1") != "0"   # attn1: K and V leave the fused q|k|v projection as per-head [rows, dh] panels (me_gemm_args.C2 / me_attn_args.hsk); A/B switch
 SPLIT_SHARDED_TCONV = __import__("os").environ.get("ME_SPLIT_TCONV", "1") != "0"   # frame-sharded TemporalConv: interior frames behind the posted halo exchange, boundary frames after it
 INPLACE_SKIPS = __import__("os").environ.get("ME_INPLACE_SKIPS", "1") != "0"   # the down path writes its skips straight into the up path's concat buffers (unet_forward); A/B switch
@@ -166,6 +167,9 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
         if head_major and HEAD_MAJOR_KV and not getattr(ops, "recording", False) and getattr(ops, "HEAD_MAJOR_KV", False):
             # K and V leave the projection as one contiguous [rows, dh] panel per head (me_gemm's second output): what the attention kernel's
             # K/V tile fill wants (2.5 x fewer cache lines than dh-wide slices of 3C-wide rows); Q stays a row tensor
+            if HEAD_MAJOR_Q:   # (round 5) Q as panels too: with the heads-slowest block order each XCD reads ONE head's queries -- 80-byte slices of 640-byte rows
+                _, qkv = ops.gemm(n, P.fused(names), head_major=(0, C // HEADS))   # cost 2.4 x their bytes in cache lines per XCD, panels 1 x
+                return qkv[:HEADS], qkv[HEADS:2 * HEADS], qkv[2 * HEADS:]
             q, kv = ops.gemm(n, P.fused(names), head_major=(C, C // HEADS))
             return q, kv[:HEADS], kv[HEADS:]
         qkv = ops.gemm(n, P.fused(names))

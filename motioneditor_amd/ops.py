@@ -87,7 +87,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     row_range = (lo, hi): only the output rows [lo, hi) of the M-row problem are computed (into `out`, which must be given and hold all M rows): the
     interior / boundary launches of a frame-sharded TemporalConv (me_gemm_args.m_off).
     head_major = (col0, dh): the output columns from col0 on leave as a second tensor [(N - col0) / dh, M, dh] -- one contiguous [rows, dh]
-    panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels)."""
+    panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels); col0 = 0: every column does, the call returns (None, panels)."""
     _chk2d(x, "gemm.x")
     if w.dtype != F16 or not w.is_contiguous() or w.dim() != 3:
         raise ValueError("gemm.w: expected contiguous fp16 [N, taps, K]")
@@ -117,11 +117,13 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     panels = None
     if head_major is not None:
         col0, hdh = head_major
-        if out is not None or geglu or (N - col0) % hdh or col0 <= 0:
-            raise ValueError("gemm: head_major needs whole heads behind col0 > 0 and allocates its own outputs")
+        if out is not None or geglu or (N - col0) % hdh or col0 < 0:
+            raise ValueError("gemm: head_major needs whole heads behind col0 >= 0 and allocates its own outputs")
         panels = torch.empty(((N - col0) // hdh, M, hdh), dtype=F16, device=x.device)
         a.C2, a.c2_col0, a.c2_dh, a.c2_hs = panels.data_ptr(), col0, hdh, M * hdh
         n_out = col0
+        if col0 == 0:      # EVERY column leaves as panels (q | k | v all head-major): C is never written -- any valid, aligned address will do
+            out = panels.view(-1)[:8 * M].view(M, 8)
     if out is None:
         if row_range is not None:
             raise ValueError("gemm: row_range writes into a caller-provided `out` of all M rows")
@@ -169,6 +171,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
         n_terms = (res is not None) + (res2 is not None)
         _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (rows_in * K + N * K * taps + M * n_out * (1 + n_terms)), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
             f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
+    if panels is not None and n_out == 0:
+        return None, panels
     out = out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
     return out if panels is None else (out, panels)
 
@@ -216,11 +220,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
         if v.dim() != 3 or k.shape[0] != heads or v.shape[0] != heads or k.shape[2] != dh or v.shape[2] != dh or k.stride(2) != 1 or v.stride(2) != 1 \
                 or k.dtype != F16 or v.dtype != F16:
             raise ValueError("attention: head-major k / v must be fp16 [heads, rows, dh] with unit column stride")
-        _chk2d(q, "attention.q")
+        if q.dim() == 3:   # head-major Q as well (ABI 8, me_attn_args.hsq): [heads, rows, dh] panels
+            if q.shape[0] != heads or q.shape[2] != dh or q.stride(2) != 1 or q.dtype != F16 or q.stride(1) % 8 or q.stride(0) % 8 or q.data_ptr() % 16:
+                raise ValueError("attention: head-major q must be fp16 [heads, rows, dh] with unit column stride")
+        else:
+            _chk2d(q, "attention.q")
     else:
         for t, n in ((q, "q"), (k, "k"), (v, "v")):
             _chk2d(t, "attention." + n)
-    if q.shape[0] < (q_items or n_items) * nq:
+    qhm = q.dim() == 3
+    if q.shape[1 if qhm else 0] < (q_items or n_items) * nq:
         raise ValueError("attention: q has fewer rows than the items read")
     if seg_item.dtype != torch.int32 or seg_mode.dtype != torch.int32 or seg_item.shape != seg_mode.shape or seg_item.shape[0] != n_items:
         raise ValueError("attention: seg tables must be int32 [n_items, nseg]")
@@ -228,9 +237,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
         out = empty(n_items * nq, heads * dh, q)
     a = AttnArgs()
     a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
-    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(1 if hm else 0), v.stride(1 if hm else 0), out.stride(0)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(1 if qhm else 0), k.stride(1 if hm else 0), v.stride(1 if hm else 0), out.stride(0)
     if hm:
         a.hsk, a.hsv = k.stride(0), v.stride(0)
+    if qhm:
+        a.hsq = q.stride(0)
     a.heads, a.dh = heads, dh
     a.n_items, a.nq, a.nk, a.nseg = n_items, nq, nk, seg_item.shape[1]
     a.seg_item, a.seg_mode, a.mask = seg_item.data_ptr(), seg_mode.data_ptr(), _p(mask)

@@ -1123,6 +1123,9 @@ def test_gemm_head_major_second_output_is_the_same_numbers_elsewhere(ops, M, C, 
     q2, kv2 = ops.gemm(x, w, bias=b, head_major=(C, dh))
     ref2 = ops.gemm(x, w, bias=b)
     assert torch.equal(q2, ref2[:, :C]) and torch.equal(kv2.permute(1, 0, 2).reshape(M, 2 * C), ref2[:, C:])
+    # every column as panels (q | k | v all head-major, c2_col0 = 0): no row tensor comes back
+    none, qkv_p = ops.gemm(x, w, bias=b, head_major=(0, dh))
+    assert none is None and qkv_p.shape == (24, M, dh) and torch.equal(qkv_p.permute(1, 0, 2).reshape(M, 3 * C), ref2)
     with pytest.raises(Exception):
         ops.gemm(x, w, res=ref, head_major=(C, dh))
     with pytest.raises(Exception):
@@ -1152,3 +1155,10 @@ def test_attention_head_major_kv_equals_row_major(ops, dh, N, kind):
     kv = qkv[:, C:].reshape(n_items * N, 16, dh).permute(1, 0, 2).contiguous()
     got = ops.attention(qkv[:, :C], kv[:8], kv[8:], **args)
     assert torch.equal(got, want)
+    # ... and with Q as panels too (ABI 8, me_attn_args.hsq); the general-dual kernel does not serve it
+    qp = qkv[:, :C].reshape(n_items * N, 8, dh).permute(1, 0, 2).contiguous()
+    if kind == "ed_gen":
+        with pytest.raises(Exception):
+            ops.attention(qp, kv[:8], kv[8:], **args)
+    else:
+        assert torch.equal(ops.attention(qp, kv[:8], kv[8:], **args), want)
