@@ -367,16 +367,19 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
   }
   // row maps of the terms without a division per piece: a wave tile spans at most two row vectors / one wrap of a shared residual whenever those
   // periods are at least the tile height (every launch of the model); the general forms stay behind a wave-uniform test
+  // (a ragged last tile: the rows of a wave -- the whole second wave group, even -- may lie past M.  Term loads of such rows read row M - 1 instead, a row
+  //  that exists; nothing is stored for them.  mwc = the wave's first row, clamped the same way: the base of the row maps.)
   constexpr int TH = MT * 16;
+  const int mwc = min(mw0, a.M - 1);
   int v0 = 0, vb = 0x7fffffff, r0 = 0, q0 = 0;
-  if constexpr (has_rv) { v0 = mw0 / a.rows_per_vec; vb = (v0 + 1) * a.rows_per_vec; }
-  if constexpr (has_res) r0 = a.res_rows > 0 ? mw0 % a.res_rows : 0;
-  if constexpr (has_res2) q0 = a.res2_rows > 0 ? mw0 % a.res2_rows : 0;
-  auto vrow = [&](int m) { return a.rows_per_vec >= TH ? v0 + (m >= vb ? 1 : 0) : m / a.rows_per_vec; };
+  if constexpr (has_rv) { v0 = mwc / a.rows_per_vec; vb = (v0 + 1) * a.rows_per_vec; }
+  if constexpr (has_res) r0 = a.res_rows > 0 ? mwc % a.res_rows : 0;
+  if constexpr (has_res2) q0 = a.res2_rows > 0 ? mwc % a.res2_rows : 0;
+  auto vrow = [&](int m) { return a.rows_per_vec >= TH ? v0 + (m >= vb ? 1 : 0) : m / a.rows_per_vec; };   // m in [mwc, M)
   auto wrap = [&](int m, int period, int first) {
     if (period <= 0) return m;
     if (period < TH) return m % period;
-    const int x = first + (m - mw0);
+    const int x = first + (m - mwc);
     return x >= period ? x - period : x;
   };
   // The row vector (the time embedding of temp_conv1 / conv1: one row per batch entry) depends on the column alone while the wave tile lies inside one
@@ -386,26 +389,24 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
   bool rv_once = false;
   P8 rvp[has_rv ? IT : 1];
   if constexpr (has_rv) {
-    const int mlast = min(mw0 + TH, a.M) - 1;
-    rv_once = vrow(mw0) == vrow(mlast);
+    const int mlast = max(min(mw0 + TH, a.M) - 1, mwc);
+    rv_once = vrow(mwc) == vrow(mlast);
     if (rv_once) {
 #pragma unroll
-      for (int t = 0; t < IT; ++t) rvp[t].u = *reinterpret_cast<const uint4*>(rowvec + (long)vrow(mw0) * a.ldrv + pcol[t]);
+      for (int t = 0; t < IT; ++t) rvp[t].u = *reinterpret_cast<const uint4*>(rowvec + (long)vrow(mwc) * a.ldrv + pcol[t]);
     }
   }
   auto load_rv = [&](int c) {     // a tile that straddles two vector rows: per chunk
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-      int m = mw0 + c * ROWS + prow[t];
-      if (m >= a.M) m = mw0;
+      const int m = min(mw0 + c * ROWS + prow[t], a.M - 1);
       rvp[t].u = *reinterpret_cast<const uint4*>(rowvec + (long)vrow(m) * a.ldrv + pcol[t]);
     }
   };
   auto load_terms = [&](int c, P8 (&tv)[NRV][IT]) {
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-      int m = mw0 + c * ROWS + prow[t];
-      if (m >= a.M) m = mw0;     // a row that exists: the value is never stored
+      const int m = min(mw0 + c * ROWS + prow[t], a.M - 1);     // a row that exists: the value of a row past M is never stored
       int k = 0;
       if constexpr (has_res) tv[k++][t].u = *reinterpret_cast<const uint4*>(res + (long)wrap(m, a.res_rows, r0) * a.ldr + pcol[t]);
       if constexpr (has_res2) tv[k++][t].u = *reinterpret_cast<const uint4*>(res2 + (long)wrap(m, a.res2_rows, q0) * a.ldr2 + pcol[t]);
