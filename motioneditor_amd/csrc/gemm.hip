@@ -474,6 +474,48 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
   }
 }
 
+// GEGLU form of the row-contiguous epilogue (round 5): the 256 x 256 tile of the 8-phase GEGLU kernel yields 256 rows x 128 output columns, and a wave's
+// share is 128 rows x 32 columns -- 64-byte row segments however a wave cuts them (16 rows per 1 KB store instruction in the direct epilogue).  Here all
+// eight waves park a * gelu(g) in ONE LDS tile [256 rows][16 chunks of 16 B] behind a block barrier (the staging buffers are dead), and every wave then stores
+// 32 whole 256-byte rows: 4 rows per instruction.  The chunk position inside a row is XOR-swizzled with the row index (c ^ (row & 15)): the MFMA-layout
+// writes (16 rows x one column chunk per ds_write_b64) and the row-major reads both spread over all banks; a lane stores the chunk its position holds, so
+// the 16 lanes of a row still cover the row's 256 bytes.  Same values as epilogue_geglu (same products, same rounding): bitwise.
+template <int NT, int MT, int WN>
+__device__ __forceinline__ void epilogue_geglu_rowpass(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int m0, int n0, int wr, int wc, int lane, char* tile) {
+  static_assert(NT == 4 && WN == 64, "256-wide GEGLU tile: 4 waves x 32 output columns");
+  constexpr int NO = NT / 2, GR = MT * 16;   // output column tiles per wave; rows per wave group
+  f16* C = reinterpret_cast<f16*>(a.C);
+  const int wrow = lane & 15, wq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int jj = 0; jj < NO; ++jj) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * gelu_sigpoly(acc[2 * jj + 1][i][r]);   // alpha == 1 (me_gemm checks)
+      union { f16x2 h[2]; uint2 u; } o;
+      o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
+      o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
+      const int row = wr * GR + i * 16 + wrow;                       // row of the 2 * GR-row tile
+      const int col = wc * 32 + jj * 16 + wq * 4;                    // output column inside the tile's 128
+      const int pos = (col >> 3) ^ (row & 15);                       // swizzled chunk position
+      *reinterpret_cast<uint2*>(tile + row * 256 + pos * 16 + (col & 4) * 2) = o.u;
+    }
+  __syncthreads();
+  // wave w stores rows [32 w, 32 w + 32) of the tile: piece p = 64 t + lane -> row 32 w + p / 16, position p % 16
+  const int wave = wr * 4 + wc;
+  constexpr int RW = 2 * GR / 8;              // rows per wave (32, or 24 at 192-row tiles -- the GEGLU kernel only has the 256-row form)
+  const int Nout0 = n0 / 2;
+#pragma unroll
+  for (int t = 0; t < RW / 4; ++t) {
+    const int p = t * 64 + lane, row = wave * RW + (p >> 4), pos = p & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(tile + row * 256 + pos * 16);
+    const int m = m0 + row, n = Nout0 + ((pos ^ (row & 15)) << 3);
+    if (m < a.M) st16<true>(C + (long)m * a.ldc + n, v);
+  }
+}
+
+
 // any combination of terms, tested element by element (activations, rare combinations)
 template <int NT, int MT, int WN, class RowFn>
 __device__ __forceinline__ void epilogue_generic(const me_gemm_args& a, f32x4 (&acc)[NT][MT], RowFn rowfn, int m0, int n0, int wn, int lane, f16* sC, int CLD) {
@@ -1246,6 +1288,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #undef ME_BAR
 #undef ME_LGKM0
 
+  if constexpr (BN == 256 && BM == 256) {
+    if (a.splits_ & ROWEPI_FLAG) {   // GEGLU: one 64 KB LDS tile for the whole block (me_gemm has checked geglu, N % 256 == 0, ldc % 8 == 0, 16-byte aligned C)
+      __builtin_amdgcn_s_barrier();
+      return epilogue_geglu_rowpass<NT, MT, WN>(a, acc, m0, n0, wr, wc, lane, smem);
+    }
+  }
   if constexpr (BN == 320) {
     if (a.splits_ & ROWEPI_FLAG) {   // wave-uniform; me_gemm has checked alignments, N % 320 == 0, no activation / GEGLU
       // every wave's DMAs have landed (its own vmcnt(0) above + this barrier): the staging buffers are dead, each wave takes 32 x 160 B of them
@@ -1489,6 +1537,7 @@ static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
     if (BN == 320 && row_epilogue() && !a->geglu && a->act == 0 && a->N % 320 == 0 && (f == 0 || f == 2 || f == 4 || f == 6 || f == 12) && al(a->C, a->ldc) &&
         al(a->rowvec, a->ldrv) && al(a->res, a->ldr) && al(a->res2, a->ldr2) && (!a->C2 || f == 0))
       b.splits_ = ROWEPI_FLAG;
+    if (BN == 256 && BM == 256 && row_epilogue() && a->geglu && a->N % 256 == 0 && al(a->C, a->ldc) && !a->C2) b.splits_ = ROWEPI_FLAG;
   }
   hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, b);
   {

@@ -205,7 +205,7 @@ def test_gemm_8phase_kernel(ops, case, monkeypatch):
     check(got[sub], want[sub], f"8-phase gemm {case}")
 
 
-@pytest.mark.parametrize("terms", ["none", "head_major", "rowvec", "res", "rowvec+res", "res+res2", "res shared small", "res shared wrap", "rowvec short", "alpha"])
+@pytest.mark.parametrize("terms", ["none", "head_major", "rowvec", "res", "rowvec+res", "res+res2", "res shared small", "res shared wrap", "rowvec short", "alpha", "geglu"])
 @pytest.mark.parametrize("shape", ["256-row", "256-row tail", "192-row"])
 def test_gemm_row_contiguous_epilogue_equals_the_direct_epilogue(ops, terms, shape, monkeypatch):
     """epilogue_rowpass (round 5: the 8-phase kernels park their fp16 tile in wave-private LDS and store / read terms as 16-byte pieces of
@@ -215,8 +215,14 @@ def test_gemm_row_contiguous_epilogue_equals_the_direct_epilogue(ops, terms, sha
     M, N, K = {"256-row": (256 * 520, 320, 128), "256-row tail": (256 * 519 + 77, 640, 128), "192-row": (24576 - 40, 1280, 512)}[shape]
     if terms == "head_major" and shape == "192-row":
         pytest.skip("the q|k|v widths (3 C) never land on the 192-row tiles")
+    if terms == "geglu":      # the 256 x 256 GEGLU tile: one LDS tile per block, 256-byte rows (epilogue_geglu_rowpass)
+        if shape == "192-row":
+            pytest.skip("the GEGLU kernel has the 256-row form only")
+        N = 2560
     x, w = rnd(M, K, seed=1).cuda(), rnd(N, 1, K, seed=2, scale=K ** -0.5).cuda()
     kw = dict(bias=rnd(N, seed=3).cuda())
+    if terms == "geglu":
+        kw["geglu"] = True
     if terms == "head_major":
         if N % 960:
             N = 960

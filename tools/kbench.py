@@ -125,6 +125,8 @@ def bench_gemm_rowepi():
         cases += [(f"L{li} qkv", M, 3 * C, C, None, None, "", None), (f"L{li} qkv head-major", M, 3 * C, C, None, None, "", (C, C // 8)), (f"L{li} proj +b", M, C, C, None, None, "b", None),
                   (f"L{li} out +b+res", M, C, C, None, None, "br", None), (f"L{li} ff2 +b+res", M, C, 4 * C, None, None, "br", None),
                   (f"L{li} tconv +b+rv+res", M, C, C, None, (f, hw * hw, f), "bvr", None), (f"L{li} tconv +b+res+res2", M, C, C, None, (f, hw * hw, f), "brs", None)]
+    cases += [("L0 ff1 geglu +b", B * f * 4096, 2560, 320, None, None, "bg", None), ("L1 ff1 geglu +b", B * f * 1024, 5120, 640, None, None, "bg", None),
+              ("L2 ff1 geglu +b", B * f * 256, 10240, 1280, None, None, "bg", None)]
     cases += [("L1->L0 ups conv 640 +b", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), None, "b", None), ("L0->L1 s2 conv 320 +b", B * f * 1024, 320, 320, (64, 64, 32, 32, 2, 0), None, "b", None),
               ("L2 conv 2560->1280 +b+rv", B * f * 256, 1280, 2560, (16, 16, 16, 16, 1, 0), None, "bv", None), ("cn L0 out +b+res", 2 * f * 4096, 320, 320, None, None, "br", None)]
     print(f"{'gemm':30s} {'M':>8s} {'N':>6s} {'K':>6s} {'direct ms':>9s} {'TF/s':>7s} {'rows ms':>8s} {'TF/s':>7s} {'x':>5s}  bitwise", flush=True)
@@ -142,6 +144,8 @@ def bench_gemm_rowepi():
             kw["res"] = rnd(M, N)
         if "s" in terms:
             kw["res2"] = rnd(M, N)
+        if "g" in terms:
+            kw["geglu"] = True
         if hm:
             kw["head_major"] = hm
         os.environ["ME_GEMM_ROWEPI"] = "0"
