@@ -184,6 +184,11 @@ typedef struct me_attn_args {
    * launches (each XCD owns one head) a head's 80-byte slices of 640-byte Q rows cost 2.4 x their bytes in cache lines per XCD; panels cost 1 x.
    * O stays a row tensor (the out-projection reads it as its A operand).  Not served by the general-dual kernel. */
   int64_t hsq;
+  /* ABI 8: optional processing order of the query items inside a head's run of the heads-slowest block order: device int32 [n_items], a permutation; the
+   * k-th item a head's blocks work on is item_order[k].  NULL: ascending.  Scheduling only -- the output is bitwise the same.  The edited launches pass
+   * (recon frame g, edit frame g, recon frame g + 1, ...): an edit item reads its source's K | V right after the reconstruction item did, while they
+   * are still in the XCD's L2 (ascending order puts two dozen items between the two). */
+  const int32_t* item_order;
 } me_attn_args;
 
 int me_attn(const me_attn_args* a, void* stream);

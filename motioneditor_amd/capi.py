@@ -51,7 +51,7 @@ class AttnArgs(C.Structure):
         ("n_items", _i32), ("nq", _i32), ("nk", _i32), ("nseg", _i32),
         ("seg_item", _vp), ("seg_mode", _vp), ("mask", _vp), ("scale", _f32), ("general_dual", _i32),
         ("vsum", _vp), ("n_kv_items", _i32), ("q_items", _i32), ("lse", _vp),
-        ("hsk", _i64), ("hsv", _i64), ("hsq", _i64),
+        ("hsk", _i64), ("hsv", _i64), ("hsq", _i64), ("item_order", _vp),
     ]
 
 

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   // 2 x 2 frames = 5.2 MB and met every K | V frame twice, a dozen block rounds apart: the 1.55 - 1.67 x HBM traffic of the round-3 / round-4 PMC passes.
   const bool head_slowest = (a.general_dual & ATTN_HEAD_SLOWEST) != 0;
   const int h = head_slowest ? rest / a.n_items : rest % a.heads;
-  const int item = head_slowest ? rest % a.n_items : rest / a.heads;
+  int item = head_slowest ? rest % a.n_items : rest / a.heads;
+  if (head_slowest && a.item_order) item = __builtin_amdgcn_readfirstlane(a.item_order[item]);   // (ABI 8) the caller's order of the items inside a head's run
 
   const f16* __restrict__ Q = reinterpret_cast<const f16*>(a.Q);
   const char* __restrict__ K = reinterpret_cast<const char*>(a.K);
@@ -1292,6 +1293,7 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (a->q_items < 0 || (a->general_dual && (a->q_items > 0 || a->lse))) { me_set_error("me_attn: q_items / lse are not served by the general-dual kernel"); return ME_EINVAL; }
   if (a->lse && a->vsum) { me_set_error("me_attn: lse is written for plain segments only"); return ME_EINVAL; }
   if (a->hsk < 0 || a->hsv < 0 || a->hsq < 0 || a->hsk % 8 || a->hsv % 8 || a->hsq % 8) { me_set_error("me_attn: head strides must be non-negative multiples of 8"); return ME_EINVAL; }
+  if (a->item_order && ((uintptr_t)a->item_order & 3)) { me_set_error("me_attn: misaligned item_order"); return ME_EINVAL; }
   if (a->hsq > 0 && a->general_dual) { me_set_error("me_attn: head-major Q is not served by the general-dual kernel"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;

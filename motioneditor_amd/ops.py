@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import capi
@@ -254,6 +256,9 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
         bd = bool((seg_mode == 3).any().item())
     a.general_dual = 1 if gd else 0
     a.q_items = q_items
+    order = segments.ITEM_ORDER.get(seg_item.data_ptr())
+    if order is not None and order.device == q.device and order.numel() == n_items and os.environ.get("ME_ATTN_ITEM_ORDER", "1") != "0":   # (A/B switch)
+        a.item_order = order.data_ptr()
     if lse is not None:
         if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != n_items * nq * heads:
             raise ValueError("attention: lse must be a contiguous fp32 [n_items * nq, heads] tensor")

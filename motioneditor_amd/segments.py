@@ -18,12 +18,19 @@ SEG_COUNT: Dict[int, int] = {}  # seg_item.data_ptr() -> number of valid (item, 
 KEY_UNITS: Dict[int, int] = {}  # seg_item.data_ptr() -> sum over items of (1 per plain, 2 per dual segment); FLOP accounting only
 
 
-def _mk(key, rows_item, rows_mode, device, ref_units=None):
-    """ref_units: reference-semantics key units of the table when it differs from what the rows spell out (collapsed duplicates)."""
+ITEM_ORDER: Dict[int, torch.Tensor] = {}    # seg_item.data_ptr() -> int32 permutation of the query items (me_attn_args.item_order), for tables that want one
+
+
+def _mk(key, rows_item, rows_mode, device, ref_units=None, order=None):
+    """ref_units: reference-semantics key units of the table when it differs from what the rows spell out (collapsed duplicates).
+    order: the processing order of the query items inside a head's run of the attention kernel's heads-slowest block order (scheduling only)."""
     hit = _cache.get((key, str(device)))
     if hit is None:
         hit = (torch.tensor(rows_item, dtype=torch.int32, device=device), torch.tensor(rows_mode, dtype=torch.int32, device=device))
         _cache[(key, str(device))] = hit
+        if order is not None:
+            assert sorted(order) == list(range(len(rows_item)))
+            ITEM_ORDER[hit[0].data_ptr()] = torch.tensor(order, dtype=torch.int32, device=device)
         GENERAL_DUAL[hit[1].data_ptr()] = any(m in (SEG_DUAL_CUR, SEG_DUAL_PREV) for rm in rows_mode for m in rm)
         BINARY_DUAL[hit[1].data_ptr()] = any(m == SEG_DUAL_BIN for rm in rows_mode for m in rm)
         SEG_COUNT[hit[0].data_ptr()] = sum(1 for ri in rows_item for i_ in ri if i_ >= 0)
@@ -98,7 +105,10 @@ def edited_spatial(f: int, device, binary_mask: bool = False, B: int = 4, shard=
             else:
                 rows.append([gi(b - 1, max(g - 1, 0)), gi(b - 1, g), gi(b, g)])
                 modes.append([SEG_DUAL_BIN, SEG_DUAL_BIN, SEG_PLAIN] if binary_mask else [SEG_DUAL_PREV, SEG_DUAL_CUR, SEG_PLAIN])
-    return _mk(("edited", f, binary_mask, B) + key, rows, modes, device)
+    # processing order: (recon frame i, edit frame i, recon frame i + 1, ...) per (recon, edit) pair -- an edit item reads its source's K | V right after
+    # the reconstruction item did, while they are still in the XCD's L2 (ascending order puts f items between the two)
+    order = [b * f + i + r * f for b in range(0, B - 1, 2) for i in range(f) for r in (0, 1)] + ([(B - 1) * f + i for i in range(f)] if B % 2 else [])
+    return _mk(("edited", f, binary_mask, B) + key, rows, modes, device, order=order)
 
 
 def has_dual(seg_mode: torch.Tensor) -> bool:
