@@ -105,7 +105,8 @@ typedef struct me_gemm_args {
    * -- the fused q|k|v projection of a self-attention (attention_2d.py:705-768) hands K and V to me_attn as contiguous [keys][dh] panels per
    * head (me_attn_args.hsk / hsv) instead of dh-wide column slices of 3C-wide rows: the attention's K/V tile fill touches 2.5 x fewer cache
    * lines, and the projection's own stores land 80 ... 320 bytes apart instead of 1920 ... 7680.  Requires: no geglu / act / rowvec / res /
-   * res2, c2_dh % 8 == 0, c2_col0 % 16 == 0, (N - c2_col0) % c2_dh == 0, c2_hs % 8 == 0, C2 16-byte aligned. */
+   * res2, c2_dh % 8 == 0, c2_col0 % 16 == 0, (N - c2_col0) % c2_dh == 0, c2_hs % 8 == 0, C2 16-byte aligned.  c2_col0 = 0 (round 5): EVERY column leaves
+   * as panels -- q | k | v all head-major (me_attn_args.hsq) -- and C is never written (it must still be a valid, aligned address). */
   void* C2;
   int32_t c2_col0, c2_dh;
   int64_t c2_hs;      /* elements between the panels of consecutive heads (>= M * c2_dh) */

@@ -154,3 +154,18 @@ def test_plan_helpers_refuse_torch_kernels_inside_a_recorded_step(monkeypatch):
     monkeypatch.setattr(plan, "ACTIVE", None)
     assert graph.text_rows(torch.zeros(2, 77, 768)).shape == (154, 768)
     assert autodiff.Recorder.NATIVE is False and autodiff.Recorder.recording is True
+
+
+def test_edited_launch_item_order_is_a_pairwise_interleaving_permutation():
+    """segments.edited_spatial hands me_attn a processing order (me_attn_args.item_order, ABI 8): (recon frame g, edit frame g, recon g + 1, ...) per
+    (recon, edit) pair, a permutation of the items; other tables have none."""
+    from motioneditor_amd import segments
+    for B, f in ((4, 24), (2, 6), (4, 3)):
+        si, _ = segments.edited_spatial(f, "cpu", True, B)
+        order = segments.ITEM_ORDER[si.data_ptr()].tolist()
+        assert sorted(order) == list(range(B * f))
+        for k in range(0, B * f, 2):
+            assert order[k] % (2 * f) < f and order[k + 1] == order[k] + f      # a reconstruction item, then the edit item of the same frame
+        assert [o for o in order if o % (2 * f) < f] == sorted(o for o in order if o % (2 * f) < f)   # frames ascend inside a pair
+    si, _ = segments.prev_cur(4, 24, "cpu")
+    assert si.data_ptr() not in segments.ITEM_ORDER

@@ -32,7 +32,7 @@ for name, R, B in (("cfg2 x frames2 (4)", 2, 2), ("cfg2 x frames4 (8)", 4, 2), (
 #   (dedup); under a CFG split every pair member computes both again, under frame sharding they shard with the frames.  Small grids lose efficiency:
 #   EFF[batch rows per rank] from the measured secondary workloads (8 f x 32^2: 9.3 TFLOP in 19.9 ms = 0.47 PF/s vs 0.91 at config 3).
 #   links: a 2-rank exchange uses ONE xGMI link (153 GB/s per direction, MI355X guide: 7 links x ~153 GB/s per GPU); an all-to-all among R ranks R - 1 links.
-def predict(one_gpu_ms=160.4, cn_ms=12.0, prefix_ms=4.0, link_gbs=153.0, lat_us=35.0):
+def predict(one_gpu_ms=152.0, cn_ms=11.5, prefix_ms=3.8, link_gbs=153.0, lat_us=35.0):   # round 5: 145.7 ... 155.2 ms/step on seven boxes, 152 in the middle
     rows = []
     base = one_gpu_ms - cn_ms - prefix_ms          # the part that splits along the CFG axis
     n_ops = {1: 0, 2: 185, 4: 185, 8: 185}         # exchanges per step and rank in a frame-sharded step: 16 halos + 2 x 28 all-to-all + 12 + 56 + 45
