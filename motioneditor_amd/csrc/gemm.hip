@@ -45,7 +45,7 @@ constexpr int BK = 64;
 #define WIDE_TERMS 0
 #endif
 constexpr int STAGE_REG = 0, STAGE_GLDS = 1, STAGE_BUF = 2;
-constexpr int ROWEPI_FLAG = 1 << 30;   // me_gemm_args.splits_ (private to me_gemm): the 8-phase kernel takes the row-contiguous epilogue
+constexpr int ROWEPI_FLAG = 1 << 30, TILEORDER_FLAG = 1 << 29;   // me_gemm_args.splits_ (private to me_gemm): the 8-phase kernel takes the row-contiguous epilogue
 
 // epilogue stores.  NT = non-temporal: used by the GEGLU epilogue only (a [rows, 4C] tensor that the next GEMM streams once: L0 0.832 -> 0.805 ms,
 // L2 0.576 -> 0.560); on epilogues that read a residual -- usually the very lines they then write -- non-temporal stores cost 20-50 %.
@@ -1068,7 +1068,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   const int nbn = (a.N + BN - 1) / BN;
   const int nbm = (a.M - a.m_off + BM - 1) / BM;   // tiles cover the rows [m_off, M)
   const int w = xcd_remap(blockIdx.x, nbm * nbn);
-  const int tile_n = w % nbn, tile_m = w / nbn;
+  // tile order inside an XCD's contiguous run: column tiles fastest (default: the nbn tiles of a row block run side by side and share its A rows in L2) or, with
+  // TILEORDER_FLAG (experiment, ME_GEMM_TILE_ORDER=1), row blocks fastest: 32 row blocks of ONE column tile at a time share its weight slabs
+  int tile_n, tile_m;
+  if (a.splits_ & TILEORDER_FLAG) { tile_m = w % nbm; tile_n = w / nbm; }
+  else { tile_n = w % nbn; tile_m = w / nbn; }
   const int m0 = a.m_off + tile_m * BM, n0 = tile_n * BN;
 
   const f16* __restrict__ X = reinterpret_cast<const f16*>(a.X);
@@ -1536,8 +1540,12 @@ static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
     const int f = (a->rowvec ? 2 : 0) | (a->res ? 4 : 0) | (a->res2 ? 8 : 0);
     if (BN == 320 && row_epilogue() && !a->geglu && a->act == 0 && a->N % 320 == 0 && (f == 0 || f == 2 || f == 4 || f == 6 || f == 12) && al(a->C, a->ldc) &&
         al(a->rowvec, a->ldrv) && al(a->res, a->ldr) && al(a->res2, a->ldr2) && (!a->C2 || f == 0))
-      b.splits_ = ROWEPI_FLAG;
-    if (BN == 256 && BM == 256 && row_epilogue() && a->geglu && a->N % 256 == 0 && al(a->C, a->ldc) && !a->C2) b.splits_ = ROWEPI_FLAG;
+      b.splits_ |= ROWEPI_FLAG;
+    {
+      const char* e = getenv("ME_GEMM_TILE_ORDER");
+      if (e && e[0] == '1') b.splits_ |= TILEORDER_FLAG;
+    }
+    if (BN == 256 && BM == 256 && row_epilogue() && a->geglu && a->N % 256 == 0 && al(a->C, a->ldc) && !a->C2) b.splits_ |= ROWEPI_FLAG;
   }
   hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, b);
   {

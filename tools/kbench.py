@@ -165,6 +165,37 @@ def bench_gemm_rowepi():
     os.environ.pop("ME_GEMM_ROWEPI", None)
 
 
+def bench_gemm_tileorder():
+    """Experiment (round 5): order of the tiles inside an XCD's contiguous run of the 8-phase kernels -- column tiles fastest (default) vs row blocks fastest
+    (ME_GEMM_TILE_ORDER=1: 32 row blocks of one column tile at a time share its weight slabs in L2).  Same process, alternating, bitwise check."""
+    import os
+    B, f = 4, 24
+    cases = []
+    for li, (hw, C) in enumerate([(64, 320), (32, 640), (16, 1280)]):
+        M = B * f * hw * hw
+        cases += [(f"L{li} qkv", M, 3 * C, C, None, False), (f"L{li} ff1 geglu", M, 8 * C, C, None, True), (f"L{li} ff2", M, C, 4 * C, None, False)]
+    cases += [("L2 conv3x3", B * f * 256, 1280, 1280, (16, 16, 16, 16, 1, 0), False), ("L2 conv 2560->1280", B * f * 256, 1280, 2560, (16, 16, 16, 16, 1, 0), False),
+              ("L1->L0 ups conv 640", B * f * 4096, 640, 640, (32, 32, 64, 64, 1, 1), False), ("L2->L1 ups conv 1280", B * f * 1024, 1280, 1280, (16, 16, 32, 32, 1, 1), False),
+              ("L3 ff1 geglu", B * f * 64, 10240, 1280, None, True), ("big 8192 x 8320 K4096", 8192, 8320, 4096, None, False)]
+    print(f"{'gemm':26s} {'M':>8s} {'N':>6s} {'K':>6s} {'cols-fastest ms':>16s} {'rows-fastest ms':>16s} {'x':>6s}  bitwise", flush=True)
+    for name, M, N, K, conv, geglu in cases:
+        taps = 9 if conv else 1
+        rows_in = M if not conv else (M // (conv[2] * conv[3])) * conv[0] * conv[1]
+        x, w = rnd(rows_in, K), rnd(N, taps, K) * (0.05 if K * taps > 2000 else 0.2)
+        kw = dict(M=M, conv=conv, geglu=geglu, bias=rnd(N))
+        res = {"0": [], "1": []}
+        outs = {}
+        for rep in range(2):
+            for o in ("0", "1"):
+                os.environ["ME_GEMM_TILE_ORDER"] = o
+                outs[o] = ops.gemm(x, w, **kw)
+                res[o].append(timeit(lambda: ops.gemm(x, w, **kw)))
+        t0, t1 = min(res["0"]), min(res["1"])
+        print(f"{name:26s} {M:8d} {N:6d} {K*taps:6d} {t0:16.3f} {t1:16.3f} {t0 / t1:6.3f}  {'equal' if torch.equal(outs['0'], outs['1']) else 'DIFFERENT'}  {ops._last_kernel()}", flush=True)
+        del x, w, outs, kw
+    os.environ.pop("ME_GEMM_TILE_ORDER", None)
+
+
 def bench_gemm_cached():
     """Same dense shapes with every X row aliased to row 0 (stride-0 view): X comes from L2, only the output streams.
     The gap to the normal run = what HBM latency / bandwidth on the activation stream costs."""
@@ -423,6 +454,8 @@ if __name__ == "__main__":
         bench_gemm_abl()
     if "rowepi" in what:
         bench_gemm_rowepi()
+    if "tileorder" in what:
+        bench_gemm_tileorder()
     if "gemmc" in what:
         bench_gemm_cached()
     if "attnorder" in what:
