@@ -471,6 +471,26 @@ def main():
     if dist_on:
         from motioneditor_amd import parallel
         comm = parallel.stats_summary(args.steps)
+        if not use_graph and args.steps + args.warmup + i0 + 2 <= len(ts):
+            # which exchanges hold the step's stream, and for how long: TWO more steps, untimed, with an event pair (CUDA) / clock pair (CPU tensors) around
+            # every blocking exchange and every join of an asynchronous one (parallel.TIMING).  Kept out of the timed region (~400 event records per step);
+            # every rank runs them (they contain the same collectives).  Not under --graph: events cannot be timed inside a captured step.
+            parallel.reset_stats()
+            parallel.TIMING = True
+            try:
+                for k in range(2):
+                    lat = run_step(i0 + args.warmup + args.steps + k, lat)
+                sync()
+                dist.barrier()
+                held = parallel.stats_summary(2)
+            finally:
+                parallel.TIMING = False
+            for k, v in held.items():
+                if "stream_held_ms_per_step" in v:
+                    comm.setdefault(k, {})["stream_held_ms_per_step"] = v["stream_held_ms_per_step"]
+            comm["stream_held_note"] = ("stream_held_ms_per_step: time this rank's stream spent inside exchanges of that kind (waiting for the peers + the transfer), from an event pair "
+                                        "around every blocking exchange / join, measured on two extra untimed steps after the timed region; 'join <kind>' = the join of an exchange "
+                                        "posted earlier (what was NOT hidden behind the launches in between)")
     # Roofline pass: the SAME steps once more, eagerly, with a HIP event pair around every launch and on a single stream.
     # It is not folded into the timed region because (a) ~1100 event pairs per step cost ~6 % of the step and (b) the timed
     # region overlaps two streams (ControlNet + adapter beside the UNet),

@@ -24,21 +24,82 @@ import torch.distributed as dist
 
 # data-path exchange accounting (bench.py reports it per step): kind -> [calls, payload bytes this rank sends or contributes]
 STATS = {}
+# How long the CALLER'S stream is held by every exchange (round 5: so that a first real scaling run can be read -- which exchange kinds the step waits for).
+# TIMING on: every blocking exchange and every join of an asynchronous one is bracketed by two events on the current stream (CUDA) or two clock reads
+# (CPU tensors); the interval covers waiting for the peers AND the transfer itself.  kind -> [event pairs] / accumulated seconds.  Off inside a graph
+# capture (events cannot be timed there) and by default (the tests' counters do not need it).
+TIMING = False
+_WAIT_EVENTS = {}
+_WAIT_SECONDS = {}
+_last_kind = "?"
 
 
 def _count(kind: str, t: torch.Tensor, frac: float = 1.0) -> None:
+    global _last_kind
+    _last_kind = kind
     c = STATS.setdefault(kind, [0, 0])
     c[0] += 1
     c[1] += int(t.numel() * t.element_size() * frac)
 
 
+def _set_kind(kind: str) -> None:
+    """Label the next exchange without counting it (a rank that only RECEIVES in an exchange has counted nothing)."""
+    global _last_kind
+    _last_kind = kind
+
+
+class _timed:
+    """with _timed(kind, cuda): ... -- the interval of the caller's stream (or of the host, for CPU tensors) spent inside one exchange."""
+
+    def __init__(self, kind: str, cuda: bool):
+        self.kind, self.cuda = kind, cuda and TIMING and not torch.cuda.is_current_stream_capturing()
+        self.cpu = TIMING and not cuda
+
+    def __enter__(self):
+        if self.cuda:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        elif self.cpu:
+            import time
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cuda:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _WAIT_EVENTS.setdefault(self.kind, []).append((self.e0, e1))
+        elif self.cpu:
+            import time
+            _WAIT_SECONDS[self.kind] = _WAIT_SECONDS.get(self.kind, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
+class _Pending:
+    """An asynchronous exchange in flight: the adapter's own handle plus the kind it was counted under (for the join's timing)."""
+
+    def __init__(self, kind: str, inner, cuda: bool):
+        self.kind, self.inner, self.cuda = kind, inner, cuda
+
+
 def reset_stats() -> None:
     STATS.clear()
+    _WAIT_EVENTS.clear()
+    _WAIT_SECONDS.clear()
 
 
 def stats_summary(steps: int = 1) -> dict:
     out = {k: {"calls_per_step": v[0] / steps, "mbytes_per_step": round(v[1] / steps / 1e6, 3)} for k, v in sorted(STATS.items())}
     out["total"] = {"calls_per_step": sum(v[0] for v in STATS.values()) / steps, "mbytes_per_step": round(sum(v[1] for v in STATS.values()) / steps / 1e6, 3)}
+    if _WAIT_EVENTS or _WAIT_SECONDS:
+        if _WAIT_EVENTS:
+            torch.cuda.synchronize()
+        tot = 0.0
+        for k in set(_WAIT_EVENTS) | set(_WAIT_SECONDS):
+            ms = sum(a.elapsed_time(b) for a, b in _WAIT_EVENTS.get(k, [])) + 1e3 * _WAIT_SECONDS.get(k, 0.0)
+            out.setdefault(k, {})["stream_held_ms_per_step"] = round(ms / steps, 3)
+            tot += ms
+        out["total"]["stream_held_ms_per_step"] = round(tot / steps, 3)
     return out
 
 
@@ -60,27 +121,35 @@ class TorchExchange:
         self._ranks = dist.get_process_group_ranks(group) if group is not None else list(range(self.world))
 
     def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> None:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
+        with _timed(_last_kind, t.is_cuda):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX, group=self.group)
 
     def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor) -> None:
-        dist.all_gather_into_tensor(out, inp, group=self.group)
+        with _timed(_last_kind, out.is_cuda):
+            dist.all_gather_into_tensor(out, inp, group=self.group)
 
     def all_gather_start(self, out: torch.Tensor, inp: torch.Tensor):
-        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)   # in place: inp = this rank's slot of out
+        return _Pending(_last_kind, dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True), out.is_cuda)   # in place: inp = this rank's slot of out
 
     def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
-        dist.all_to_all_single(recv, send, group=self.group)
+        with _timed(_last_kind, recv.is_cuda):
+            dist.all_to_all_single(recv, send, group=self.group)
 
     def p2p_start(self, ops_):
         if not ops_:
             return None
-        return dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._ranks[peer], self.group) for k, t, peer in ops_])
+        return _Pending(_last_kind, dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, self._ranks[peer], self.group) for k, t, peer in ops_]),
+                        ops_[0][1].is_cuda)
 
     def finish(self, handle) -> None:
         if handle is None:
             return
-        for r in (handle if isinstance(handle, (list, tuple)) else [handle]):
-            r.wait()
+        kind, cuda = "?", False
+        if isinstance(handle, _Pending):
+            kind, cuda, handle = handle.kind, handle.cuda, handle.inner
+        with _timed("join " + kind, cuda):
+            for r in (handle if isinstance(handle, (list, tuple)) else [handle]):
+                r.wait()
 
 
 class RcclExchange:
@@ -93,25 +162,29 @@ class RcclExchange:
         self.rank, self.world = self.comm.rank, self.comm.world
 
     def all_reduce_(self, t: torch.Tensor, op: str = "sum") -> None:
-        self.comm.all_reduce_(t, op)
+        with _timed(_last_kind, True):
+            self.comm.all_reduce_(t, op)
 
     def all_gather_into(self, out: torch.Tensor, inp: torch.Tensor) -> None:
-        self.comm.all_gather_into(out, inp)
+        with _timed(_last_kind, True):
+            self.comm.all_gather_into(out, inp)
 
     def all_gather_start(self, out: torch.Tensor, inp: torch.Tensor):
-        return (self.comm.side(lambda: self.comm.all_gather_into(out, inp)), out, inp)     # tensors kept alive until finish()
+        return _Pending(_last_kind, (self.comm.side(lambda: self.comm.all_gather_into(out, inp)), out, inp), True)     # tensors kept alive until finish()
 
     def all_to_all(self, recv: torch.Tensor, send: torch.Tensor) -> None:
-        self.comm.all_to_all_single(recv, send)
+        with _timed(_last_kind, True):
+            self.comm.all_to_all_single(recv, send)
 
     def p2p_start(self, ops_):
         if not ops_:
             return None
-        return (self.comm.side(lambda: self.comm.batch_p2p(ops_)), ops_)
+        return _Pending(_last_kind, (self.comm.side(lambda: self.comm.batch_p2p(ops_)), ops_), True)
 
     def finish(self, handle) -> None:
         if handle is not None:
-            self.comm.join(handle[0])
+            with _timed("join " + handle.kind, True):
+                self.comm.join(handle.inner[0])
 
 
 class HostStagedExchange(TorchExchange):
@@ -280,6 +353,7 @@ class FrameShard:
                 copy_rows(last[b * npix:(b + 1) * npix], x_ext[(b * self.f_loc + self.f_loc - 1) * npix:(b * self.f_loc + self.f_loc) * npix])
             _count("p2p(TemporalConv halo)", last)
             ops_ += [("send", last, self.rank + 1), ("recv", next_blk, self.rank + 1)]
+        _set_kind("p2p(TemporalConv halo)")
         reqs = self.x.p2p_start(ops_)
         hrows = (rows if self.rank > 0 else -1, rows + hb if self.rank < self.world - 1 else -1)
         if defer:      # the caller runs the interior frames (no remote data) while the halos travel, then joins: finish_halos(handle)
@@ -332,6 +406,7 @@ class PrevFrameHalo:
             ops_.append(("recv", ext[:B * npix], self.rank - 1))
         else:
             copy_rows(ext[:B * npix], kv[:B * npix])      # never addressed (frame 0 has no predecessor); keep it finite
+        _set_kind("p2p(attn1 K|V halo)")
         return (s.x.p2p_start(ops_), ext, keep)
 
     def finish_kv(self, handle) -> torch.Tensor:
@@ -418,6 +493,7 @@ class ChunkHalo:
             copy_rows(ext[:hb], kv[:hb])          # never addressed; keep it finite
         if op is None:
             copy_rows(ext[hb:2 * hb], kv[:hb])
+        _set_kind("p2p(adapter K|V halo)")
         return (s.x.p2p_start(ops_), ext, keep)
 
     def finish_kv(self, handle) -> torch.Tensor:
