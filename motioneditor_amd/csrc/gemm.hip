@@ -341,7 +341,10 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
   static_assert(F >= 0 && (F & 1) == 0 && MT % 2 == 0 && WN % 16 == 0, "row-pass epilogue");
   constexpr bool has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
     // a chunk = two 16-row MFMA row blocks = 32 rows x WN columns = 32 * WN / 8 16-byte pieces, IT per lane (5 at WN = 80: no masked piece)
-  constexpr int NCHK = MT / 2, ROWS = 32, CH = WN / 8, PIECES = ROWS * CH, IT = PIECES / 64, PITCH = WN * 2;
+  // scratch row pitch = the 160-byte segment + 16: at 40 dwords the 16 rows of an MFMA-layout ds_write_b64 (bank = dword address mod 32, lanes 0-15 / 16-31 / ...
+  // together) fall on 4 bank groups -- a 4-way conflict, +10 LDS cycles on each of the 40 writes of a wave tile (SQ_LDS_BANK_CONFLICT: a fifth of the LDS cycles);
+  // at 44 dwords rows m and m + 8 still meet (2-way: +2), which is the best a 16-byte-aligned pitch can do, and the ds_read_b128 readback stays aligned
+  constexpr int NCHK = MT / 2, ROWS = 32, CH = WN / 8, PIECES = ROWS * CH, IT = PIECES / 64, PITCH = WN * 2 + 16;
   static_assert(PIECES % 64 == 0, "whole instructions per chunk");
   const f16* __restrict__ rowvec = reinterpret_cast<const f16*>(a.rowvec);
   const f16* res = reinterpret_cast<const f16*>(a.res);    // may alias C (in-place residual): a piece is read and written by the same lane
@@ -358,12 +361,13 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
       o[i][j].h[1] = __builtin_convertvector((f32x2){acc[j][i][2] * a.alpha, acc[j][i][3] * a.alpha}, f16x2);
     }
   // this lane's pieces: piece t of a chunk = 16-byte piece p = 64 t + lane = (row p / CH, columns 8 (p % CH) ...) -- the same in every chunk
-  int prow[IT], pcol[IT];
+  int prow[IT], pcol[IT], poff[IT];
 #pragma unroll
   for (int t = 0; t < IT; ++t) {
     const int p = t * 64 + lane;
     prow[t] = p / CH;
     pcol[t] = nw0 + (p - prow[t] * CH) * 8;
+    poff[t] = prow[t] * PITCH + (p - prow[t] * CH) * 16;      // the piece inside the scratch
   }
   // row maps of the terms without a division per piece: a wave tile spans at most two row vectors / one wrap of a shared residual whenever those
   // periods are at least the tile height (every launch of the model); the general forms stay behind a wave-uniform test
@@ -413,13 +417,13 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
     }
   };
   const int wrow = lane & 15, wq = lane >> 4;
-  auto park = [&](int c, P8 (&d)[IT]) {     // MFMA layout -> this wave's LDS scratch -> row-major 16-byte pieces (piece p = scratch bytes [16 p, 16 p + 16): PITCH = 16 CH)
+  auto park = [&](int c, P8 (&d)[IT]) {     // MFMA layout -> this wave's LDS scratch -> row-major 16-byte pieces
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
       for (int j = 0; j < NT; ++j) *reinterpret_cast<uint2*>(scr + (ii * 16 + wrow) * PITCH + (j * 16 + wq * 4) * 2) = o[c * 2 + ii][j].u;
 #pragma unroll
-    for (int t = 0; t < IT; ++t) d[t].u = *reinterpret_cast<const uint4*>(scr + (t * 64 + lane) * 16);
+    for (int t = 0; t < IT; ++t) d[t].u = *reinterpret_cast<const uint4*>(scr + poff[t]);
   };
   auto add_rv = [&](P8 (&d)[IT]) {          // order of the packed fp16 adds as in epilogue_rows: rowvec, res, res2
 #pragma unroll
@@ -1302,7 +1306,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
     if (a.splits_ & ROWEPI_FLAG) {   // wave-uniform; me_gemm has checked alignments, N % 320 == 0, no activation / GEGLU
       // every wave's DMAs have landed (its own vmcnt(0) above + this barrier): the staging buffers are dead, each wave takes 32 x 160 B of them
       __builtin_amdgcn_s_barrier();
-      char* scr = smem + wave * (32 * WN * 2);
+      char* scr = smem + wave * (32 * (WN * 2 + 16));
       const int mw0 = m0 + wr * GR, nw0 = n0 + wc * WN;
       switch ((a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0)) {
         case 0: return epilogue_rowpass<0, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
