@@ -21,6 +21,9 @@ def test_bench_gpus_2_spawns_two_ranks_and_reports_them():
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "strong"
     assert d["config"]["parallel_mode"] == "cfg"
     assert d["comm"]["total"]["calls_per_step"] == 1      # one all-gather of the noise prediction per step
+    # ... and how long the rank's stream was held by it (two extra untimed steps with an event / clock pair around every exchange, parallel.TIMING)
+    assert d["comm"]["total"]["stream_held_ms_per_step"] > 0 and "stream_held_note" in d["comm"]
+    assert d["comm"]["all_gather(noise prediction, CFG pair)"]["stream_held_ms_per_step"] == d["comm"]["total"]["stream_held_ms_per_step"]
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data"):
         assert k in d
 
