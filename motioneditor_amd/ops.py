@@ -171,7 +171,8 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
         # algorithmic HBM bytes: X once (a gather's taps re-read it from L2), the weights, the output, and every residual term the epilogue reads
         rows_in = (M // (conv[2] * conv[3])) * conv[0] * conv[1] if conv is not None else M
         n_terms = (res is not None) + (res2 is not None)
-        _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (rows_in * K + N * K * taps + M * n_out * (1 + n_terms)), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
+        n_hm = panels.numel() // M if panels is not None else 0      # output columns that leave as head-major panels (counted like any other output byte)
+        _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (rows_in * K + N * K * taps + M * n_out * (1 + n_terms) + M * n_hm), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
             f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
     if panels is not None and n_out == 0:
         return None, panels
