@@ -17,7 +17,7 @@ not product code.  What it does:
   5. (--only-inversion / full run) DDIM inversion: the reference UNet with ``normal_infer=True`` and the reference's
      in-tree ``next_step`` (util.py:77-87) walked over three inversion steps -> inversion.npz.
 
-Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-controlnet]
+Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-single96 | --only-controlnet]
 """
 from __future__ import annotations
 
@@ -351,6 +351,18 @@ def step_golden(tag: str, f: int, h: int, step: int = 4, single_branch: bool = F
         # prediction and updated latents FROM THE REFERENCE's eps (CFG :643-645; DDIM through the oracle's step, itself pinned by the reference's
         # in-tree prev_step vectors) -- step_single.npz is then reference-generated where it matters.
         unet = build_reference_unet(synth.synth_state_dict(synth.unet_schema()))
+        if 2 * f * 8 * (h * h) * (2 * h * h) * 4 > 20e9:
+            # the [prev | cur] score tensor of level 0 in one piece (87 GB at 96 x 96 latents) does not fit the container: run the reference the way inference.py does --
+            # `unet.enable_xformers_memory_efficient_attention()` (inference.py:187), i.e. BasicTransformerBlock.set_use_memory_efficient_attention_xformers
+            # (attention_2d.py:465-491) -- by setting the two flags that method sets (the method itself insists on CUDA); xformers.ops is the exact, chunked stand-in
+            n_on = 0
+            for m in unet.modules():
+                if hasattr(m, "set_use_memory_efficient_attention_xformers") and hasattr(m, "attn1"):
+                    m.attn1._use_memory_efficient_attention_xformers = True
+                    if getattr(m, "attn2", None) is not None:
+                        m.attn2._use_memory_efficient_attention_xformers = True
+                    n_on += 1
+            print(f"reference UNet: xformers path enabled on {n_on} transformer blocks (attention_2d.py:488-490)")
         xin = torch.cat([x["latents"][:1]] * 2)
         emb = torch.cat([x["uncond"][step].expand(1, 77, 768), x["cond"][:1]])
         t1 = time.time()
@@ -459,6 +471,9 @@ def main():
         return
     if "--only-geom96" in sys.argv:
         step_golden("step_geom96", 8, 96)
+        return
+    if "--only-single96" in sys.argv:   # the 96 x 96-latent geometry of BASELINE configs[4] (9216 tokens, 18432 [prev | cur] keys) through the reference UNet itself
+        step_golden("step_single96", 8, 96, single_branch=True)
         return
     if "--only-single" in sys.argv:
         step_golden("step_single", 8, 64, single_branch=True)

@@ -808,6 +808,13 @@ def test_step_single_branch_config2_vs_golden():
     _step_vs_golden("step_single")
 
 
+def test_step_single_branch_96x96_vs_reference_golden():
+    """The 96 x 96-latent geometry of BASELINE configs[4] -- 9216 tokens, 18432 [prev | cur] keys per query, 18 query blocks per (item, head) -- single-branch
+    UNet3D at 8 frames, classifier-free guidance + DDIM, against tests/golden/step_single96.npz: noise prediction and latents from the REFERENCE's own UNet
+    (oracle/make_golden.py --only-single96: the reference model through the chunked xformers stand-in, oracle == reference asserted there)."""
+    _step_vs_golden("step_single96")
+
+
 def test_step_96x96_latents_vs_golden():
     """The spatial geometry of BASELINE configs[4] (768^2 images: 96x96 latents -- 9216 tokens / 18 query blocks of 512 / 72 + 72 (+ 72) stages of
     keys per item at level 0, 48x48 at level 1 (dh = 80, 2304 keys), 24x24, 12x12) on one GPU at 8 frames, two-branch + ControlNet + adapter, both
