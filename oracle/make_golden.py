@@ -17,7 +17,7 @@ not product code.  What it does:
   5. (--only-inversion / full run) DDIM inversion: the reference UNet with ``normal_infer=True`` and the reference's
      in-tree ``next_step`` (util.py:77-87) walked over three inversion steps -> inversion.npz.
 
-Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-single96 | --only-controlnet]
+Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-single96 | --only-two64 | --only-controlnet]
 """
 from __future__ import annotations
 
@@ -397,6 +397,48 @@ def step_golden(tag: str, f: int, h: int, step: int = 4, single_branch: bool = F
     print(f"{tag}.npz written")
 
 
+def two_branch_64_golden(unet, sd, Spatial, reg_spatial, Temporal, reg_temporal):
+    """The two-branch UNet forward with BOTH reference editors ACTIVE at a production token count: batch 4 = [u.rec, u.edit, c.rec, c.edit], 8 frames x 64x64
+    latents (N = 4096 queries; the edit rows attend 5 N = 20480 materialised keys, fully_control.py:381-413), adapter fed with ControlNet-shaped residuals.
+    The reference's own code runs it in the container because every self-attention of a model with registered editors goes through
+    xformers.ops.memory_efficient_attention (control_utils.py / fully_control_utils.py AttentionBase.forward, fully_control.py:418) -- here the exact,
+    chunked stand-in of oracle/shim.  (attn_batch hard-codes num_frames = 8, fully_control.py:377: the shape has 8 frames.)  Asserts oracle == reference and
+    writes tests/golden/unet_two_active_64.npz from the REFERENCE output (every other latent row / column)."""
+    cb = make_case_inputs("two", B=4, f=8, h=64, w=64)
+
+    class Holder:
+        pass
+
+    holder = Holder()
+    holder.unet = unet
+    ted = quiet(Temporal, start_step=4, start_layer=10)
+    quiet(reg_temporal, holder, ted)
+    sed = quiet(Spatial, start_step=4, start_layer=10, source_masks=cb["source_masks"])
+    quiet(reg_spatial, holder, sed)
+    step = 4
+    ted.reset(); sed.reset()
+    ted.cur_step = sed.cur_step = step
+    my_sp, my_tp = ref_cpu.SpatialEditor(cb["source_masks"]), ref_cpu.TemporalEditor()
+    my_sp.cur_step = my_tp.cur_step = step
+    with torch.no_grad():
+        t0 = time.time()
+        ref = quiet(unet, cb["sample"], torch.tensor(cb["t"]), cb["ehs"], down_block_additional_residuals=cb["down_res"],
+                    mid_block_additional_residual=cb["mid_res"]).sample
+        print(f"reference two-branch forward, editors active, 8 f x 64x64 (B = 4): {time.time() - t0:.0f} s")
+        t0 = time.time()
+        taps = {}
+        mine = ref_cpu.unet_forward(sd, cb["sample"], cb["t"], cb["ehs"], cb["down_res"], cb["mid_res"], my_sp, my_tp, taps=taps)
+        print(f"oracle: {time.time() - t0:.0f} s")
+    e = relerr(mine, ref)
+    print("two-branch (active) 64x64 oracle vs reference rel err", e)
+    assert e < 2e-4, e
+    assert (ted.cur_step, ted.cur_att_layer, sed.cur_step, sed.cur_att_layer) == (step + 1, 0, step + 1, 0)
+    np.savez_compressed(GOLD / "unet_two_active_64.npz", out_sub=ref[:, :, :, ::2, ::2].numpy().astype(np.float32), out_stats=stats(ref), step=step,
+                        skip_stats=np.stack([stats(s_) for s_ in taps["skips"]]), motion_stats=np.stack([stats(s_) for s_ in taps["motion"]]),
+                        mid_stats=stats(taps["mid"]), oracle_relerr=e)
+    print("unet_two_active_64.npz written")
+
+
 def controlnet_trunk_golden():
     """R16 (diffusers ControlNetModel, source not in the reference tree): pin the TRUNK against the reference's own blocks.
     conv_in, the time embedding, down_blocks.* and mid_block.* of the ControlNet share the SD-1.5 key schema with the reference's
@@ -513,6 +555,11 @@ def main():
     from motion_editor.attn_control.fully_control_utils import regiter_fully_attention_editor_diffusers
     from motion_editor.attn_control.temporal_control import TemporalSelfAttentionControl
     from motion_editor.attn_control.temporal_control_utils import regiter_temporal_attention_editor_diffusers
+
+    if "--only-two64" in sys.argv:
+        two_branch_64_golden(unet, sd, FullySelfAttentionControlMask, regiter_fully_attention_editor_diffusers, TemporalSelfAttentionControl,
+                             regiter_temporal_attention_editor_diffusers)
+        return
 
     # ---- case A: single branch, no editors (config-2 shape family, small) ----
     ca = make_case_inputs("single", B=2, f=8, h=16, w=16)
