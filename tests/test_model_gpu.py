@@ -114,7 +114,7 @@ def test_unet_two_branch_editors_vs_reference_golden(unet, tag, step):
         assert d[1] > 10 * d[0] and d[3] > 10 * d[2]
 
 
-@pytest.mark.parametrize("hw", [64])
+@pytest.mark.parametrize("hw", [64, 96])
 def test_unet_two_branch_editors_active_64x64_vs_reference_golden(unet, hw):
     """The two-branch UNet with BOTH editors active at a production token count -- batch 4, 8 frames x 64 x 64 latents: 4096 queries, the edit rows against
     20480 materialised keys in the reference (fully_control.py:381-413), [src prev (dual) | src cur (dual) | own cur] segments here -- against
