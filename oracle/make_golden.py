@@ -17,7 +17,7 @@ not product code.  What it does:
   5. (--only-inversion / full run) DDIM inversion: the reference UNet with ``normal_infer=True`` and the reference's
      in-tree ``next_step`` (util.py:77-87) walked over three inversion steps -> inversion.npz.
 
-Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-single96 | --only-two64 | --only-two96 | --only-controlnet]
+Usage:  python oracle/make_golden.py [--skip-two-branch | --only-inversion | --only-null-text | --only-adapter-train | --only-config3 | --only-geom96 | --only-single | --only-single96 | --only-two64 | --only-two96 | --only-two64-f24 | --only-controlnet]
 """
 from __future__ import annotations
 
@@ -397,14 +397,14 @@ def step_golden(tag: str, f: int, h: int, step: int = 4, single_branch: bool = F
     print(f"{tag}.npz written")
 
 
-def two_branch_64_golden(unet, sd, Spatial, reg_spatial, Temporal, reg_temporal, h=64):
+def two_branch_64_golden(unet, sd, Spatial, reg_spatial, Temporal, reg_temporal, h=64, f=8):
     """The two-branch UNet forward with BOTH reference editors ACTIVE at a production token count: batch 4 = [u.rec, u.edit, c.rec, c.edit], 8 frames x 64x64
     latents (N = 4096 queries; the edit rows attend 5 N = 20480 materialised keys, fully_control.py:381-413), adapter fed with ControlNet-shaped residuals.
     The reference's own code runs it in the container because every self-attention of a model with registered editors goes through
     xformers.ops.memory_efficient_attention (control_utils.py / fully_control_utils.py AttentionBase.forward, fully_control.py:418) -- here the exact,
     chunked stand-in of oracle/shim.  (attn_batch hard-codes num_frames = 8, fully_control.py:377: the shape has 8 frames.)  Asserts oracle == reference and
     writes tests/golden/unet_two_active_64.npz from the REFERENCE output (every other latent row / column)."""
-    cb = make_case_inputs("two", B=4, f=8, h=h, w=h)      # (h = 96: the level-0 geometry of BASELINE configs[4], 9216 queries / 46080 materialised keys)
+    cb = make_case_inputs("two", B=4, f=f, h=h, w=h)      # (f = 24, h = 64: the UNet shape of the benchmark itself, BASELINE configs[2]; h = 96: the level-0 geometry of BASELINE configs[4], 9216 queries / 46080 materialised keys)
 
     class Holder:
         pass
@@ -424,7 +424,7 @@ def two_branch_64_golden(unet, sd, Spatial, reg_spatial, Temporal, reg_temporal,
         t0 = time.time()
         ref = quiet(unet, cb["sample"], torch.tensor(cb["t"]), cb["ehs"], down_block_additional_residuals=cb["down_res"],
                     mid_block_additional_residual=cb["mid_res"]).sample
-        print(f"reference two-branch forward, editors active, 8 f x {h}x{h} (B = 4): {time.time() - t0:.0f} s")
+        print(f"reference two-branch forward, editors active, {f} f x {h}x{h} (B = 4): {time.time() - t0:.0f} s")
         t0 = time.time()
         taps = {}
         mine = ref_cpu.unet_forward(sd, cb["sample"], cb["t"], cb["ehs"], cb["down_res"], cb["mid_res"], my_sp, my_tp, taps=taps)
@@ -433,10 +433,11 @@ def two_branch_64_golden(unet, sd, Spatial, reg_spatial, Temporal, reg_temporal,
     print(f"two-branch (active) {h}x{h} oracle vs reference rel err", e)
     assert e < 2e-4, e
     assert (ted.cur_step, ted.cur_att_layer, sed.cur_step, sed.cur_att_layer) == (step + 1, 0, step + 1, 0)
-    np.savez_compressed(GOLD / f"unet_two_active_{h}.npz", out_sub=ref[:, :, :, ::2, ::2].numpy().astype(np.float32), out_stats=stats(ref), step=step, latent=h,
+    tag = f"unet_two_active_{h}" + ("" if f == 8 else f"_f{f}")
+    np.savez_compressed(GOLD / f"{tag}.npz", out_sub=ref[:, :, ::(1 if f == 8 else 2), ::2, ::2].numpy().astype(np.float32), out_stats=stats(ref), step=step, latent=h, frames=f,
                         skip_stats=np.stack([stats(s_) for s_ in taps["skips"]]), motion_stats=np.stack([stats(s_) for s_ in taps["motion"]]),
                         mid_stats=stats(taps["mid"]), oracle_relerr=e)
-    print(f"unet_two_active_{h}.npz written")
+    print(f"{tag}.npz written")
 
 
 def controlnet_trunk_golden():
@@ -556,9 +557,9 @@ def main():
     from motion_editor.attn_control.temporal_control import TemporalSelfAttentionControl
     from motion_editor.attn_control.temporal_control_utils import regiter_temporal_attention_editor_diffusers
 
-    if "--only-two64" in sys.argv or "--only-two96" in sys.argv:
+    if "--only-two64" in sys.argv or "--only-two96" in sys.argv or "--only-two64-f24" in sys.argv:
         two_branch_64_golden(unet, sd, FullySelfAttentionControlMask, regiter_fully_attention_editor_diffusers, TemporalSelfAttentionControl,
-                             regiter_temporal_attention_editor_diffusers, h=96 if "--only-two96" in sys.argv else 64)
+                             regiter_temporal_attention_editor_diffusers, h=96 if "--only-two96" in sys.argv else 64, f=24 if "--only-two64-f24" in sys.argv else 8)
         return
 
     # ---- case A: single branch, no editors (config-2 shape family, small) ----
