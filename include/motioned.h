@@ -32,7 +32,7 @@ extern "C" {
 #define ME_EINVAL (-1) /* bad argument (shape / alignment / unsupported size)          */
 #define ME_EHIP (-2)   /* HIP runtime error at launch                                   */
 
-#define ME_ABI_VERSION 8
+#define ME_ABI_VERSION 9
 
 /* ---- library ------------------------------------------------------------------------------ */
 int me_abi_version(void);
@@ -114,9 +114,33 @@ typedef struct me_gemm_args {
    * absolute).  A frame-sharded TemporalConv (resnet_2d.py:18-26 over a rank's frames) is issued as an interior launch -- frames that need no remote
    * data -- behind the posted halo exchange, and boundary launches after it.  DENSE / TCONV only; such a launch is never split along K. */
   int32_t m_off;
+  /* ABI 9: LayerNorm folded into the projection that consumes it (BasicTransformerBlock, attention_2d.py:493-547: norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q,
+   * norm3 -> ff.net.0.proj, norm_temp -> attn_temp.to_q|k|v; the adapter's norm_temp / ff_norm / norm_self_temp, controlnet_adapter.py:497-534).
+   *   LN(x) W^T + b  =  rstd * (x W'^T - mean * colsum(W')) + (W beta + b),   W' = W diag(gamma)
+   * so the normalised tensor never exists: X holds the UN-normalised rows, W = W' (packed once, fp16), and with ln_stats != NULL every kernel of me_gemm
+   * maps its fp32 accumulators through  rstd[m] * (acc - mean[m] * ln_colsum[n]) + ln_cvec[n]  before its usual epilogue (GEGLU included).
+   * ln_stats: fp32 partial row sums [ln_parts][...][2] = (sum x, sum x^2) of row m over the columns [320 p, 320 p + 320) of X -- the format the epilogue of
+   * the PRODUCING projection writes (ln_out below) or me_ln_stats computes; part p of row m at ln_stats[p * ln_stride + 2 m].  mean = S1 / K,
+   * rstd = rsqrt(max(S2 / K - mean^2, 0) + ln_eps).  ln_colsum / ln_cvec: fp32 [N].  Requires DENSE, bias == NULL (it is inside ln_cvec), no rowvec / res / res2 / act, alpha == 1;
+   * such a launch is never split along K. */
+  const void* ln_stats;
+  const void* ln_colsum;
+  const void* ln_cvec;
+  int64_t ln_stride;  /* floats between consecutive parts of ln_stats (>= 2 * rows of X) */
+  int32_t ln_parts;   /* K / 320 for the model's widths (1, 2, 4); 1 when K is not a multiple of 320 */
+  float ln_eps;
+  /* ... and the producer side: ln_out != NULL asks for the partial row sums (sum y, sum y^2) of THIS launch's fp16 output rows, part p = columns
+   * [320 p, 320 p + 320) at ln_out[p * ln_out_stride + 2 m] -- from the row-contiguous epilogue of the 8-phase kernels where the launch takes them
+   * (fixed order: 8-column pieces, then the wave's 10 pieces, then the 4 waves of a row), from a read-only pass over C behind the launch otherwise.
+   * Requires N % 8 == 0, no GEGLU / C2. */
+  void* ln_out;
+  int64_t ln_out_stride;
 } me_gemm_args;
 
 int me_gemm(const me_gemm_args* a, void* stream);
+/* ABI 9: partial row sums of X [rows, C] (fp16, row stride ldx) in the ln_stats format above: stats[p * stride + 2 m] = (sum, sum of squares) of row m over
+ * columns [320 p, 320 p + 320), p < C / 320 (one part over the whole row when C is not a multiple of 320).  C % 8 == 0, C <= 1536. */
+int me_ln_stats(const void* X, int32_t ldx, int64_t rows, int32_t C, void* stats, int64_t stride, void* stream);
 /* bytes of `work` that me_gemm may use for these arguments (0: the launch is never split) */
 int64_t me_gemm_work_bytes(const me_gemm_args* a);
 
@@ -183,7 +207,7 @@ typedef struct me_attn_args {
   /* ABI 8: head-major Q.  hsq > 0: element (row, head, d) of Q lies at row * ldq + head * hsq + d (the fused q|k|v projection writes all three as
    * per-head [rows, dh] panels, me_gemm_args.c2_col0 = 0); 0: at row * ldq + head * dh + d.  With the heads-slowest block order of the multi-segment
    * launches (each XCD owns one head) a head's 80-byte slices of 640-byte Q rows cost 2.4 x their bytes in cache lines per XCD; panels cost 1 x.
-   * O stays a row tensor (the out-projection reads it as its A operand).  Not served by the general-dual kernel. */
+   * O stays a row tensor (the out-projection reads it as its A operand).  Served by every kernel of me_attn (round 6: the general-dual one too). */
   int64_t hsq;
   /* ABI 8: optional processing order of the query items inside a head's run of the heads-slowest block order: device int32 [n_items], a permutation; the
    * k-th item a head's blocks work on is item_order[k].  NULL: ascending.  Scheduling only -- the output is bitwise the same.  The edited launches pass

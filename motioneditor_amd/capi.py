@@ -12,7 +12,7 @@ from pathlib import Path
 LIB_PATH = Path(__import__("os").environ.get("ME_LIB") or Path(__file__).resolve().parent / "libmotioned.so")   # ME_LIB: an A/B build of the same ABI (tools/)
 
 ME_OK, ME_EINVAL, ME_EHIP = 0, -1, -2
-ABI_VERSION = 8
+ABI_VERSION = 9
 GATHER_DENSE, GATHER_CONV3, GATHER_TCONV = 0, 1, 2
 SEG_PLAIN, SEG_DUAL_CUR, SEG_DUAL_PREV, SEG_DUAL_BIN = 0, 1, 2, 3
 
@@ -31,6 +31,8 @@ class GemmArgs(C.Structure):
         ("res", _vp), ("ldr", _i32), ("res2", _vp), ("ldr2", _i32), ("geglu", _i32), ("act", _i32), ("alpha", _f32), ("res_rows", _i32), ("res2_rows", _i32),
         ("work", _vp), ("work_bytes", _i64), ("splits_", _i32), ("sel_rows", _i32),
         ("C2", _vp), ("c2_col0", _i32), ("c2_dh", _i32), ("c2_hs", _i64), ("m_off", _i32),
+        ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_cvec", _vp), ("ln_stride", _i64), ("ln_parts", _i32), ("ln_eps", _f32),
+        ("ln_out", _vp), ("ln_out_stride", _i64),
     ]
 
 
@@ -126,6 +128,7 @@ SYMBOLS = {
     "me_groupnorm_stats": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "me_groupnorm_apply": (C.c_int, [C.POINTER(GroupNormArgs), _i64, _vp]),
     "me_layernorm": (C.c_int, [C.POINTER(LayerNormArgs), _vp]),
+    "me_ln_stats": (C.c_int, [_vp, _i32, _i64, _i32, _vp, _i64, _vp]),
     "me_softmax_rows": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "me_axpy_rows": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i64, _i32, _f32, _vp]),
     "me_attn_vsum_bytes": (_i64, [_i32, _i32]),

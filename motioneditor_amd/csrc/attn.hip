@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
   // Q fragments (MFMA operand B): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
   f16x8 fq[QT][D32];
   int qrow[QT];
+  const long hq = a.hsq > 0 ? a.hsq : DH;   // head-major Q panels (ABI 8) as in attn2_kernel, or heads as column slices of the rows
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int q = qb * BQ + (wave * QT + qt) * 16 + l15;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const me_attn_args a) {
     for (int ks = 0; ks < D32; ++ks) {
       const int d = ks * 32 + g * 8;
       U128 u;
-      u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * DH + d) : zero128();
+      u.u = (qrow[qt] >= 0 && d < DH) ? ldg128(Q + (long)qrow[qt] * a.ldq + h * hq + d) : zero128();
       fq[qt][ks] = u.h;
     }
   }
@@ -1294,7 +1295,6 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
   if (a->lse && a->vsum) { me_set_error("me_attn: lse is written for plain segments only"); return ME_EINVAL; }
   if (a->hsk < 0 || a->hsv < 0 || a->hsq < 0 || a->hsk % 8 || a->hsv % 8 || a->hsq % 8) { me_set_error("me_attn: head strides must be non-negative multiples of 8"); return ME_EINVAL; }
   if (a->item_order && ((uintptr_t)a->item_order & 3)) { me_set_error("me_attn: misaligned item_order"); return ME_EINVAL; }
-  if (a->hsq > 0 && a->general_dual) { me_set_error("me_attn: head-major Q is not served by the general-dual kernel"); return ME_EINVAL; }
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int rc;
   if (a->general_dual) {   // non-binary masks: the mask-reading kernel

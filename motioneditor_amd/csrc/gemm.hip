@@ -142,6 +142,47 @@ __device__ __forceinline__ void init_acc(const me_gemm_args& a, f32x4 (&acc)[NT]
   }
 }
 
+// ABI 9 -- LayerNorm folded into the projection (me_gemm_args.ln_stats): the accumulators hold x W'^T of the UN-normalised rows; map them through
+//     rstd[m] * (acc - mean[m] * colsum[n]) + cvec[n]
+// before the usual epilogue.  (mean, rstd) come from the partial row sums (sum x, sum x^2) the producing projection's epilogue (or me_ln_stats) left per
+// 320-column part; the fused multiply-adds are spelled out so that every kernel of this file rounds the same way (the tile shape must not show).
+//   mbase / nbase: first row / column of this wave's tile; lane holds rows mbase + 16 i + (lane & 15), columns nbase + 16 j + 4 (lane >> 4) + r.
+template <int NT, int MT>
+__device__ __forceinline__ void ln_fold_acc(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int mbase, int nbase, int lane) {
+  const float* __restrict__ st = reinterpret_cast<const float*>(a.ln_stats);
+  const float* __restrict__ cs = reinterpret_cast<const float*>(a.ln_colsum);
+  const float* __restrict__ cv = reinterpret_cast<const float*>(a.ln_cvec);
+  const float invK = 1.0f / (float)a.K;
+  float nmean[MT], rstd[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = min(mbase + i * 16 + (lane & 15), a.M - 1);   // rows past M: any row that exists (never stored)
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < a.ln_parts; ++p) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(st + (long)p * a.ln_stride + 2 * (long)m);
+      s1 += v[0];
+      s2 += v[1];
+    }
+    const float mu = s1 * invK;
+    const float var = __builtin_fmaf(-mu, mu, s2 * invK);
+    nmean[i] = -mu;
+    rstd[i] = rsqrtf(fmaxf(var, 0.f) + a.ln_eps);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = nbase + j * 16 + (lane >> 4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, c = {0.f, 0.f, 0.f, 0.f};
+    if (n < a.N) {
+      s = *reinterpret_cast<const f32x4*>(cs + n);
+      c = *reinterpret_cast<const f32x4*>(cv + n);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][i][r] = __builtin_fmaf(rstd[i], __builtin_fmaf(nmean[i], s[r], acc[j][i][r]), c[r]);
+  }
+}
+
 // lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
 // sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
@@ -336,8 +377,13 @@ __device__ __forceinline__ void epilogue_rows(const me_gemm_args& a, f32x4 (&acc
 // with packed fp16 adds in that order -- the results are bitwise those of the direct epilogue (test_gemm_8phase_kernel compares the two).
 // vmcnt retires in order: the term loads of chunk c + 1 are issued BEFORE the stores of chunk c.
 //   mw0 / nw0: first output row / column of this wave's MT*16 x WN tile;  scr: 32 * WN * 2 bytes of LDS owned by this wave.
+//   ln_out (ABI 9): the partial row sums (sum y, sum y^2) of the FINAL fp16 rows, for the LayerNorm-folded projection that reads this output next: every 16-byte
+//   piece is summed with v_dot2_f32_f16 (against ones / itself), the wave's CH pieces of a row meet in its scratch, the four waves of a row in `red`
+//   (float2 [2 wave rows][4 wave columns][GR rows], behind a block barrier), and 2 * GR threads store one (sum, sum of squares) pair per row of the
+//   tile -- a fixed order throughout.  lnx = {first row of the tile, wave row, wave column, thread id}.
+struct LnOutCtx { int m0, wr, wc, tid; char* red; };
 template <int F, int NT, int MT, int WN>
-__device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int mw0, int nw0, int lane, char* scr) {
+__device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&acc)[NT][MT], int mw0, int nw0, int lane, char* scr, const LnOutCtx& lnx) {
   static_assert(F >= 0 && (F & 1) == 0 && MT % 2 == 0 && WN % 16 == 0, "row-pass epilogue");
   constexpr bool has_rv = (F & 2) != 0, has_res = (F & 4) != 0, has_res2 = (F & 8) != 0;
     // a chunk = two 16-row MFMA row blocks = 32 rows x WN columns = 32 * WN / 8 16-byte pieces, IT per lane (5 at WN = 80: no masked piece)
@@ -459,6 +505,30 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
       st16(dst, d[t].u);
     }
   };
+  const bool lnout = a.ln_out != nullptr;    // (wave-uniform)
+  static_assert(CH % 2 == 0, "row sums: half the pieces of a row per half wave");
+  f32x2 rsum[NCHK];                           // lanes < 32: (sum, sum of squares) of row 32 c + lane over this wave's WN columns
+  auto row_sums = [&](int c, P8 (&d)[IT]) {
+    const f16x2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s1 = __builtin_amdgcn_fdot2(d[t].h[q], one2, s1, false);
+        s2 = __builtin_amdgcn_fdot2(d[t].h[q], d[t].h[q], s2, false);
+      }
+      const int p = t * 64 + lane;            // piece p = (row p / CH, piece p % CH): the partials of a row are CH consecutive float2
+      *reinterpret_cast<uint2*>(scr + p * 8) = make_uint2(__float_as_uint(s1), __float_as_uint(s2));   // (uint2 like park's stores: one access type per scratch)
+    }
+    f32x2 acc2 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CH / 2; ++k) {
+      const uint2 v = *reinterpret_cast<const uint2*>(scr + ((lane & 31) * CH + (lane >> 5) * (CH / 2) + k) * 8);
+      acc2 += f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+    }
+    rsum[c] = f32x2{xor32_sum(acc2[0]), xor32_sum(acc2[1])};
+  };
   // software pipeline over the chunks: the residual pieces of chunk c + 1 are requested before chunk c is stored
   P8 tv[2][NRV][IT];
   if constexpr (NRES > 0) load_terms(0, tv[0]);
@@ -475,6 +545,26 @@ __device__ __forceinline__ void epilogue_rowpass(const me_gemm_args& a, f32x4 (&
       if (c + 1 < NCHK) load_terms(c + 1, tv[(c + 1) & 1]);
     }
     store(c, d);
+    if (lnout) row_sums(c, d);
+  }
+  if (lnout) {
+    constexpr int GR = MT * 16;
+    uint2* red = reinterpret_cast<uint2*>(lnx.red);
+    if (lane < 32) {
+#pragma unroll
+      for (int c = 0; c < NCHK; ++c) red[(lnx.wr * 4 + lnx.wc) * GR + c * 32 + lane] = make_uint2(__float_as_uint(rsum[c][0]), __float_as_uint(rsum[c][1]));
+    }
+    __syncthreads();
+    if (lnx.tid < 2 * GR) {
+      const int g = lnx.tid / GR, r = lnx.tid - g * GR, m = lnx.m0 + lnx.tid;
+      f32x2 sum = {0.f, 0.f};
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const uint2 v = red[(g * 4 + w4) * GR + r];
+        sum += f32x2{__uint_as_float(v.x), __uint_as_float(v.y)};
+      }
+      if (m < a.M) *reinterpret_cast<f32x2*>(reinterpret_cast<float*>(a.ln_out) + (long)((nw0 - lnx.wc * WN) / 320) * a.ln_out_stride + 2 * (long)m) = sum;
+    }
   }
 }
 
@@ -885,6 +975,7 @@ __global__ __launch_bounds__(BM / WM * 128, WM == 128 ? 1 : 2) void gemm_kernel(
   }
 
   // ---- epilogue ----
+  if (a.ln_stats) ln_fold_acc<NT, MT>(a, acc, m0 + wm * WM, n0 + wn * WN, lane);   // (wave-uniform) LayerNorm folded into this projection
   const int ncols = a.geglu ? BN / 2 : BN;            // output columns of this block
   const int Nout = a.geglu ? a.N / 2 : a.N;
   constexpr bool CFITS = (size_t)BM * (BN + 8) <= (size_t)2 * (BM + BN) * LD;   // the C tile fits the staging buffers
@@ -1053,7 +1144,11 @@ __global__ __launch_bounds__(512, 2) void conv3_halo_kernel(const me_gemm_args a
 // DMA-after-read: a part's slot is re-issued two phases after its last read (A0: read phase 0, issued phase 2; B1: 1 -> 3;
 // A1: 2 -> 0; B0: 3 -> 1).  Tiles past the end are issued as out-of-range offsets (zero fill, no memory traffic) so that the
 // counts stay uniform; everything is drained before the epilogue.
-template <int BM, int BN, bool GATHER>
+// EPI (round 6): the epilogue compiled into this instantiation -- the row-contiguous epilogue with exactly one term set (0 / 2 / 4 / 6 / 12: none, rowvec,
+// res, rowvec + res, res + res2; BN = 256: 0 = the GEGLU row pass) or, EPI = -1, every direct epilogue behind run-time tests.  One kernel with all of them
+// behind a switch carried 530 spilled VGPRs (hipcc hoists the lane-constant address arithmetic of EVERY variant above the K loop, where 160 accumulators
+// and 56 fragment registers leave room for none of it); one variant per instantiation: 0 (22 for res + res2).  Same arithmetic, bitwise the same output.
+template <int BM, int BN, bool GATHER, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   // BM = 256, or 192 for grids whose 256-row tiles would leave the last block round half empty (M = 24576 x N = 1280: 384 tiles = 1.5 rounds of
   // the 256 CUs, 512 tiles of 192 rows = 2): wave tile GR x WN with GR = BM / 2 rows per wave group, A halves of HALF = GR / 2 rows.
@@ -1296,33 +1391,27 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #undef ME_BAR
 #undef ME_LGKM0
 
-  if constexpr (BN == 256 && BM == 256) {
-    if (a.splits_ & ROWEPI_FLAG) {   // GEGLU: one 64 KB LDS tile for the whole block (me_gemm has checked geglu, N % 256 == 0, ldc % 8 == 0, 16-byte aligned C)
-      __builtin_amdgcn_s_barrier();
-      return epilogue_geglu_rowpass<NT, MT, WN>(a, acc, m0, n0, wr, wc, lane, smem);
-    }
+  if constexpr (EPI <= 0) {   // (the LayerNorm-folded projections -- q | k | v, to_q, GEGLU -- have no row-vector / residual terms: me_gemm checks)
+    if (a.ln_stats) ln_fold_acc<NT, MT>(a, acc, m0 + wr * GR, n0 + wc * WN, lane);   // (wave-uniform)
   }
-  if constexpr (BN == 320) {
-    if (a.splits_ & ROWEPI_FLAG) {   // wave-uniform; me_gemm has checked alignments, N % 320 == 0, no activation / GEGLU
-      // every wave's DMAs have landed (its own vmcnt(0) above + this barrier): the staging buffers are dead, each wave takes 32 x 160 B of them
-      __builtin_amdgcn_s_barrier();
-      char* scr = smem + wave * (32 * (WN * 2 + 16));
-      const int mw0 = m0 + wr * GR, nw0 = n0 + wc * WN;
-      switch ((a.rowvec ? 2 : 0) | (a.res ? 4 : 0) | (a.res2 ? 8 : 0)) {
-        case 0: return epilogue_rowpass<0, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
-        case 2: return epilogue_rowpass<2, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
-        case 4: return epilogue_rowpass<4, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
-        case 6: return epilogue_rowpass<6, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
-        case 12: return epilogue_rowpass<12, NT, MT, WN>(a, acc, mw0, nw0, lane, scr);
-        default: break;
-      }
-    }
+
+  if constexpr (EPI >= 0 && BN == 256) {   // GEGLU: one 64 KB LDS tile for the whole block (me_gemm has checked geglu, N % 256 == 0, ldc % 8 == 0, 16-byte aligned C)
+    __builtin_amdgcn_s_barrier();
+    return epilogue_geglu_rowpass<NT, MT, WN>(a, acc, m0, n0, wr, wc, lane, smem);
+  } else if constexpr (EPI >= 0) {         // row-contiguous epilogue; me_gemm has checked alignments, N % 320 == 0, no activation / GEGLU, and the term set is EPI
+    // every wave's DMAs have landed (its own vmcnt(0) above + this barrier): the staging buffers are dead, each wave takes 32 x 160 B of them
+    __builtin_amdgcn_s_barrier();
+    char* scr = smem + wave * (32 * (WN * 2 + 16));
+    const int mw0 = m0 + wr * GR, nw0 = n0 + wc * WN;
+    const LnOutCtx lnx = {m0, wr, wc, tid, smem + 8 * (32 * (WN * 2 + 16))};    // `red` (8 KB) behind the eight scratches
+    return epilogue_rowpass<EPI, NT, MT, WN>(a, acc, mw0, nw0, lane, scr, lnx);
+  } else {
+    auto rowfn = [&](int i) {
+      const int m = m0 + wr * GR + i * 16 + (lane & 15);
+      return m < a.M ? m : -1;
+    };
+    epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wc, lane, nullptr, 0);
   }
-  auto rowfn = [&](int i) {
-    const int m = m0 + wr * GR + i * 16 + (lane & 15);
-    return m < a.M ? m : -1;
-  };
-  epilogue<NT, MT, WN>(a, acc, rowfn, m0, n0, wc, lane, nullptr, 0);
 }
 
 // split-K second pass: C = epilogue(alpha * sum_s work[s] + bias ...) with the epilogue semantics of the one-pass kernels (no activation: round to
@@ -1387,7 +1476,7 @@ int choose_split(const me_gemm_args* a, long blocks, int nit) {
   // N >= 1280 only (the 16 x 16- and 8 x 8-latent levels): a split changes the fp32 summation order, and the level-0 / level-1 launches must give
   // the same rows whatever the batch size -- the UNet graph runs its first blocks on half the batch (classifier-free-guidance prefix) and the
   // step has to stay bitwise the same.  (A 20-tile K loop measured slower split than whole: 32 tiles at least.)
-  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32 || a->C2 || a->m_off) return 1;
+  if (a->geglu || a->K % 64 || a->N < 1280 || blocks >= split_below() || nit < 32 || a->C2 || a->m_off || a->ln_stats) return 1;
   int S = (int)((640 + blocks - 1) / blocks);
   if (S > 4) S = 4;
   if (S > nit / 4) S = nit / 4;
@@ -1449,6 +1538,15 @@ bool row_epilogue() {   // ME_GEMM_ROWEPI=0: the 8-phase kernels keep the direct
   return !(e && e[0] == '0');
 }
 
+bool tile_order_exp() {   // ME_GEMM_TILE_ORDER=1: row blocks fastest inside an XCD's run (an experiment of round 5; read once)
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("ME_GEMM_TILE_ORDER");
+    on = (e && e[0] == '1') ? 1 : 0;
+  }
+  return on == 1;
+}
+
 long min_tiles_192() {   // ME_GEMM_8P_192: smallest grid (in 192 x 320 tiles) that takes the 192-row 8-phase kernel (0 = never)
   const char* e = getenv("ME_GEMM_8P_192");
   const long v = e ? atol(e) : 448;
@@ -1473,6 +1571,9 @@ bool tile160() {
 
 extern "C" void me_set_error(const char* msg);
 extern "C" void me_set_kernel(const char* name);
+extern "C" const char* me_last_kernel(void);
+
+static thread_local bool g_ln_fused = false;   // the launch me_gemm just made writes me_gemm_args.ln_out from its own epilogue (else me_gemm appends me_ln_stats)
 
 template <int BM, int BN, int STAGE, int WM = 64>
 static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
@@ -1521,37 +1622,57 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
   return ME_OK;
 }
 
-template <int BM, int BN, bool GATHER>
-static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
+template <int BM, int BN, bool GATHER, int EPI>
+static int launch_gemm8p_epi(const me_gemm_args& b, hipStream_t st) {
   const int lds = 2 * (BM + BN) * 128 + (GATHER ? 9 * 256 * 4 : 0);
   static bool attr_set_dev[64] = {};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
   bool& attr_set = attr_set_dev[dev_id & 63];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BM, BN, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p_kernel<BM, BN, GATHER, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
       me_set_error("me_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
       return ME_EHIP;
     }
     attr_set = true;
   }
-  const int nbm = (a->M - a->m_off + BM - 1) / BM, nbn = (a->N + BN - 1) / BN;
+  const int nbm = (b.M - b.m_off + BM - 1) / BM, nbn = (b.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER, EPI>), dim3(nbm * nbn), dim3(512), lds, st, b);
+  return ME_OK;
+}
+
+template <int BM, int BN, bool GATHER>
+static int launch_gemm8p(const me_gemm_args* a, hipStream_t st) {
   (void)hipGetLastError();
   me_gemm_args b = *a;
   b.splits_ = 0;
+  int epi = -1;   // the direct epilogues
   {   // row-contiguous epilogue (epilogue_rowpass): 16-byte pieces of every tensor it touches, one of the specialised term sets
     auto al = [](const void* p, int ld) { return p == nullptr || (ld % 8 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0); };
     const int f = (a->rowvec ? 2 : 0) | (a->res ? 4 : 0) | (a->res2 ? 8 : 0);
     if (BN == 320 && row_epilogue() && !a->geglu && a->act == 0 && a->N % 320 == 0 && (f == 0 || f == 2 || f == 4 || f == 6 || f == 12) && al(a->C, a->ldc) &&
         al(a->rowvec, a->ldrv) && al(a->res, a->ldr) && al(a->res2, a->ldr2) && (!a->C2 || f == 0))
-      b.splits_ |= ROWEPI_FLAG;
-    {
-      const char* e = getenv("ME_GEMM_TILE_ORDER");
-      if (e && e[0] == '1') b.splits_ |= TILEORDER_FLAG;
-    }
-    if (BN == 256 && BM == 256 && row_epilogue() && a->geglu && a->N % 256 == 0 && al(a->C, a->ldc) && !a->C2) b.splits_ |= ROWEPI_FLAG;
+      epi = f;
+    if (tile_order_exp()) b.splits_ |= TILEORDER_FLAG;
+    if (BN == 256 && BM == 256 && row_epilogue() && a->geglu && a->N % 256 == 0 && al(a->C, a->ldc) && !a->C2) epi = 0;
+    if (epi >= 0) b.splits_ |= ROWEPI_FLAG;
+    g_ln_fused = BN == 320 && epi >= 0 && a->ln_out != nullptr;
+    if (!g_ln_fused) b.ln_out = nullptr;
   }
-  hipLaunchKernelGGL((gemm8p_kernel<BM, BN, GATHER>), dim3(nbm * nbn), dim3(512), lds, st, b);
+  int rc;
+  if constexpr (BN == 256) {
+    rc = epi == 0 ? launch_gemm8p_epi<BM, BN, GATHER, 0>(b, st) : launch_gemm8p_epi<BM, BN, GATHER, -1>(b, st);
+  } else {
+    switch (epi) {
+      case 0: rc = launch_gemm8p_epi<BM, BN, GATHER, 0>(b, st); break;
+      case 2: rc = launch_gemm8p_epi<BM, BN, GATHER, 2>(b, st); break;
+      case 4: rc = launch_gemm8p_epi<BM, BN, GATHER, 4>(b, st); break;
+      case 6: rc = launch_gemm8p_epi<BM, BN, GATHER, 6>(b, st); break;
+      case 12: rc = launch_gemm8p_epi<BM, BN, GATHER, 12>(b, st); break;
+      default: rc = launch_gemm8p_epi<BM, BN, GATHER, -1>(b, st); break;
+    }
+  }
+  if (rc != ME_OK) return rc;
   {
     char nm[64];
     snprintf(nm, sizeof(nm), "gemm8p_kernel<%d,%d,%s>", BM, BN, GATHER ? "true" : "false");
@@ -1598,8 +1719,35 @@ extern "C" int64_t me_gemm_work_bytes(const me_gemm_args* a) {
   return S > 1 ? (int64_t)4 * a->M * a->N * 4 : 0;
 }
 
+static int gemm_dispatch(const me_gemm_args* a, void* stream);
+
 extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (!a || !a->X || !a->W || !a->C) { me_set_error("me_gemm: null pointer"); return ME_EINVAL; }
+  if (a->ln_stats) {
+    if (a->gather != ME_GATHER_DENSE || a->bias || a->alpha != 1.0f || a->rowvec || a->res || a->res2 || a->act || !a->ln_colsum || !a->ln_cvec || a->ln_parts < 1 || a->ln_parts > 8 || a->ln_stride < 2 * (int64_t)a->M ||
+        (a->ln_stride & 1) || ((uintptr_t)a->ln_stats & 7) || (((uintptr_t)a->ln_colsum | (uintptr_t)a->ln_cvec) & 15) || !(a->ln_eps > 0.f)) {
+      me_set_error("me_gemm: a LayerNorm-folded launch is dense, has no bias (it is inside ln_cvec), no rowvec / residual / activation and alpha == 1; ln_colsum / ln_cvec fp32 [N] 16-byte aligned, "
+                   "ln_stats 8-byte aligned with 1 <= ln_parts <= 8 parts ln_stride >= 2 M floats apart, ln_eps > 0");
+      return ME_EINVAL;
+    }
+  }
+  if (a->ln_out && (a->geglu || a->C2 || a->N % 8 || a->N > 1536 || a->ldc % 8 || ((uintptr_t)a->C & 15) || ((uintptr_t)a->ln_out & 7) || a->ln_out_stride < 2 * (int64_t)a->M || (a->ln_out_stride & 1))) {
+    me_set_error("me_gemm: ln_out needs a plain fp16 output of N % 8 == 0, N <= 1536 columns (no GEGLU, no head-major panels), ldc % 8 == 0, and parts >= 2 M floats apart");
+    return ME_EINVAL;
+  }
+  g_ln_fused = false;
+  const int rc = gemm_dispatch(a, stream);
+  if (rc != ME_OK || !a->ln_out || g_ln_fused) return rc;
+  // the kernel that took the launch has no row sums in its epilogue: a read-only pass over the rows it wrote
+  char nm[96];
+  snprintf(nm, sizeof(nm), "%s", me_last_kernel());
+  const int rc2 = me_ln_stats(reinterpret_cast<const f16*>(a->C) + (long)a->m_off * a->ldc, a->ldc, (int64_t)a->M - a->m_off, a->N,
+                              reinterpret_cast<float*>(a->ln_out) + 2 * (long)a->m_off, a->ln_out_stride, stream);
+  me_set_kernel(nm);
+  return rc2;
+}
+
+static int gemm_dispatch(const me_gemm_args* a, void* stream) {
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) { me_set_error("me_gemm: non-positive dimension"); return ME_EINVAL; }
   if (a->K % 8 || a->ldx % 8 || a->ldc % 4 || a->N % 4) { me_set_error("me_gemm: K, ldx must be multiples of 8 and N, ldc of 4"); return ME_EINVAL; }
   if (((uintptr_t)a->X | (uintptr_t)a->W) & 15 || ((uintptr_t)a->C & 7)) { me_set_error("me_gemm: misaligned pointer"); return ME_EINVAL; }

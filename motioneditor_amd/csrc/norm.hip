@@ -305,6 +305,85 @@ __global__ __launch_bounds__(256) void layernorm320_kernel(const f16* __restrict
   }
 }
 
+
+// ---- partial row sums for the LayerNorm-folded projections (ABI 9, me_gemm_args.ln_stats) ----
+// stats[p * stride + 2 m] = (sum, sum of squares) of row m over the columns [320 p, 320 p + 320) -- the format the row-contiguous GEMM epilogue writes for
+// the rows it produces (gemm.hip, ln_out); this kernel serves the rows that come from anywhere else (small grids, exchanged rows).  One wave per row.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_stats_kernel(const f16* __restrict__ X, float* __restrict__ stats, long rows, int C, int ldx, long stride, int parts) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int tpr = C / 8;
+  const f16x2 one2 = {(f16)1.f, (f16)1.f};
+  float s1[NV], s2[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = lane + 64 * k;
+    U128 u;
+    u.u = vc < tpr ? ldg128(X + row * ldx + vc * 8) : zero128();
+    s1[k] = s2[k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f16x2 h = {u.e[2 * q], u.e[2 * q + 1]};
+      s1[k] = __builtin_amdgcn_fdot2(h, one2, s1[k], false);
+      s2[k] = __builtin_amdgcn_fdot2(h, h, s2[k], false);
+    }
+  }
+  for (int p = 0; p < parts; ++p) {    // a 320-column part = 40 vectors
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int vc = lane + 64 * k;
+      const bool mine = parts == 1 || vc / 40 == p;
+      a1 += mine ? s1[k] : 0.f;
+      a2 += mine ? s2[k] : 0.f;
+    }
+    a1 = wave_sum(a1);
+    a2 = wave_sum(a2);
+    if (lane == 0) *reinterpret_cast<f32x2*>(stats + (long)p * stride + 2 * row) = f32x2{a1, a2};
+  }
+}
+
+// C = 320: half a wave per row as in layernorm320_kernel (lane l of the half: columns [8 l, 8 l + 8) and [256 + 2 l, 256 + 2 l + 2)), U row pairs per trip
+__global__ __launch_bounds__(256) void ln_stats320_kernel(const f16* __restrict__ X, float* __restrict__ stats, long rows, int ldx) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63, l32 = lane & 31, half = lane >> 5;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+  const f16x2 one2 = {(f16)1.f, (f16)1.f};
+  auto half_sum = [](float v) {   // over the 32 lanes of this half
+    v = xor16_sum(v);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (long r0 = wave * 2 * U; r0 < rows; r0 += nwaves * 2 * U) {
+    U128 a[U];
+    f16x2 c[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const long row = r0 + 2 * k + half;
+      const bool ok = row < rows;
+      a[k].u = ok ? ldg128(X + row * ldx + 8 * l32) : zero128();
+      c[k] = ok ? *reinterpret_cast<const f16x2*>(X + row * ldx + 256 + 2 * l32) : f16x2{(f16)0.f, (f16)0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      float s1 = __builtin_amdgcn_fdot2(c[k], one2, 0.f, false), s2 = __builtin_amdgcn_fdot2(c[k], c[k], 0.f, false);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f16x2 h = {a[k].e[2 * q], a[k].e[2 * q + 1]};
+        s1 = __builtin_amdgcn_fdot2(h, one2, s1, false);
+        s2 = __builtin_amdgcn_fdot2(h, h, s2, false);
+      }
+      s1 = half_sum(s1);
+      s2 = half_sum(s2);
+      const long row = r0 + 2 * k + half;
+      if (l32 == 0 && row < rows) *reinterpret_cast<f32x2*>(stats + 2 * row) = f32x2{s1, s2};
+    }
+  }
+}
+
 // Row softmax, one wave per row, the row held in registers (cols <= 8192 -> <= 16 vectors of 8 per lane).
 template <int NV>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* X, f16* Y, long rows, int cols, int ldx, int ldy) {
@@ -352,6 +431,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const f16* X, f16* Y,
 }  // namespace
 
 extern "C" void me_set_error(const char* msg);
+extern "C" void me_set_kernel(const char* name);
 
 static int gn_validate(const me_groupnorm_args* a) {
   if (!a || !a->X || !a->Y || !a->gamma || !a->beta || !a->stats) { me_set_error("me_groupnorm: null pointer"); return ME_EINVAL; }
@@ -452,6 +532,31 @@ extern "C" int me_layernorm(const me_layernorm_args* a, void* stream) {
   else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   else hipLaunchKernelGGL(layernorm_kernel<3>, dim3(blocks), dim3(256), 0, st, X, Y, gm, bt, (long)a->rows, a->C, a->ldx, a->ldy, a->eps);
   if (hipGetLastError() != hipSuccess) { me_set_error("me_layernorm: kernel launch failed"); return ME_EHIP; }
+  return ME_OK;
+}
+
+
+extern "C" int me_ln_stats(const void* X, int32_t ldx, int64_t rows, int32_t C, void* stats, int64_t stride, void* stream) {
+  if (!X || !stats) { me_set_error("me_ln_stats: null pointer"); return ME_EINVAL; }
+  if (rows <= 0 || C <= 0 || C % 8 || C > 1536 || ldx % 8 || ((uintptr_t)X & 15) || ((uintptr_t)stats & 7) || (stride & 1) || (C % 320 == 0 && C > 320 && stride < 2 * rows)) {
+    me_set_error("me_ln_stats: C must be a multiple of 8 and <= 1536, X 16-byte aligned with ldx % 8 == 0, stats 8-byte aligned, parts >= 2 * rows floats apart");
+    return ME_EINVAL;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const f16* x = reinterpret_cast<const f16*>(X);
+  float* s = reinterpret_cast<float*>(stats);
+  const int parts = C % 320 == 0 ? C / 320 : 1;
+  const unsigned blocks = (unsigned)((rows + 3) / 4);
+  const int nv = (C / 8 + 63) / 64;
+  (void)hipGetLastError();
+  if (C == 320 && rows >= 4096) {
+    const unsigned nb = (unsigned)min((long)((rows + 31) / 32), 256L * 24);   // 32 rows per block and trip
+    hipLaunchKernelGGL(ln_stats320_kernel, dim3(nb), dim3(256), 0, st, x, s, (long)rows, ldx);
+  } else if (nv == 1) hipLaunchKernelGGL(ln_stats_kernel<1>, dim3(blocks), dim3(256), 0, st, x, s, (long)rows, C, ldx, (long)stride, parts);
+  else if (nv == 2) hipLaunchKernelGGL(ln_stats_kernel<2>, dim3(blocks), dim3(256), 0, st, x, s, (long)rows, C, ldx, (long)stride, parts);
+  else hipLaunchKernelGGL(ln_stats_kernel<3>, dim3(blocks), dim3(256), 0, st, x, s, (long)rows, C, ldx, (long)stride, parts);
+  me_set_kernel("ln_stats");
+  if (hipGetLastError() != hipSuccess) { me_set_error("me_ln_stats: kernel launch failed"); return ME_EHIP; }
   return ME_OK;
 }
 

@@ -24,6 +24,7 @@ HEAD_MAJOR_Q = __import__("os").environ.get("ME_HEAD_MAJOR_Q", "1") != "0"     #
 HEAD_MAJOR_KV = __import__("os").environ.get("ME_HEAD_MAJOR_KV", "1") != "0"   # attn1: K and V leave the fused q|k|v projection as per-head [rows, dh] panels (me_gemm_args.C2 / me_attn_args.hsk); A/B switch
 SPLIT_SHARDED_TCONV = __import__("os").environ.get("ME_SPLIT_TCONV", "1") != "0"   # frame-sharded TemporalConv: interior frames behind the posted halo exchange, boundary frames after it
 INPLACE_SKIPS = __import__("os").environ.get("ME_INPLACE_SKIPS", "1") != "0"   # the down path writes its skips straight into the up path's concat buffers (unet_forward); A/B switch
+LN_FOLD = __import__("os").environ.get("ME_LN_FOLD", "1") != "0"   # LayerNorm folded into the projection that consumes it (me_gemm_args.ln_stats, ABI 9); A/B switch
 COND_EMBED_CACHE = True   # ControlNet conditioning embedding of an unchanged skeleton tensor is computed once per run (controlnet_forward)
 
 
@@ -148,18 +149,59 @@ def resnet_block(P: Packed, p: str, x: Act, temb: torch.Tensor, temb_off: int, *
     return x.like(h)
 
 
-def feed_forward(P: Packed, p: str, n: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
-    """diffusers FeedForward(geglu) + residual: GEGLU fused into the first GEMM's epilogue."""
-    g = ops.gemm(n, P.geglu_mat(p + ".net.0.proj.weight"), bias=P.geglu_vec(p + ".net.0.proj.bias"), geglu=True)
-    return ops.gemm(g, P.mat(p + ".net.2.weight"), bias=P.vec(p + ".net.2.bias"), res=res)
+def _fold() -> bool:
+    """LayerNorms are folded into their projections (no normalised tensor, no LayerNorm launch): not under the autodiff tape (its backward rules differentiate
+    the LayerNorm launch) and only on backends that implement it."""
+    return LN_FOLD and not getattr(ops, "recording", False) and getattr(ops, "LN_FOLD", False)
+
+
+def _gemm_st(*args, **kw):
+    """ops.gemm that also hands back the partial row sums of its output rows -- (out, stats) -- for the LayerNorm-folded projection that reads them next
+    (stats = None when LayerNorms are not folded)."""
+    if _fold():
+        return ops.gemm(*args, ln_out=True, **kw)
+    return ops.gemm(*args, **kw), None
+
+
+class LN:
+    """LayerNorm `norm` of the rows x, not yet applied (nn.LayerNorm in front of attn1 / attn2.to_q / ff / attn_temp, attention_2d.py:493-547): a projection
+    takes it folded -- gemm(names): x W'^T mapped through rstd (acc - mean colsum) + cvec, W' = W diag(gamma) -- or, where the normalised rows themselves are
+    needed (autodiff tape, the frame<->pixel exchange), as a launch of its own -- rows().  stats: the partial row sums the producer of x left (ops.gemm ln_out)."""
+
+    def __init__(self, P: Packed, norm: str, x: torch.Tensor, stats: Optional[torch.Tensor] = None):
+        self.P, self.norm, self.x, self.stats, self._rows = P, norm, x, stats, None
+
+    def rows(self) -> torch.Tensor:
+        if self._rows is None:
+            self._rows = ops.layernorm(self.x, self.P.vec(self.norm + ".weight"), self.P.vec(self.norm + ".bias"))
+        return self._rows
+
+    def gemm(self, names: Sequence[str], *, geglu_bias: Optional[str] = None, **kw):
+        names = list(names)
+        geglu = geglu_bias is not None
+        if _fold() and self._rows is None:
+            if self.stats is None:
+                self.stats = ops.ln_stats(self.x)
+            w, cs, cv = self.P.ln_fold(self.norm, names, geglu=geglu, bias=geglu_bias)
+            return ops.gemm(self.x, w, ln=(self.stats, cs, cv, 1e-5), geglu=geglu, **kw)
+        if geglu:
+            return ops.gemm(self.rows(), self.P.geglu_mat(names[0]), bias=self.P.geglu_vec(geglu_bias), geglu=True, **kw)
+        return ops.gemm(self.rows(), self.P.fused(names) if len(names) > 1 else self.P.mat(names[0]), **kw)
+
+
+def feed_forward(P: Packed, p: str, n: "LN", res: torch.Tensor, want_stats: bool = False):
+    """diffusers FeedForward(geglu) + residual: GEGLU fused into the first GEMM's epilogue, norm3 / ff_norm folded into it.  Returns (rows, their partial row
+    sums or None)."""
+    g = n.gemm([p + ".net.0.proj.weight"], geglu_bias=p + ".net.0.proj.bias")
+    return (_gemm_st if want_stats else (lambda *a, **k: (ops.gemm(*a, **k), None)))(g, P.mat(p + ".net.2.weight"), bias=P.vec(p + ".net.2.bias"), res=res)
 
 
 def _ln(P: Packed, p: str, x: torch.Tensor) -> torch.Tensor:
     return ops.layernorm(x, P.vec(p + ".weight"), P.vec(p + ".bias"))
 
 
-def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int = 0, head_major: bool = False):
-    """q, k, v row views of the self-attention projections of `n`.  Unsharded: one fused [rows, 3C] GEMM.  Frame-sharded:
+def _qkv(P: Packed, p: str, n: "LN", C: int, shard, B: int = 0, N: int = 0, head_major: bool = False):
+    """q, k, v row views of the self-attention projections of the LayerNorm `n` (folded into them).  Unsharded: one fused [rows, 3C] GEMM.  Frame-sharded:
     q stays local, k|v is projected into a contiguous [rows, 2C] tensor and completed by the shard view (all-gather over
     the frame shards, or the previous rank's last frame only for spatial attn1)."""
     names = [p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]
@@ -168,21 +210,21 @@ def _qkv(P: Packed, p: str, n: torch.Tensor, C: int, shard, B: int = 0, N: int =
             # K and V leave the projection as one contiguous [rows, dh] panel per head (me_gemm's second output): what the attention kernel's
             # K/V tile fill wants (2.5 x fewer cache lines than dh-wide slices of 3C-wide rows); Q stays a row tensor
             if HEAD_MAJOR_Q:   # (round 5) Q as panels too: with the heads-slowest block order each XCD reads ONE head's queries -- 80-byte slices of 640-byte rows
-                _, qkv = ops.gemm(n, P.fused(names), head_major=(0, C // HEADS))   # cost 2.4 x their bytes in cache lines per XCD, panels 1 x
+                _, qkv = n.gemm(names, head_major=(0, C // HEADS))   # cost 2.4 x their bytes in cache lines per XCD, panels 1 x
                 return qkv[:HEADS], qkv[HEADS:2 * HEADS], qkv[2 * HEADS:]
-            q, kv = ops.gemm(n, P.fused(names), head_major=(C, C // HEADS))
+            q, kv = n.gemm(names, head_major=(C, C // HEADS))
             return q, kv[:HEADS], kv[HEADS:]
-        qkv = ops.gemm(n, P.fused(names))
+        qkv = n.gemm(names)
         return qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-    ext, loc = shard.kv_buffer(n.shape[0], 2 * C, B, N, n)     # the K|V GEMM writes straight into its slot of the exchanged tensor
-    ops.gemm(n, P.fused(names[1:]), out=loc)
+    ext, loc = shard.kv_buffer(n.x.shape[0], 2 * C, B, N, n.x)     # the K|V GEMM writes straight into its slot of the exchanged tensor
+    n.gemm(names[1:], out=loc)
     pending = shard.start_kv(ext, B, N, ops.copy_rows)          # the exchange (RCCL stream) runs under the query projection
-    q = ops.gemm(n, P.mat(names[0]))
+    q = n.gemm(names[:1])
     kv = shard.finish_kv(pending)
     return q, kv[:, :C], kv[:, C:]
 
 
-def _temporal_attn(P: Packed, p: str, n: torch.Tensor, C: int, B: int, f: int, N: int, dh: int, shard, editor=None, place: str = "") -> torch.Tensor:
+def _temporal_attn(P: Packed, p: str, n: "LN", C: int, B: int, f: int, N: int, dh: int, shard, editor=None, place: str = "") -> torch.Tensor:
     """Causal attention over frames of the projections of `n` (the normed stream, rows (b, local frame, pixel)); returns the
     attention output in the same row order.  Frame-sharded: the rows of `n` go through the frame<->pixel all-to-all BEFORE
     the q|k|v projection (a row-wise GEMM commutes with the row exchange, so C columns travel instead of 3C), every rank
@@ -191,7 +233,7 @@ def _temporal_attn(P: Packed, p: str, n: torch.Tensor, C: int, B: int, f: int, N
     def go(tc):
         return editor(call=tc, is_cross=False, place_in_unet=place, num_heads=HEADS) if editor is not None else tc.run()
     if shard is not None and shard.pixel_sharded(N):
-        r = shard.to_pixel_shards(n, B * f, N, ops.copy_blocks)
+        r = shard.to_pixel_shards(n.rows(), B * f, N, ops.copy_blocks)     # (the NORMALISED rows travel: the exchange needs a tensor of its own anyway)
         qkv = ops.gemm(r, P.fused([p + ".to_q.weight", p + ".to_k.weight", p + ".to_v.weight"]))
         a = go(TemporalCall(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], B, shard.f_total, N // shard.world, dh, None, shard.world))
         return shard.to_frame_shards(a, B * f, N, ops.copy_blocks)
@@ -235,17 +277,19 @@ def _ext_rows(x: "Act", shard) -> int:
 
 
 def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_seg, *, spatial, temporal, place: str,
-                sc_attn: bool, has_temp: bool, shard=None, text_kv: Optional[torch.Tensor] = None, expand: int = 1) -> Act:
+                sc_attn: bool, has_temp: bool, shard=None, text_kv: Optional[torch.Tensor] = None, expand: int = 1, stats: Optional[torch.Tensor] = None) -> Act:
     """BasicTransformerBlock.forward (attention_2d.py:493-547) on rows [(B f N), C].
     expand > 1 (unet_forward's CFG prefix): x holds B / expand distinct batch entries -- entry b + k B / expand of the full batch would be a
     bit-for-bit copy of entry b up to the text cross-attention -- so attn1 runs once per distinct entry, attn2 reads the shared queries
-    (q_items) against every entry's own text keys, and its output projection adds the shared residual (res_rows): from there on the batch is full."""
+    (q_items) against every entry's own text keys, and its output projection adds the shared residual (res_rows): from there on the batch is full.
+    Round 6: the four LayerNorms are folded into the projections behind them (class LN); `stats` / `st` = the partial row sums of the stream, which every
+    projection that writes the stream leaves behind for the next fold (ops.gemm ln_out) -- no LayerNorm launch, no normalised tensor."""
     t, C = x.t, x.C
     dh = C // HEADS
     # --- attn1 (MotionFrameAttention / patched closure, attention_2d.py:705-768, fully_control_utils.py:113-161)
     # plain per-frame self-attention (ControlNet, normal_infer) needs no other frames; [prev | cur] needs ONE halo frame
     sh1 = shard.prev_frame_view() if (shard is not None and sc_attn) else None
-    q, k, v = _qkv(P, p + ".attn1", _ln(P, p + ".norm1", t), C, sh1, x.B, x.N, head_major=True)
+    q, k, v = _qkv(P, p + ".attn1", LN(P, p + ".norm1", t, stats), C, sh1, x.B, x.N, head_major=True)
     call = AttnCall(q, k, v, x.B, x.f, x.N, dh, x.N, False, sh1)
     if spatial is not None:
         a = spatial(call=call, is_cross=False, place_in_unet=place, num_heads=HEADS)
@@ -253,12 +297,12 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
         a = call.run(*segments.prev_cur(x.B, x.f, t.device, sh1))
     else:
         a = call.run(*segments.self_items(x.B * x.f, t.device))
-    t = ops.gemm(a, P.mat(p + ".attn1.to_out.0.weight"), bias=P.vec(p + ".attn1.to_out.0.bias"), res=t)
+    t, st = _gemm_st(a, P.mat(p + ".attn1.to_out.0.weight"), bias=P.vec(p + ".attn1.to_out.0.bias"), res=t)
     # --- attn2 (CrossAttention, attention_2d.py:115-201): K/V projected once per text row
     if expand > 1 and text is None:
         raise ValueError("basic_block: expand needs the text cross-attention (that is where the batch entries start to differ)")
     if text is not None:
-        q = ops.gemm(_ln(P, p + ".norm2", t), P.mat(p + ".attn2.to_q.weight"))
+        q = LN(P, p + ".norm2", t, st).gemm([p + ".attn2.to_q.weight"])
         # k | v of the text rows: this block's column slice of the one GEMM that projects the text for every layer (text_kv_all), or its own
         kv = text_kv if text_kv is not None else ops.gemm(text, P.fused([p + ".attn2.to_k.weight", p + ".attn2.to_v.weight"]))
         call = AttnCall(q, kv[:, :C], kv[:, C:], x.B * expand, x.f, x.N, dh, 77, True, None, x.B * x.f if expand > 1 else 0)
@@ -266,14 +310,14 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
             a = spatial(call=call, is_cross=True, place_in_unet=place, num_heads=HEADS, text_seg=text_seg)
         else:
             a = call.run(*text_seg)
-        t = ops.gemm(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t, **({"res_rows": t.shape[0]} if expand > 1 else {}))
+        t, st = _gemm_st(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t, **({"res_rows": t.shape[0]} if expand > 1 else {}))
         if expand > 1:
             x = Act(t, x.B * expand, x.f, x.h, x.w)
     # --- feed-forward (attention_2d.py:531)
-    t = feed_forward(P, p + ".ff", _ln(P, p + ".norm3", t), t)
+    t, st = feed_forward(P, p + ".ff", LN(P, p + ".norm3", t, st), t, want_stats=has_temp)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
     if has_temp:
-        a = _temporal_attn(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, x.B, x.f, x.N, dh, shard, temporal, place)
+        a = _temporal_attn(P, p + ".attn_temp", LN(P, p + ".norm_temp", t, st), C, x.B, x.f, x.N, dh, shard, temporal, place)
         t = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     return x.like(t)
 
@@ -283,9 +327,9 @@ def transformer2d(P: Packed, p: str, x: Act, text, text_seg, *, spatial=None, te
     """Transformer2DModel.forward (attention_2d.py:338-389): per-frame GroupNorm(32, eps 1e-6), 1x1 proj in/out.
     out: where the block's result is written (a column slice of the next skip-concat buffer)."""
     n = ops.groupnorm(x.t, P.vec(p + ".norm.weight"), P.vec(p + ".norm.bias"), rows_per_group=x.N, eps=1e-6, silu=False)
-    t = ops.gemm(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
+    t, st = _gemm_st(n, P.mat(p + ".proj_in.weight"), bias=P.vec(p + ".proj_in.bias"))
     t = basic_block(P, p + ".transformer_blocks.0", x.like(t), text, text_seg, spatial=spatial, temporal=temporal, place=place,
-                    sc_attn=sc_attn, has_temp=has_temp, shard=shard, text_kv=None if text_kv is None else text_kv[p], expand=expand).t
+                    sc_attn=sc_attn, has_temp=has_temp, shard=shard, text_kv=None if text_kv is None else text_kv[p], expand=expand, stats=st).t
     y = ops.gemm(t, P.mat(p + ".proj_out.weight"), bias=P.vec(p + ".proj_out.bias"), res=x.t, **({} if out is None else {"out": out}),
                  **({"res_rows": x.t.shape[0]} if expand > 1 else {}))
     return Act(y, x.B * expand, x.f, x.h, x.w)
@@ -371,7 +415,7 @@ def adapter_block(P: Packed, p: str, x: Act, src, nb: Optional[int] = None, shar
     hc = ops.gemm(hc, P.mat(p + ".block2.weight"), bias=P.vec(p + ".block2.bias"), res=t)
     # sparse-causal self attention inside chunks of 8 frames
     sh2 = shard.chunk_view(ADAPTER_CHUNK) if (shard is not None and shard.adapter == "halo") else shard   # two halo frames, not the all-gather
-    q_, k_, v_ = _qkv(P, p + ".attn_temp", _ln(P, p + ".norm_temp", t), C, sh2, x.B, x.N)
+    q_, k_, v_ = _qkv(P, p + ".attn_temp", LN(P, p + ".norm_temp", t), C, sh2, x.B, x.N)
     a = AttnCall(q_, k_, v_, x.B, x.f, x.N, dh, x.N, False, sh2).run(*segments.first_prev_chunked(x.B, x.f, ADAPTER_CHUNK, dev, sh2))
     a = ops.gemm(a, P.mat(p + ".attn_temp.to_out.0.weight"), bias=P.vec(p + ".attn_temp.to_out.0.bias"), res=t)
     a = _ln(P, p + ".cross_pose_norm", a)  # the normed tensor replaces the stream (controlnet_adapter.py:518)
@@ -388,10 +432,10 @@ def adapter_block(P: Packed, p: str, x: Act, src, nb: Optional[int] = None, shar
     seg = segments.self_items(nb * x.f, dev)
     ap = ops.attention(q, kv[:, :C], kv[:, C:], heads=HEADS, dh=dh, n_items=nb * x.f, nq=x.N, nk=x.N, seg_item=seg[0], seg_mode=seg[1],
                        **({"q_items": x.B * x.f} if share else {}))
-    a = ops.gemm(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a, **({"res_rows": rows_x} if share else {}))
-    a = feed_forward(P, p + ".ff", _ln(P, p + ".ff_norm", a), a)
+    a, st = _gemm_st(ap, P.mat(p + ".attn_pose.to_out.0.weight"), bias=P.vec(p + ".attn_pose.to_out.0.bias"), res=a, **({"res_rows": rows_x} if share else {}))
+    a, st = feed_forward(P, p + ".ff", LN(P, p + ".ff_norm", a, st), a, want_stats=True)
     # causal temporal attention over the TRUE frame count
-    at = _temporal_attn(P, p + ".attn_self_temp", _ln(P, p + ".norm_self_temp", a), C, nb, x.f, x.N, dh, shard)
+    at = _temporal_attn(P, p + ".attn_self_temp", LN(P, p + ".norm_self_temp", a, st), C, nb, x.f, x.N, dh, shard)
     return ops.gemm(at, P.mat(p + ".attn_self_temp.to_out.0.weight"), bias=P.vec(p + ".attn_self_temp.to_out.0.bias"), res=a, res2=hc,
                     **({"res2_rows": rows_x} if share else {}))
 

@@ -73,6 +73,7 @@ def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
 
 
 ROW_RANGE = True       # this backend implements gemm(row_range=...) (me_gemm_args.m_off)
+LN_FOLD = True         # ... and gemm(ln=..., ln_out=...) / ln_stats (ABI 9: LayerNorm folded into the projection that consumes it)
 HEAD_MAJOR_KV = True   # this backend implements gemm(head_major=...) / 3-D k, v in attention (the CPU emulation and the autodiff recorder do not)
 
 
@@ -81,7 +82,7 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
          res: Optional[torch.Tensor] = None, res2: Optional[torch.Tensor] = None, geglu: bool = False, act: int = 0, alpha: float = 1.0,
          conv: Optional[Tuple[int, int, int, int, int, int]] = None,
          tconv: Optional[Tuple[int, ...]] = None, res_rows: int = 0, res2_rows: int = 0, head_major: Optional[Tuple[int, int]] = None,
-         row_range: Optional[Tuple[int, int]] = None):
+         row_range: Optional[Tuple[int, int]] = None, ln: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor, float]] = None, ln_out: bool = False):
     """out[m, n] = epilogue(sum_{tap,c} x[src(m,tap), c] * w[n, tap, c]).
 
     w: fp16 [N, taps, K] (taps = 1 dense, 9 for ``conv=(Hin, Win, Hout, Wout, stride, ups)``,
@@ -89,7 +90,10 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     row_range = (lo, hi): only the output rows [lo, hi) of the M-row problem are computed (into `out`, which must be given and hold all M rows): the
     interior / boundary launches of a frame-sharded TemporalConv (me_gemm_args.m_off).
     head_major = (col0, dh): the output columns from col0 on leave as a second tensor [(N - col0) / dh, M, dh] -- one contiguous [rows, dh]
-    panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels); col0 = 0: every column does, the call returns (None, panels)."""
+    panel per head (me_gemm_args.C2) -- and the call returns (out[:, :col0], panels); col0 = 0: every column does, the call returns (None, panels).
+    ln = (stats, colsum, cvec, eps): x holds UN-normalised rows and w = W diag(gamma) (weights.Packed.ln_fold): the LayerNorm in front of this projection
+    is applied to the accumulators, rstd (acc - mean colsum) + cvec, from the partial row sums `stats` fp32 [parts, rows, 2] (ln_stats(), or ln_out of the
+    projection that produced x).  ln_out: the call also returns the partial row sums of ITS output rows, (out, stats)."""
     _chk2d(x, "gemm.x")
     if w.dtype != F16 or not w.is_contiguous() or w.dim() != 3:
         raise ValueError("gemm.w: expected contiguous fp16 [N, taps, K]")
@@ -156,6 +160,19 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
     a.act = act
     a.alpha = alpha
     a.res_rows, a.res2_rows = res_rows, res2_rows
+    if ln is not None:
+        st_, cs_, cv_, eps_ = ln
+        if st_.dtype != torch.float32 or st_.dim() != 3 or st_.shape[2] != 2 or st_.stride(2) != 1 or st_.stride(1) != 2 or st_.shape[1] < M \
+                or cs_.dtype != torch.float32 or cv_.dtype != torch.float32 or cs_.numel() != N or cv_.numel() != N or not cs_.is_contiguous() or not cv_.is_contiguous():
+            raise ValueError("gemm: ln = (fp32 stats [parts, rows, 2], fp32 colsum [N], fp32 cvec [N], eps)")
+        a.ln_stats, a.ln_colsum, a.ln_cvec, a.ln_eps = st_.data_ptr(), cs_.data_ptr(), cv_.data_ptr(), eps_
+        a.ln_parts, a.ln_stride = st_.shape[0], st_.stride(0)
+    so = None
+    if ln_out:
+        if panels is not None or geglu:
+            raise ValueError("gemm: ln_out is for plain row outputs")
+        so = torch.empty((n_out // 320 if n_out % 320 == 0 else 1, M, 2), dtype=torch.float32, device=x.device)
+        a.ln_out, a.ln_out_stride = so.data_ptr(), so.stride(0)
     if SELECT_ROWS_SCALE > 1:
         a.sel_rows = M * SELECT_ROWS_SCALE
     for r_, n_ in ((res, res_rows), (res2, res2_rows)):
@@ -173,11 +190,25 @@ def gemm(x: torch.Tensor, w: torch.Tensor, *, M: Optional[int] = None, out: Opti
         n_terms = (res is not None) + (res2 is not None)
         n_hm = panels.numel() // M if panels is not None else 0      # output columns that leave as head-major panels (counted like any other output byte)
         _pe(e0, "gemm", 2.0 * M * N * K * taps, 2.0 * (rows_in * K + N * K * taps + M * n_out * (1 + n_terms) + M * n_hm), f"M{M} N{N} K{K} taps{taps}{' geglu' if geglu else ''}{' +b' if bias is not None else ''}{' +rv' if rowvec is not None else ''}"
-            f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}", _last_kernel())
+            f"{' +res' if res is not None else ''}{' +res2' if res2 is not None else ''}{' act' + str(act) if act else ''}{' a' + str(alpha) if alpha != 1.0 else ''}{' ln' if ln is not None else ''}{' lnout' if ln_out else ''}", _last_kernel())
     if panels is not None and n_out == 0:
         return None, panels
     out = out[:M, :n_out] if (out.shape[0] != M or out.shape[1] != n_out) else out
+    if so is not None:
+        return out, so
     return out if panels is None else (out, panels)
+
+
+def ln_stats(x: torch.Tensor) -> torch.Tensor:
+    """Partial row sums (sum, sum of squares) of x over its 320-column parts, fp32 [parts, rows, 2]: what gemm(ln=...) derives a row's mean / rstd from
+    when the producer of x could not leave them behind (me_ln_stats)."""
+    _chk2d(x, "ln_stats.x")
+    rows, Cc = x.shape
+    st = torch.empty((Cc // 320 if Cc % 320 == 0 else 1, rows, 2), dtype=torch.float32, device=x.device)
+    e0 = _pb()
+    capi.check(capi.lib().me_ln_stats(x.data_ptr(), x.stride(0), rows, Cc, st.data_ptr(), st.stride(0), _stream()), "me_ln_stats")
+    _pe(e0, "layernorm", 3.0 * rows * Cc, 2.0 * rows * Cc, "stats", "ln_stats")
+    return st
 
 
 def gemm_splits_k(M: int, N: int, K: int, taps: int = 1) -> bool:

@@ -132,6 +132,33 @@ class Packed:
     def geglu_vec(self, name: str) -> torch.Tensor:
         return self._get("gegluv:" + name)
 
+    def ln_fold(self, norm: str, names: Iterable[str], geglu: bool = False, bias: Optional[str] = None):
+        """LayerNorm `norm` folded into the projection(s) `names` that consume it (me_gemm_args.ln_stats, ABI 9):
+            LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (W beta + b),   W' = W diag(gamma).
+        Returns (W' in the packed layout and dtype of the projection, colsum(W') fp32 [N] -- taken over the ROUNDED W', so that the identity holds
+        exactly for the numbers the kernel multiplies --, W beta + b fp32 [N]).  geglu: the value / gate interleaved packing of ff.net.0.proj."""
+        names = list(names)
+        key = ("lnwg:" if geglu else "lnw:") + "|".join([norm + ".weight", norm + ".bias", *names, *([bias] if bias else [])])
+        hit = self.cache.get(key)
+        if hit is None:
+            gamma, beta = self.raw(norm + ".weight").reshape(-1), self.raw(norm + ".bias").reshape(-1)
+            if geglu:
+                w = self.packed_f32("geglu:" + names[0])
+                b = self.packed_f32("gegluv:" + bias) if bias else None
+            else:
+                w = torch.cat([self._as_taps(self.raw(n)) for n in names], dim=0)
+                b = self.raw(bias).reshape(-1) if bias else None
+            if w.shape[1] != 1:
+                raise ValueError("ln_fold: dense projections only")
+            wq = (w * gamma[None, None, :]).to(self.dtype).contiguous()
+            colsum = wq.float().sum(dim=(1, 2))
+            cvec = w[:, 0, :] @ beta
+            if b is not None:
+                cvec = cvec + b
+            hit = (wq.to(self.device), colsum.contiguous().to(self.device), cvec.float().contiguous().to(self.device))
+            self.cache[key] = hit   # type: ignore[assignment]
+        return hit
+
     def is_zero(self, *names: str) -> bool:
         """True when every named tensor is exactly zero (the reference zero-initialises TemporalConv
         and never trains it, resnet_2d.py:15-16: its branch can be skipped for real checkpoints)."""

@@ -32,12 +32,31 @@ def empty(rows, cols, like):
     return torch.empty((rows, cols), dtype=like.dtype, device=like.device)
 
 
+LN_FOLD = True   # this backend implements gemm(ln=..., ln_out=...) / ln_stats (ABI 9)
+
+
+def _row_parts(y):
+    """[P, rows, 2] fp32 partial row sums (sum, sum of squares) over 320-column parts: the me_gemm_args.ln_stats format."""
+    rows, C = y.shape
+    P = C // 320 if C % 320 == 0 else 1
+    yf = y.float().reshape(rows, P, C // P)
+    return torch.stack([yf.sum(-1), (yf * yf).sum(-1)], dim=-1).permute(1, 0, 2).contiguous()
+
+
+def ln_stats(x):
+    return _row_parts(x)
+
+
 def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=None, res2=None, geglu=False, act=0, alpha=1.0,
-         conv=None, tconv=None, res_rows=0, res2_rows=0, row_range=None):
+         conv=None, tconv=None, res_rows=0, res2_rows=0, row_range=None, ln=None, ln_out=False):
+    if ln_out:
+        y = gemm(x, w, M=M, out=out, bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res=res, res2=res2, geglu=geglu, act=act, alpha=alpha, conv=conv, tconv=tconv,
+                 res_rows=res_rows, res2_rows=res2_rows, row_range=row_range, ln=ln)
+        return y, _row_parts(y)
     if row_range is not None:   # rows [lo, hi) of the full launch, written into `out`
         lo, hi = row_range
         full = gemm(x, w, M=M, bias=bias, rowvec=rowvec, rows_per_vec=rows_per_vec, res=res, res2=res2, geglu=geglu, act=act, alpha=alpha, conv=conv, tconv=tconv,
-                    res_rows=res_rows, res2_rows=res2_rows)
+                    res_rows=res_rows, res2_rows=res2_rows, ln=ln)
         out[lo:hi, :full.shape[1]] = full[lo:hi]
         return out[:full.shape[0], :full.shape[1]]
     N, taps, K = w.shape
@@ -91,6 +110,13 @@ def gemm(x, w, *, M=None, out=None, bias=None, rowvec=None, rows_per_vec=0, res=
     if M is None:
         M = acc.shape[0]
     acc = acc[:M] * alpha
+    if ln is not None:   # LayerNorm folded into the projection: rstd (acc - mean colsum) + cvec from the partial row sums (me_gemm_args.ln_stats)
+        st, colsum, cvec, eps = ln
+        assert conv is None and tconv is None and bias is None and alpha == 1.0 and rowvec is None and res is None and res2 is None and act == 0
+        S = st.float().sum(dim=0)[:M]
+        mean = S[:, 0] / K
+        rstd = torch.rsqrt((S[:, 1] / K - mean * mean).clamp_min(0) + eps)
+        acc = rstd[:, None] * (acc - mean[:, None] * colsum.float()[None]) + cvec.float()[None]
     if geglu:
         if bias is not None:
             acc = acc + bias.float()

@@ -20,7 +20,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(str(capi.LIB_PATH))
     for name in declared:
         getattr(L, name)
-    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 8
+    assert capi.lib().me_abi_version() == capi.ABI_VERSION == 9
 
 
 def test_argument_validation_returns_einval_without_a_device():

@@ -18,7 +18,7 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
+def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, bench_inputs=False):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -31,7 +31,8 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
     from motioneditor_amd.models.unet_2d_condition import UNet2DConditionModel
     from motioneditor_amd.pipelines import MotionEditorPipeline
     from test_step_cpu import step_inputs
-    x = step_inputs(f=f, h=8, w=8)
+    # bench_inputs: bench.py's own inputs (synth.bench_inputs) -- what tests/golden/step_config3.npz was generated on
+    x = synth.bench_inputs(f, hw, hw) if bench_inputs else step_inputs(f=f, h=hw, w=hw)
     unet = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cuda")
     cn = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
     pipe = MotionEditorPipeline(unet=unet, controlnet=cn)
@@ -44,7 +45,8 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
     t = pipe.scheduler.timesteps[step]
     H = x["skeleton"].shape[-1]
     images = x["skeleton"].reshape(f, 3, H, H).cuda()
-    emb = torch.cat([x["uncond"].expand(2, 77, 768), x["cond"]]).cuda()
+    unc = x["uncond"][step] if bench_inputs else x["uncond"]      # (bench_inputs holds one unconditional embedding per step: null-text inversion)
+    emb = torch.cat([unc.expand(2, 77, 768), x["cond"]]).cuda()
     lat = x["latents"].cuda()
     cfg_x = shard_group = None
     if hybrid:   # rank = shard * 2 + cfg half (bench.py's layout): CFG pairs {0,1},{2,3}; frame-shard groups {0,2},{1,3}
@@ -68,8 +70,9 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
     assert st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
     if shard.world > 1:
         assert st.get("p2p(TemporalConv halo)", {"calls_per_step": 0})["calls_per_step"] > 0, st
-        if temporal == "a2a":
-            assert st["all_to_all(temporal in)"]["calls_per_step"] == st["all_to_all(temporal out)"]["calls_per_step"] == 24, st
+        if temporal == "a2a":   # 8 / 8 / 8 / 4 temporal attentions at the four levels (16 UNet blocks + 12 adapter blocks); a level whose pixel count the ranks do not divide all-gathers
+            want_a2a = sum(n for n, lv in ((8, 0), (8, 1), (8, 2), (4, 3)) if ((hw >> lv) ** 2) % shard.world == 0)
+            assert st["all_to_all(temporal in)"]["calls_per_step"] == st["all_to_all(temporal out)"]["calls_per_step"] == want_a2a, st
     parts = [torch.empty(got.shape, dtype=got.dtype) for _ in range(world)]
     dist.all_gather(parts, got.cpu())
     if hybrid:
@@ -81,18 +84,18 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter):
         ted.cur_step = sed.cur_step = step
         want = pipe.denoise_step(lat, t, emb, torch.cat([images] * 2), 7.5).cpu()
         err = float((full.double() - want.double()).norm() / want.double().norm())
-        torch.save({"err": err, "stats": st}, out_path)
+        torch.save({"err": err, "stats": st, "latents": full if bench_inputs else None}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(tmp_path, world, f, hybrid=False, temporal="a2a", adapter="halo"):
+def _run(tmp_path, world, f, hybrid=False, temporal="a2a", adapter="halo", hw=8, bench_inputs=False):
     from motioneditor_amd import synth
     synth.synth_state_dict(synth.unet_schema())                               # fill the per-machine weight cache once: the ranks map it instead of
     synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")     # generating 1.7 G parameters each
     out = tmp_path / "r.pt"
-    port = 29100 + (os.getpid() % 2000) + world * 7 + f + (3 if hybrid else 0)
-    mp.spawn(_worker, args=(world, port, f, str(out), hybrid, temporal, adapter), nprocs=world, join=True)
+    port = 29100 + (os.getpid() % 2000) + world * 7 + f + (3 if hybrid else 0) + hw
+    mp.spawn(_worker, args=(world, port, f, str(out), hybrid, temporal, adapter, hw, bench_inputs), nprocs=world, join=True)
     return torch.load(out)
 
 
@@ -121,4 +124,36 @@ def test_four_frame_shards_on_one_gpu_the_layout_of_baseline_configs3(tmp_path):
     r = _run(tmp_path, 4, 24)
     from test_model_gpu import record
     record("frame_shard_four_ranks_one_gpu_config3_layout", r["err"])
+    assert r["err"] < 2e-3, r
+
+
+def test_four_frame_shards_at_configs3_size(tmp_path):
+    """BASELINE configs[3] AS WRITTEN, at its own size: 24 frames x 512^2 (64 x 64 latents), batch 4, two-branch + ControlNet + adapter + both editors,
+    the frames sharded 6 per rank over 4 ranks (here: 4 processes sharing the one GPU, exchanges staged through the host) -- the gathered latents against
+    tests/golden/step_config3.npz (the oracle's step at this very workload, oracle/make_golden.py --only-config3) at the step tolerance, and against
+    the plain step on the same GPU.  Level-0 launches of a rank are 6 frames x 4096 pixels x batch 4 = 98304 rows: the real tile shapes, the 4-part
+    frame<->pixel all-to-all at 1024 pixels per part, one-frame K | V halos of 4096 keys."""
+    import numpy as np
+    from conftest import GOLD
+    from test_model_gpu import STEP_TOL, record
+    from conftest import rel_l2
+    r = _run(tmp_path, 4, 24, hw=64, bench_inputs=True)
+    g = np.load(GOLD / "step_config3.npz")
+    assert int(g["frames"]) == 24 and int(g["latent"]) == 64
+    sp_lat = int(g["lat_stride"]) if "lat_stride" in g.files else 2
+    e = rel_l2(r["latents"][:, :, :, ::sp_lat, ::sp_lat], torch.from_numpy(g["latents_sub"]))
+    record("frame_shard_four_ranks_configs3_size_vs_plain", r["err"])
+    record("frame_shard_four_ranks_configs3_size_vs_golden", e)
+    assert r["err"] < 2e-3, r["err"]
+    assert e <= STEP_TOL, e
+
+
+def test_eight_frame_shards_the_layout_of_baseline_configs4(tmp_path):
+    """BASELINE configs[4]'s layout -- 48 frames sharded 6 per rank over 8 ranks (8 processes on the one GPU) -- at 32 x 32 latents: the world-8 frame<->pixel
+    all-to-all (128 pixels per part at level 0, 2 at level 3), the adapter's chunk halos on all 7 rank boundaries (ranges start at frames 6, 12, ..., 42 of
+    chunks that start at 0, 8, ..., 40), TemporalConv halos on both sides of the six middle ranks, GroupNorm statistics summed over 8 ranks -- against the plain
+    step on the same GPU (the 48-frame count against the oracle: test_denoise_step_baseline_config0_and_48_frames_vs_cpu_oracle)."""
+    from test_model_gpu import record
+    r = _run(tmp_path, 8, 48, hw=32)
+    record("frame_shard_eight_ranks_one_gpu_configs4_layout", r["err"])
     assert r["err"] < 2e-3, r

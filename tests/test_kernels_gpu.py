@@ -1161,10 +1161,78 @@ def test_attention_head_major_kv_equals_row_major(ops, dh, N, kind):
     kv = qkv[:, C:].reshape(n_items * N, 16, dh).permute(1, 0, 2).contiguous()
     got = ops.attention(qkv[:, :C], kv[:8], kv[8:], **args)
     assert torch.equal(got, want)
-    # ... and with Q as panels too (ABI 8, me_attn_args.hsq); the general-dual kernel does not serve it
+    # ... and with Q as panels too (ABI 8, me_attn_args.hsq) -- the general-dual (mask-reading) kernel included (round 6: the default graph hands it
+    # head-major Q whenever the source masks are not binary)
     qp = qkv[:, :C].reshape(n_items * N, 8, dh).permute(1, 0, 2).contiguous()
-    if kind == "ed_gen":
-        with pytest.raises(Exception):
-            ops.attention(qp, kv[:8], kv[8:], **args)
+    assert torch.equal(ops.attention(qp, kv[:8], kv[8:], **args), want)
+
+
+# ------------------------------------------------------------------ LayerNorm folded into the projection (ABI 9)
+def _ln_fold_pack(w, gamma, beta, bias=None):
+    """weights.Packed.ln_fold on raw tensors: W' = W diag(gamma) rounded to fp16, colsum over the ROUNDED W', W beta + b."""
+    wq = (w.float() * gamma.float()[None, None, :]).half()
+    cs = wq.float().sum(dim=(1, 2))
+    cv = w.float()[:, 0, :] @ beta.float()
+    if bias is not None:
+        cv = cv + bias.float()
+    return wq, cs, cv
+
+
+@pytest.mark.parametrize("M,C,N,kind", [(256 * 520, 320, 960, "hm"), (256 * 520, 320, 320, "plain"), (256 * 514 + 77, 320, 2560, "geglu"), (256 * 260, 640, 1920, "hm"),
+                                        (192 * 130 + 5, 1280, 3840, "plain"), (6144, 1280, 3840, "plain"), (1000, 1280, 10240, "geglu"), (300, 320, 960, "plain"),
+                                        (1536, 640, 640, "plain")])
+def test_gemm_layernorm_fold(ops, M, C, N, kind):
+    """LN(x) W^T (+ b, GEGLU) computed as rstd (x W'^T - mean colsum) + cvec from partial row sums (me_gemm_args.ln_stats) against LayerNorm-then-GEMM in fp32:
+    the 8-phase kernels (row-contiguous F = 0 epilogue with and without head-major panels, the GEGLU row pass), the 192-row tiles, the 128-row kernels; rows
+    with a large common offset (mean / std ~ 8); ragged last tiles."""
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, C, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 4.0 * torch.randn(M, 1, generator=g)).half()
+    gamma, beta = (1.0 + 0.2 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
+    w = rnd(N, 1, C, seed=2, scale=C ** -0.5)
+    bias = rnd(N, seed=3, scale=0.1) if kind == "geglu" else None
+    wq, cs, cv = _ln_fold_pack(w, gamma, beta, bias)
+    n = emu.layernorm(x.float(), gamma, beta)
+    want = emu.gemm(n, w.float(), bias=None if bias is None else bias.float(), geglu=kind == "geglu")
+    st = ops.ln_stats(cu(x))
+    P = C // 320
+    assert st.shape == (P, M, 2)
+    xf = x.float().reshape(M, P, 320)
+    check(st[:, :, 0].t(), xf.sum(-1), "ln_stats sum", rel=1e-5, mx=1e-3)
+    check(st[:, :, 1].t(), (xf * xf).sum(-1), "ln_stats sumsq", rel=1e-5, mx=1e-3)
+    ln = (st, cu(cs), cu(cv), 1e-5)
+    if kind == "hm":
+        _, panels = ops.gemm(cu(x), cu(wq), ln=ln, head_major=(0, C // 8))
+        got = panels.permute(1, 0, 2).reshape(M, N)
     else:
-        assert torch.equal(ops.attention(qp, kv[:8], kv[8:], **args), want)
+        got = ops.gemm(cu(x), cu(wq), ln=ln, geglu=kind == "geglu")
+    check(got, want, f"ln-folded gemm {M}x{N}x{C} {kind}")
+    # the emulation of the same call (what the CPU graph tests run) agrees too
+    check(emu.gemm(x.float(), wq.float(), ln=(emu.ln_stats(x), cs, cv, 1e-5), geglu=kind == "geglu"), want, "emulated fold", rel=1e-3)
+    with pytest.raises(Exception):
+        ops.gemm(cu(x), cu(wq), ln=ln, bias=cu(rnd(N, seed=9)))
+
+
+@pytest.mark.parametrize("M,N,K,terms", [(256 * 520, 320, 320, "res"), (256 * 520 + 31, 320, 1280, "bias+res"), (256 * 260, 640, 640, "bias"), (192 * 130, 1280, 1280, "bias+res"),
+                                         (256 * 520, 320, 64, "res+res2"), (6144, 1280, 1280, "bias+res"), (300, 320, 320, "res")])
+def test_gemm_row_sums_of_the_output_for_the_next_layernorm_fold(ops, M, N, K, terms, monkeypatch):
+    """ops.gemm(ln_out=True): the partial row sums (sum y, sum y^2) per 320-column part of the rows a projection WRITES -- from the row-contiguous epilogue of the
+    8-phase kernels (256- and 192-row tiles, every term set), from me_ln_stats behind the launch otherwise -- equal the sums of the fp16 output it stored; the
+    output itself is bitwise what the launch writes without ln_out; and the two producers of the statistics agree to fp32 rounding."""
+    x, w = rnd(M, K, seed=1), rnd(N, 1, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3) if "bias" in terms else None
+    res = rnd(M, N, seed=5) if "res" in terms else None
+    res2 = rnd(M, N, seed=6) if "res2" in terms else None
+    kw = dict(bias=cu(bias), res=cu(res), res2=cu(res2))
+    plain = ops.gemm(cu(x), cu(w), **kw)
+    y, st = ops.gemm(cu(x), cu(w), ln_out=True, **kw)
+    assert torch.equal(y, plain)
+    P = N // 320
+    assert st.shape == (P, M, 2)
+    yf = y.float().reshape(M, P, 320)
+    check(st[:, :, 0].t(), yf.sum(-1), "row sums", rel=1e-5, mx=1e-3)
+    check(st[:, :, 1].t(), (yf * yf).sum(-1), "row sums of squares", rel=1e-5, mx=1e-3)
+    monkeypatch.setenv("ME_GEMM_ROWEPI", "0")     # the direct epilogue has no row sums: me_gemm appends the read-only pass
+    y2, st2 = ops.gemm(cu(x), cu(w), ln_out=True, **kw)
+    assert torch.equal(y2, plain)
+    check(st2, st, "fused vs appended statistics", rel=2e-5, mx=1e-3)
+    assert torch.equal(ops.ln_stats(y), st2)
