@@ -601,7 +601,17 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction), not this run"
                 else:
                     traffic_src = "profiles/pmc_traffic.json does not cover this run's dominant kernels (kernel set changed since it was collected): not reported"
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(fl / tsec / 1e12, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+            PEAK_HBM_GBS = 8000.0                      # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec; a copy kernel measures ~6.3)
+            ridge = PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)    # flop per algorithmic HBM byte at which the two roofs meet (312)
+
+            def roofs(fl_, by_, sec_):
+                """which roof bounds a kernel, from its ALGORITHMIC intensity (launch-weighted over its launches), and the fraction of each roof it reaches"""
+                inten = fl_ / by_ if by_ else float("inf")
+                return {"intensity_flop_per_byte": round(inten, 1) if by_ else None, "bound": "mfma" if inten >= ridge else "hbm",
+                        "frac_mfma": round(fl_ / sec_ / 1e12 / PEAK_MFMA_TFLOPS, 4) if sec_ else 0, "frac_hbm": round(by_ / sec_ / 1e9 / PEAK_HBM_GBS, 4) if sec_ else 0}
+            rf = roofs(fl, by, tsec)
+            out["roofline"] = {"kernel": dom, "bound": rf["bound"], "intensity_flop_per_byte": rf["intensity_flop_per_byte"], "ridge_flop_per_byte": round(ridge, 1),
+                               "frac_hbm": rf["frac_hbm"], "achieved": round(fl / tsec / 1e12, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(fl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4), "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                                "achieved_executed": round(xfl / tsec / 1e12, 1), "frac_executed": round(xfl / tsec / 1e12 / PEAK_MFMA_TFLOPS, 4),
                                "flops_counted": "achieved = reference-semantics FLOPs of the launches (SURVEY 8d: a binary dual segment counts its 2 nk materialised keys); "
@@ -610,11 +620,14 @@ def main():
                                "share_of_gpu_time": round(tsec / tot, 3),
                                "measured_in": "event-instrumented single-stream eager pass of the same steps inside this run, right after the timed region "
                                               "(the timed region is un-instrumented and overlaps two streams)"}
-            out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
-                                  "tflops_executed": round(v[4] / v[0] / 1e12, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps}
+            # per kernel / family: BOTH roofs (round-5 verdict: the K <= 640 GEMM launches sit between them, GroupNorm / LayerNorm / temporal attention are HBM kernels)
+            out["kernels"] = {k: dict({"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
+                                       "tflops_executed": round(v[4] / v[0] / 1e12, 1) if v[0] else 0, "gbs": round(v[2] / v[0] / 1e9, 1) if v[0] else 0,
+                                       "launches_per_step": v[3] // args.steps}, **roofs(v[1], v[2], v[0]))
                               for k, v in sorted(kern.items(), key=lambda kv: -kv[1][0])[:8]}
-            out["kernel_families"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
-                                          "gbs": round(v[2] / v[0] / 1e9, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps} for k, v in sorted(fam.items())}
+            out["kernel_families"] = {k: dict({"ms_per_step": round(v[0] / args.steps * 1e3, 2), "tflops": round(v[1] / v[0] / 1e12, 1) if v[0] else 0,
+                                               "gbs": round(v[2] / v[0] / 1e9, 1) if v[0] else 0, "launches_per_step": v[3] // args.steps}, **roofs(v[1], v[2], v[0]))
+                                      for k, v in sorted(fam.items())}
         if world == 1 and not args.no_cpu_baseline and args.cpu_baseline != "off" and not args.emulate and not (args.single_branch or args.inversion):
             cdt, cores, cf, ch, cw = cpu_baseline(usd, csd)
             ctf, _ = step_tflop(cf, ch, cw)

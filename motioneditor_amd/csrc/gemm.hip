@@ -183,6 +183,42 @@ __device__ __forceinline__ void ln_fold_acc(const me_gemm_args& a, f32x4 (&acc)[
   }
 }
 
+// The same map with its operands read from LDS: the 8-phase kernels (one block per CU -- nothing hides a global load's latency in their epilogue: the
+// global form cost 1.4 us per 256-row tile, +2.5 ms per step on each of the two LayerNorm-folded kernel families) fetch the tile's partial row sums, column sums
+// and constants by LDS-DMA together with the first K tile (gemm8p_kernel, LN_LDS).  Image: [parts <= 4][BM rows][2 floats] at 2 KB per part | colsum [BN] at
+// + 8 KB | cvec [BN] at + 10 KB.  Same values, same operation order as ln_fold_acc: bitwise the same result.
+constexpr int LN_LDS_BYTES = 12288, LN_LDS_COLSUM = 8192, LN_LDS_CVEC = 10240;
+template <int NT, int MT>
+__device__ __forceinline__ void ln_fold_acc_lds(const me_gemm_args& a, f32x4 (&acc)[NT][MT], const char* img, int rloc, int cloc, int lane) {
+  const float invK = 1.0f / (float)a.K;
+  float nmean[MT], rstd[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = rloc + i * 16 + (lane & 15);
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < a.ln_parts; ++p) {
+      const uint2 v = *reinterpret_cast<const uint2*>(img + p * 2048 + row * 8);
+      s1 += __uint_as_float(v.x);
+      s2 += __uint_as_float(v.y);
+    }
+    const float mu = s1 * invK;
+    const float var = __builtin_fmaf(-mu, mu, s2 * invK);
+    nmean[i] = -mu;
+    rstd[i] = rsqrtf(fmaxf(var, 0.f) + a.ln_eps);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = cloc + j * 16 + (lane >> 4) * 4;
+    const uint4 su = *reinterpret_cast<const uint4*>(img + LN_LDS_COLSUM + col * 4), cu = *reinterpret_cast<const uint4*>(img + LN_LDS_CVEC + col * 4);
+    const f32x4 s = {__uint_as_float(su.x), __uint_as_float(su.y), __uint_as_float(su.z), __uint_as_float(su.w)};
+    const f32x4 c = {__uint_as_float(cu.x), __uint_as_float(cu.y), __uint_as_float(cu.z), __uint_as_float(cu.w)};
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][i][r] = __builtin_fmaf(rstd[i], __builtin_fmaf(nmean[i], s[r], acc[j][i][r]), c[r]);
+  }
+}
+
 // lane holds D[n = (lane>>4)*4 + r][m = lane & 15] of each 16x16 tile acc[j][i].
 // sC != nullptr: instead of 8-byte global stores (32-byte segments), park the finished fp16 values in an LDS
 // tile [128][CLD] so that the block can write whole 16-byte x row-contiguous vectors afterwards.
@@ -1342,6 +1378,31 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
     if (BM == 256 || two_a) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   };
+  // LayerNorm-folded launch (term-free epilogue, dense): the fold's operands travel with the first K tile -- the oldest requests of every wave, so the
+  // prologue's counted wait covers them; wave w moves pieces w and w + 8 of { 2 per part: the tile's BM x (sum, sum of squares) | 2: colsum | 2: cvec }
+  constexpr bool LN_LDS = EPI == 0 && !GATHER;
+  if constexpr (LN_LDS) {
+    if (a.ln_stats) {   // (me_gemm: ln_parts <= 4)
+      const int np = 2 * a.ln_parts;
+      for (int q = wave; q < np + 4; q += 8) {
+        const char* src;
+        unsigned range;
+        int dst;
+        if (q < np) {
+          src = reinterpret_cast<const char*>(a.ln_stats) + ((long)(q >> 1) * a.ln_stride + 2 * (long)m0) * 4;
+          range = (unsigned)min(a.M - m0, BM) * 8u;
+          dst = (q >> 1) * 2048 + (q & 1) * 1024;
+        } else {
+          const int k = q - np;
+          src = reinterpret_cast<const char*>((k >> 1) ? a.ln_cvec : a.ln_colsum) + (long)n0 * 4;
+          range = (unsigned)min(a.N - n0, BN) * 4u;
+          dst = ((k >> 1) ? LN_LDS_CVEC : LN_LDS_COLSUM) + (k & 1) * 1024;
+        }
+        const auto srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(src), 0, range, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lptr_t)(smem + 2 * BUFBYTES + dst), 16, (q & 1) * 1024 + lane * 16, 0, 0, 0);
+      }
+    }
+  }
   // prologue: tile 0 whole, the first two parts of tile 1
   issueA(cA0, 0);
   issueB0();
@@ -1392,7 +1453,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
 #undef ME_LGKM0
 
   if constexpr (EPI <= 0) {   // (the LayerNorm-folded projections -- q | k | v, to_q, GEGLU -- have no row-vector / residual terms: me_gemm checks)
-    if (a.ln_stats) ln_fold_acc<NT, MT>(a, acc, m0 + wr * GR, n0 + wc * WN, lane);   // (wave-uniform)
+    if (a.ln_stats) {         // (wave-uniform; ONE form per instantiation: two alternatives behind a run-time test cost 168 spilled registers at the join)
+      if constexpr (LN_LDS) ln_fold_acc_lds<NT, MT>(a, acc, smem + 2 * BUFBYTES, wr * GR, wc * WN, lane);   // (the image landed under the prologue's counted wait + barrier)
+      else ln_fold_acc<NT, MT>(a, acc, m0 + wr * GR, n0 + wc * WN, lane);
+    }
   }
 
   if constexpr (EPI >= 0 && BN == 256) {   // GEGLU: one 64 KB LDS tile for the whole block (me_gemm has checked geglu, N % 256 == 0, ldc % 8 == 0, 16-byte aligned C)
@@ -1624,7 +1688,7 @@ static int launch_gemm(const me_gemm_args* a, hipStream_t st) {
 
 template <int BM, int BN, bool GATHER, int EPI>
 static int launch_gemm8p_epi(const me_gemm_args& b, hipStream_t st) {
-  const int lds = 2 * (BM + BN) * 128 + (GATHER ? 9 * 256 * 4 : 0);
+  const int lds = 2 * (BM + BN) * 128 + (GATHER ? 9 * 256 * 4 : (EPI == 0 ? LN_LDS_BYTES : 0));   // (dense, term-free: room for the LayerNorm fold's operands)
   static bool attr_set_dev[64] = {};
   int dev_id = 0;
   (void)hipGetDevice(&dev_id);
@@ -1724,10 +1788,10 @@ static int gemm_dispatch(const me_gemm_args* a, void* stream);
 extern "C" int me_gemm(const me_gemm_args* a, void* stream) {
   if (!a || !a->X || !a->W || !a->C) { me_set_error("me_gemm: null pointer"); return ME_EINVAL; }
   if (a->ln_stats) {
-    if (a->gather != ME_GATHER_DENSE || a->bias || a->alpha != 1.0f || a->rowvec || a->res || a->res2 || a->act || !a->ln_colsum || !a->ln_cvec || a->ln_parts < 1 || a->ln_parts > 8 || a->ln_stride < 2 * (int64_t)a->M ||
+    if (a->gather != ME_GATHER_DENSE || a->bias || a->alpha != 1.0f || a->rowvec || a->res || a->res2 || a->act || !a->ln_colsum || !a->ln_cvec || a->ln_parts < 1 || a->ln_parts > 4 || a->ln_stride < 2 * (int64_t)a->M ||
         (a->ln_stride & 1) || ((uintptr_t)a->ln_stats & 7) || (((uintptr_t)a->ln_colsum | (uintptr_t)a->ln_cvec) & 15) || !(a->ln_eps > 0.f)) {
       me_set_error("me_gemm: a LayerNorm-folded launch is dense, has no bias (it is inside ln_cvec), no rowvec / residual / activation and alpha == 1; ln_colsum / ln_cvec fp32 [N] 16-byte aligned, "
-                   "ln_stats 8-byte aligned with 1 <= ln_parts <= 8 parts ln_stride >= 2 M floats apart, ln_eps > 0");
+                   "ln_stats 8-byte aligned with 1 <= ln_parts <= 4 parts ln_stride >= 2 M floats apart, ln_eps > 0");
       return ME_EINVAL;
     }
   }
