@@ -76,6 +76,10 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="A/B: run ControlNet on the main stream instead of beside the UNet's down path")
     ap.add_argument("--no-cfg-prefix-sharing", action="store_true",
                     help="execute the classifier-free-guidance prefix (conv_in .. first cross-attention queries) for both halves of the batch, as the reference does (A/B)")
+    ap.add_argument("--shard-overlap", action="store_true",
+                    help="frame-sharded modes: ControlNet + content-aware adapter on the side stream beside the UNet's down path and mid block, the adapter's exchanges on "
+                         "a second communicator per shard group (parallel.FrameShard.side_shard).  Off by default: bitwise the serialised sharded step on 4 ranks sharing one "
+                         "GPU (tests/test_frame_shard_gpu.py), never measured between physical GPUs")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a captured hipGraph (MotionEditorPipeline.denoise_step_graphed) instead of enqueueing its ~1100 launches from Python -- "
                          "in every mode: the sharded / CFG-parallel steps are captured with their RCCL exchanges as graph nodes.  Off by default: on one GPU it is "
@@ -354,7 +358,7 @@ def main():
     cfg_r = rank % n_cfg
     shard_i = (rank // n_cfg) % n_shards
     clip = rank // (n_cfg * n_shards)
-    cfg_group = shard_group = None
+    cfg_group = shard_group = side_group = None
     if dist_on:   # every rank creates every group, in the same order
         if n_cfg == 2:
             for c in range(n_clips):
@@ -368,8 +372,9 @@ def main():
                 for k in range(n_cfg):
                     ranks = [(c * n_shards + s_) * n_cfg + k for s_ in range(n_shards)]
                     g = dist.new_group(ranks)
+                    g2 = dist.new_group(ranks) if args.shard_overlap else None     # the adapter's own communicator (--shard-overlap)
                     if rank in ranks:
-                        shard_group = g
+                        shard_group, side_group = g, g2
     shard = None
     comm = "torch" if args.emulate else (args.comm if args.comm != "auto" else ("rccl" if args.graph else "torch"))
     if dist_on and comm == "rccl":   # our own communicators (every rank of a group creates it together); the pipeline takes the adapter in place of the group
@@ -379,12 +384,14 @@ def main():
     if n_shards > 1 or mode == "frames":
         from motioneditor_amd import parallel
         lean = args.shard_exchange == "lean"
-        shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather", comm=comm)   # f / n_shards frames per rank
+        shard = parallel.FrameShard(f, shard_group, temporal="a2a" if lean else "gather", adapter="halo" if lean else "gather", comm=comm,   # f / n_shards frames per rank
+                                    side_group=side_group)
         assert shard.rank == shard_i
     x = build_inputs(f, h, w, seed=33 + clip)   # one clip per rank (replicas), per GPU pair (cfg), or for all ranks
     pipe, sed, ted = make_pipeline(device, usd, csd, x["masks"], emu_dtype)
     pipe.overlap_controlnet = pipe.overlap_adapter = not (args.no_overlap or args.emulate)
     pipe.dedup_cfg_prefix = not args.no_cfg_prefix_sharing
+    pipe.shard_overlap = bool(args.shard_overlap and not args.emulate)
     images = torch.cat([x["skeleton"]] * 2).reshape(2 * f, 3, 8 * h, 8 * w).to(device)
     lat = x["latents"].to(device)
     if shard is not None:   # this rank's frames only
@@ -547,7 +554,8 @@ def main():
                                        f"(editors {args.editors}), 1 DDIM step = 1 unit; seeded random SD-1.5-architecture weights"),
                           "frames": f, "latent_hw": [h, w], "batch": 2 if args.single_branch else 4, "guidance": 7.5, "editors": args.editors, "zero_temporal_conv": bool(args.zero_tconv),
                           "controlnet_dedup": bool(pipe.dedup_controlnet and f % 2 == 0),
-                          "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and shard is None and n_cfg == 1), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
+                          "cfg_prefix_shared": bool(pipe.dedup_cfg_prefix and n_cfg == 1), "shard_overlap": bool(pipe.shard_overlap and shard is not None),
+                          "layernorm_folded": bool(getattr(__import__("motioneditor_amd.models.graph", fromlist=["LN_FOLD"]), "LN_FOLD", False)), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
                           "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(plan_state["on"]), "launch_plan_error": plan_state["error"], "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,

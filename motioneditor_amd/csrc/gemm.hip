@@ -187,6 +187,9 @@ __device__ __forceinline__ void ln_fold_acc(const me_gemm_args& a, f32x4 (&acc)[
 // global form cost 1.4 us per 256-row tile, +2.5 ms per step on each of the two LayerNorm-folded kernel families) fetch the tile's partial row sums, column sums
 // and constants by LDS-DMA together with the first K tile (gemm8p_kernel, LN_LDS).  Image: [parts <= 4][BM rows][2 floats] at 2 KB per part | colsum [BN] at
 // + 8 KB | cvec [BN] at + 10 KB.  Same values, same operation order as ln_fold_acc: bitwise the same result.
+// Measured and not kept (profiles/r06_lnfold_ab.txt): the accumulators STARTING at cvec sd - mean colsum behind the prologue's barrier and the epilogue scaling
+// row m by rstd where it scaled by alpha anyway -- the same 2 operations per accumulator, half of them moved to the tile's head: GEGLU kernel 16.2 vs 15.6 ms
+// per step (14.2 without the fold), the 320-wide kernel 24.5 vs 24.6 (23.2): at one block per CU VALU work at EITHER end of a tile is exposed.
 constexpr int LN_LDS_BYTES = 12288, LN_LDS_COLSUM = 8192, LN_LDS_CVEC = 10240;
 template <int NT, int MT>
 __device__ __forceinline__ void ln_fold_acc_lds(const me_gemm_args& a, f32x4 (&acc)[NT][MT], const char* img, int rloc, int cloc, int lane) {

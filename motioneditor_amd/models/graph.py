@@ -313,6 +313,9 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
         t, st = _gemm_st(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t, **({"res_rows": t.shape[0]} if expand > 1 else {}))
         if expand > 1:
             x = Act(t, x.B * expand, x.f, x.h, x.w)
+            # from here on the launches hold the full batch: me_gemm selects their kernels by their own row count again (unet_forward set the scale for the
+            # shared sub-batch; the 8-phase and the 128-row kernels round a LayerNorm-folded projection differently, so the choice has to be the full launch's)
+            ops.SELECT_ROWS_SCALE = 1
     # --- feed-forward (attention_2d.py:531)
     t, st = feed_forward(P, p + ".ff", LN(P, p + ".norm3", t, st), t, want_stats=has_temp)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
@@ -497,7 +500,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
               text_kv=text_kv_all(P, text, attention_block_names(True)))
 
     # the CFG prefix (docstring): only when the spatial editor leaves the first self-attention alone (it does for start_layer > 0), un-sharded, not recording
-    share = (cfg_dup and B % 2 == 0 and shard is None and DOWN_HAS_ATTN[0] and not getattr(ops, "recording", False) and
+    # (round 6: frame-sharded too -- `frames` mode holds the full batch of 4 on every rank; the prefix's exchanges then run at half the batch)
+    share = (cfg_dup and B % 2 == 0 and DOWN_HAS_ATTN[0] and not getattr(ops, "recording", False) and
              (spatial is None or (hasattr(spatial, "edits_next_self_attention") and not spatial.edits_next_self_attention())))
     Bp = B // 2 if share else B
     x = Act(ops.conv_small(sample, P.mat32("conv_in.weight"), P.vec32("conv_in.bias"), n_img=Bp * f, Cin=4, H=h, Wd=w,
@@ -506,7 +510,10 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
     # stream (the one ControlNet ran on, so the residuals are ordered) every block is enqueued there as soon as its skip
     # exists and runs beside the rest of the down path and the mid block; the skips themselves are updated after the
     # down path (main may still be reading them), and the up path waits on one event.
-    side = side_stream if (side_stream is not None and down_res is not None and taps is None and shard is None and sample.is_cuda) else None
+    # Frame-sharded (round 6, `--shard-overlap`): the adapter's own exchanges need their own communicator beside the main stream's (parallel.FrameShard.side_shard)
+    side = side_stream if (side_stream is not None and down_res is not None and taps is None and sample.is_cuda and
+                           (shard is None or getattr(shard, "side_shard", None) is not None)) else None
+    ashard = shard.side_shard if (shard is not None and side is not None) else shard     # the shard view the adapter's exchanges go through
     main = torch.cuda.current_stream() if side is not None else None
     motion: List[torch.Tensor] = []
 
@@ -516,8 +523,8 @@ def unet_forward(P: Packed, sample: torch.Tensor, t: float, ehs: torch.Tensor, *
             n = s.f * s.N
             shared = r.shape[0] == n and len(edit_rows) > 1   # one ControlNet entry shared by all edit rows
             return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, 1 if shared else len(edit_rows), s.f, s.h, s.w), [s.rows_of(eb) for eb in edit_rows],
-                                 len(edit_rows), shard)
-        return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, shard)   # (unet_2d_condition.py:483-485)
+                                 len(edit_rows), ashard)
+        return adapter_block(P, f"controlnet_adapter.body.{i}", Act(r, s.B, s.f, s.h, s.w), s.t, None, ashard)   # (unet_2d_condition.py:483-485)
 
     def push_skip(s: Act) -> None:
         skips.append(s)

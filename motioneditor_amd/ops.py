@@ -72,6 +72,7 @@ def empty(rows: int, cols: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty((rows, cols), dtype=F16, device=like.device)
 
 
+ATTN_ITEM_ORDER = os.environ.get("ME_ATTN_ITEM_ORDER", "1") != "0"   # the edited launches walk their items (recon g, edit g, recon g + 1, ...): me_attn_args.item_order
 ROW_RANGE = True       # this backend implements gemm(row_range=...) (me_gemm_args.m_off)
 LN_FOLD = True         # ... and gemm(ln=..., ln_out=...) / ln_stats (ABI 9: LayerNorm folded into the projection that consumes it)
 HEAD_MAJOR_KV = True   # this backend implements gemm(head_major=...) / 3-D k, v in attention (the CPU emulation and the autodiff recorder do not)
@@ -289,7 +290,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, heads: int, 
     a.general_dual = 1 if gd else 0
     a.q_items = q_items
     order = segments.ITEM_ORDER.get(seg_item.data_ptr())
-    if order is not None and order.device == q.device and order.numel() == n_items and os.environ.get("ME_ATTN_ITEM_ORDER", "1") != "0":   # (A/B switch)
+    if order is not None and order.device == q.device and order.numel() == n_items and ATTN_ITEM_ORDER:   # (A/B switch, read once at import)
         a.item_order = order.data_ptr()
     if lse is not None:
         if lse.dtype != torch.float32 or not lse.is_contiguous() or lse.numel() != n_items * nq * heads:

@@ -240,11 +240,18 @@ def exchange(group=None, kind: str = "torch"):
 
 
 class FrameShard:
-    def __init__(self, f_total: int, group=None, temporal: str = "a2a", adapter: str = "halo", comm: str = "torch"):
+    def __init__(self, f_total: int, group=None, temporal: str = "a2a", adapter: str = "halo", comm: str = "torch", side_group=None):
+        """side_group (round 6, `--shard-overlap`): a SECOND process group over the same ranks.  The content-aware adapter then runs on the step's side
+        stream with its own FrameShard (`side_shard`: its chunk halos, TemporalConv halos and frame<->pixel all-to-alls travel on the second group's
+        communicator), beside the UNet's down path and mid block -- as on one GPU -- instead of serialised behind them on the main stream.  Two
+        communicators because collectives of ONE communicator execute in issue order: the main stream's GroupNorm all-reduce would otherwise queue
+        behind an adapter exchange whose input the side stream has not produced yet.  Every rank issues the same host program, so each communicator sees
+        one order on all ranks.  Creating the group is a collective over the default group (dist.new_group): the caller does it (bench.py, tests)."""
         if temporal not in ("a2a", "gather") or adapter not in ("halo", "gather"):
             raise ValueError("temporal must be 'a2a' or 'gather', adapter 'halo' or 'gather'")
         self.temporal, self.adapter = temporal, adapter
         self.group = group
+        self.side_shard = FrameShard(f_total, side_group, temporal, adapter, comm) if side_group is not None else None
         self.x = exchange(group, comm)          # every exchange below goes through it
         self.rank, self.world = self.x.rank, self.x.world
         if f_total % self.world:

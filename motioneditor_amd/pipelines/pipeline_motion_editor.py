@@ -12,12 +12,16 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 import collections
+import weakref
 from typing import Callable, List, Optional, Union
 
 import torch
 
 from .. import ops, plan
 from ..schedulers import DDIMScheduler
+
+
+_LIVE_PIPELINES = weakref.WeakSet()   # every pipeline of this process: release_plans() of one must not free scratch another's recorded steps point into
 
 
 @dataclass
@@ -64,6 +68,7 @@ class MotionEditorPipeline:
         # and the up path waits on an event.
         self.overlap_controlnet = True
         self.overlap_adapter = True     # needs overlap_controlnet (same side stream, so the residuals are already ordered)
+        self.shard_overlap = False      # the same two-stream overlap inside the frame-sharded step (denoise_step_frame_sharded; bench.py --shard-overlap)
         self._side_stream = None
         self.side_stream_priority = 0   # HIP priority of the side stream (-1 = high); A/B switch, measured in DESIGN.md section 3.1
         # denoise_step_graphed / _planned: (shapes, conditioning tensor, editor gating) -> captured / recorded step.  Every entry pins one step's
@@ -71,6 +76,7 @@ class MotionEditorPipeline:
         # active -- of one clip are the working set of a 50-step run) and `release_plans()` returns everything.
         self._graphs = collections.OrderedDict()
         self._plans = collections.OrderedDict()
+        _LIVE_PIPELINES.add(self)
         self.max_cached_steps = 4
         # who issues the launches of a step inside __call__'s loop: "eager" = this Python process, launch by launch (denoise_step);
         # "plan" = one me_denoise_step call per step on CUDA inputs (denoise_step_planned: bitwise the eager result, ~4 x less host time)
@@ -103,11 +109,16 @@ class MotionEditorPipeline:
 
     def release_plans(self):
         """Drop every recorded launch plan and captured graph (and the memory pools they pin).  The next planned / graphed step records again."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()     # a replay still in flight reads the pools dropped below (round-5 advisor finding)
         for table in (self._plans, self._graphs):
             while table:
                 _, old = table.popitem(last=False)
                 self._release_entry(old)
-        ops.scratch_trim()
+        # the retired split-K scratch blocks are process-global: another pipeline's recorded / captured steps may hold their addresses -- trim only when
+        # no pipeline of this process has a live plan or graph left (round-5 advisor finding)
+        if not any(p_._plans or p_._graphs for p_ in _LIVE_PIPELINES):
+            ops.scratch_trim()
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
 
@@ -247,16 +258,36 @@ class MotionEditorPipeline:
             r = cx.rank
             x = latents                                   # both CFG halves see the same [recon, edit] latents (:605)
             emb = text_embeddings_input[2 * r:2 * r + 2]
-        down = mid = None
+        down = mid = ready = None
         two = False
+        # shard_overlap (round 6, bench.py --shard-overlap; off by default until a multi-GPU run has measured it): the ControlNet -- rank-local, no exchange --
+        # runs on the side stream beside the UNet's down path, and the adapter follows it there when the shard has a second communicator (FrameShard.side_shard)
+        side_on = bool(self.shard_overlap and x.is_cuda and not torch.cuda.is_current_stream_capturing())
         if self.controlnet is not None and images is not None:
             prompt = text_embeddings_input[1::2]
             img = images[:f] if images.shape[0] == 2 * f else images
-            # row of the full "(b f)" ControlNet batch = entry * f_total + global frame, and it reads prompt row % 2
-            # (pipeline :615,621): this rank's first row is entry r (its CFG half), global frame frame0
-            down, mid = self.controlnet.forward_rows(x, [1], t, prompt, img, controlnet_conditioning_scale, row_offset=r * shard.f_total + shard.frame0)
+
+            def run_controlnet():
+                # row of the full "(b f)" ControlNet batch = entry * f_total + global frame, and it reads prompt row % 2
+                # (pipeline :615,621): this rank's first row is entry r (its CFG half), global frame frame0
+                return self.controlnet.forward_rows(x, [1], t, prompt, img, controlnet_conditioning_scale, row_offset=r * shard.f_total + shard.frame0)
+
+            if side_on:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(priority=self.side_stream_priority)
+                main = torch.cuda.current_stream()
+                plan.wait_stream(self._side_stream, main)
+                with torch.cuda.stream(self._side_stream):
+                    down, mid = run_controlnet()
+                ready = plan.record_event(self._side_stream)
+                for r_ in list(down) + [mid]:
+                    plan.share(r_, main)
+            else:
+                down, mid = run_controlnet()
             two = True
-        eps = self.unet.forward_rows(x, t, emb, down, mid, two, shard=shard).t
+        eps = self.unet.forward_rows(x, t, emb, down, mid, two, shard=shard, res_ready=ready,
+                                     side_stream=self._side_stream if (ready is not None and getattr(shard, "side_shard", None) is not None) else None,
+                                     cfg_dup=self.dedup_cfg_prefix and cfg_group is None).t
         if cfg_group is not None:
             both = torch.empty((2 * eps.shape[0], eps.shape[1]), dtype=eps.dtype, device=eps.device)
             parallel._count("all_gather(noise prediction, CFG pair)", eps)

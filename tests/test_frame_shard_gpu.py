@@ -18,7 +18,15 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, bench_inputs=False):
+def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, bench_inputs=False, overlap=False):
+    import time
+    t00 = time.time()
+
+    def lap(what):   # ME_TEST_TIMES=<file>: where a multi-rank case spends its wall time (rank 0)
+        log = os.environ.get("ME_TEST_TIMES")
+        if log and rank == 0:
+            with open(log, "a") as fh:
+                fh.write(f"world {world} f {f} hw {hw} overlap {overlap}: {what} at {time.time() - t00:.1f} s\n")
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -33,8 +41,10 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, ben
     from test_step_cpu import step_inputs
     # bench_inputs: bench.py's own inputs (synth.bench_inputs) -- what tests/golden/step_config3.npz was generated on
     x = synth.bench_inputs(f, hw, hw) if bench_inputs else step_inputs(f=f, h=hw, w=hw)
+    lap("imports + process group + inputs")
     unet = UNet2DConditionModel(synth.synth_state_dict(synth.unet_schema()), device="cuda")
     cn = ControlNetModel(synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet."), device="cuda")
+    lap("models built")
     pipe = MotionEditorPipeline(unet=unet, controlnet=cn)
     ted = TemporalSelfAttentionControl(start_step=4, start_layer=10)
     regiter_temporal_attention_editor_diffusers(pipe, ted)
@@ -48,7 +58,7 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, ben
     unc = x["uncond"][step] if bench_inputs else x["uncond"]      # (bench_inputs holds one unconditional embedding per step: null-text inversion)
     emb = torch.cat([unc.expand(2, 77, 768), x["cond"]]).cuda()
     lat = x["latents"].cuda()
-    cfg_x = shard_group = None
+    cfg_x = shard_group = side_group = None
     if hybrid:   # rank = shard * 2 + cfg half (bench.py's layout): CFG pairs {0,1},{2,3}; frame-shard groups {0,2},{1,3}
         ns = world // 2
         for s_ in range(ns):
@@ -57,14 +67,33 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, ben
                 cfg_x = parallel.exchange(g, "staged")
         for k in range(2):
             g = dist.new_group([2 * s_ + k for s_ in range(ns)])
+            g2 = dist.new_group([2 * s_ + k for s_ in range(ns)]) if overlap else None     # the adapter's own communicator (FrameShard.side_shard)
             if rank % 2 == k:
-                shard_group = g
+                shard_group, side_group = g, g2
+    elif overlap:
+        side_group = dist.new_group(list(range(world)))
     parallel.reset_stats()
-    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter, comm="staged")
+    shard = parallel.FrameShard(f, shard_group, temporal=temporal, adapter=adapter, comm="staged", side_group=side_group)
     lo, hi = shard.frame0, shard.frame0 + shard.f_loc
     ted.cur_step = sed.cur_step = step
+    lap("groups + shard")
     got = pipe.denoise_step_frame_sharded(lat[:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_x)
     torch.cuda.synchronize()
+    lap("sharded step")
+    if overlap:   # the same step with ControlNet + adapter on the side stream (the adapter's exchanges on the second group): the same launches, bit for bit
+        assert shard.side_shard is not None and not pipe.shard_overlap
+        pipe.shard_overlap = True
+        ted.cur_step = sed.cur_step = step
+        ted.cur_att_layer = sed.cur_att_layer = 0
+        got2 = pipe.denoise_step_frame_sharded(lat[:, :, lo:hi].contiguous(), t, emb, images[lo:hi].contiguous(), 7.5, shard, cfg_group=cfg_x)
+        torch.cuda.synchronize()
+        lap("overlapped sharded step")
+        pipe.shard_overlap = False
+        assert pipe._side_stream is not None
+        assert torch.equal(got2, got), float((got2.double() - got.double()).norm() / got.double().norm())
+        for v in parallel.STATS.values():     # two steps were counted
+            v[0] //= 2
+            v[1] //= 2
     assert (sed.cur_step, ted.cur_step, sed.cur_att_layer, ted.cur_att_layer) == (step + 1, step + 1, 0, 0)
     st = parallel.stats_summary()
     assert st["all_reduce(groupnorm stats)"]["calls_per_step"] == 45, st
@@ -83,19 +112,20 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, ben
         ted.reset(); sed.reset()
         ted.cur_step = sed.cur_step = step
         want = pipe.denoise_step(lat, t, emb, torch.cat([images] * 2), 7.5).cpu()
+        lap("plain step")
         err = float((full.double() - want.double()).norm() / want.double().norm())
         torch.save({"err": err, "stats": st, "latents": full if bench_inputs else None}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(tmp_path, world, f, hybrid=False, temporal="a2a", adapter="halo", hw=8, bench_inputs=False):
+def _run(tmp_path, world, f, hybrid=False, temporal="a2a", adapter="halo", hw=8, bench_inputs=False, overlap=False):
     from motioneditor_amd import synth
     synth.synth_state_dict(synth.unet_schema())                               # fill the per-machine weight cache once: the ranks map it instead of
     synth.synth_state_dict(synth.controlnet_schema(), salt="controlnet.")     # generating 1.7 G parameters each
     out = tmp_path / "r.pt"
     port = 29100 + (os.getpid() % 2000) + world * 7 + f + (3 if hybrid else 0) + hw
-    mp.spawn(_worker, args=(world, port, f, str(out), hybrid, temporal, adapter, hw, bench_inputs), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, f, str(out), hybrid, temporal, adapter, hw, bench_inputs, overlap), nprocs=world, join=True)
     return torch.load(out)
 
 
@@ -156,4 +186,17 @@ def test_eight_frame_shards_the_layout_of_baseline_configs4(tmp_path):
     from test_model_gpu import record
     r = _run(tmp_path, 8, 48, hw=32)
     record("frame_shard_eight_ranks_one_gpu_configs4_layout", r["err"])
+    assert r["err"] < 2e-3, r
+
+
+@pytest.mark.parametrize("hybrid", [False, True])
+def test_sharded_step_with_controlnet_and_adapter_on_the_side_stream(tmp_path, hybrid):
+    """`--shard-overlap` (round 6): inside the frame-sharded step the ControlNet and the content-aware adapter run on the side stream beside the UNet's down path
+    and mid block -- as in the single-process step -- with the adapter's chunk halos, TemporalConv halos and frame<->pixel all-to-alls on a SECOND process
+    group (parallel.FrameShard.side_shard), so that the two streams' exchanges do not queue behind each other.  4 ranks on the one GPU (frames4, and the
+    CFG pair x frames2 hybrid): the overlapped step must equal the serialised sharded step bit for bit (same launches, other streams) and the plain step to
+    the usual tolerance."""
+    r = _run(tmp_path, 4, 16 if hybrid else 24, hybrid=hybrid, overlap=True)
+    from test_model_gpu import record
+    record("frame_shard_overlap_" + ("hybrid" if hybrid else "frames4"), r["err"])
     assert r["err"] < 2e-3, r

@@ -63,6 +63,33 @@ def bench_gemm():
     print("sum ms", round(tot, 2))
 
 
+def bench_lnfold():
+    """LayerNorm folded into the projection (round 6, ABI 9) against LayerNorm + projection, and the projection that produces the row sums against the plain one:
+    same process, same data.  `fold` = me_gemm with ln_stats given (statistics from the producer: no extra launch); `ln+gemm` = me_layernorm + me_gemm."""
+    B, f = 4, 24
+    print(f"{'LN fold':22s} {'M':>8s} {'N':>6s} {'K':>6s} {'ln ms':>7s} {'gemm ms':>8s} {'fold ms':>8s} {'x':>6s} {'fold TF/s':>9s}")
+    for li, (hw, C) in enumerate([(64, 320), (32, 640), (16, 1280)]):
+        M = B * f * hw * hw
+        x = rnd(M, C)
+        gamma, beta = (1 + 0.1 * torch.randn(C, device=dev)).half(), (0.1 * torch.randn(C, device=dev)).half()
+        st = ops.ln_stats(x)
+        for name, N, geglu, hm in ((f"L{li} qkv (panels)", 3 * C, False, True), (f"L{li} to_q", C, False, False), (f"L{li} ff1 geglu", 8 * C, True, False)):
+            w = rnd(N, 1, C)
+            cs, cv = torch.randn(N, device=dev), torch.randn(N, device=dev)
+            kw = dict(head_major=(0, C // 8)) if hm else {}
+            t_ln = timeit(lambda: ops.layernorm(x, gamma, beta))
+            t_g = timeit(lambda: ops.gemm(x, w, geglu=geglu, **kw))
+            t_f = timeit(lambda: ops.gemm(x, w, geglu=geglu, ln=(st, cs, cv, 1e-5), **kw))
+            print(f"{name:22s} {M:8d} {N:6d} {C:6d} {t_ln:7.3f} {t_g:8.3f} {t_f:8.3f} {(t_ln + t_g) / t_f:6.2f} {2.0 * M * N * C / t_f / 1e9:9.1f}")
+            del w
+        w, res = rnd(C, 1, C), rnd(M, C)
+        t_p = timeit(lambda: ops.gemm(x, w, res=res))
+        t_s = timeit(lambda: ops.gemm(x, w, res=res, ln_out=True))
+        t_k = timeit(lambda: ops.ln_stats(x))
+        print(f"L{li} out + res: plain {t_p:.3f} ms, with row sums {t_s:.3f} ms (+{(t_s / t_p - 1) * 100:.1f} %); me_ln_stats alone {t_k:.3f} ms")
+        del x, w, res
+
+
 def bench_gemm_8p():
     """8-phase ping-pong kernel vs the one-barrier-per-slab kernel on the shapes that take the 256-row tile (ME_GEMM_8P flips per call):
     times both, and checks the 8-phase result BITWISE against the other kernel's (same MFMA order per accumulator, same epilogue) on
@@ -435,6 +462,10 @@ def bench_bwd():
         ms = timeit(lambda: ops.layernorm_bwd(y, gm, dy))
         print(f"{'layernorm_bwd C=' + str(C):40s} {ms:8.3f}")
 
+
+if __name__ == "__main__" and "lnfold" in sys.argv[1:]:
+    bench_lnfold()
+    sys.exit(0)
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "attn", "misc"]
