@@ -194,15 +194,24 @@ constexpr int LN_LDS_BYTES = 12288, LN_LDS_COLSUM = 8192, LN_LDS_CVEC = 10240;
 template <int NT, int MT>
 __device__ __forceinline__ void ln_fold_acc_lds(const me_gemm_args& a, f32x4 (&acc)[NT][MT], const char* img, int rloc, int cloc, int lane) {
   const float invK = 1.0f / (float)a.K;
-  float nmean[MT], rstd[MT];
+  // ALL four part slots of the image are read, branch-free (the DMA zero-fills the slots past ln_parts: + 0.0f is exact, the sum keeps the order of
+  // ln_fold_acc).  The first version looped over ln_parts: hipcc built a vectorised + remainder loop pair per row, every trip behind its own s_waitcnt --
+  // ~300 instructions of control and waits for 8 x ln_parts reads, 2 - 3 us per tile at one block per CU (tools/kbench.py lnfold: L0 q | k | v 0.452 vs 0.399 ms).
+  uint2 v[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int row = rloc + i * 16 + (lane & 15);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) v[i][p] = *reinterpret_cast<const uint2*>(img + p * 2048 + row * 8);
+  }
+  float nmean[MT], rstd[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
     float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < a.ln_parts; ++p) {
-      const uint2 v = *reinterpret_cast<const uint2*>(img + p * 2048 + row * 8);
-      s1 += __uint_as_float(v.x);
-      s2 += __uint_as_float(v.y);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      s1 += __uint_as_float(v[i][p].x);
+      s2 += __uint_as_float(v[i][p].y);
     }
     const float mu = s1 * invK;
     const float var = __builtin_fmaf(-mu, mu, s2 * invK);
@@ -1385,15 +1394,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   // prologue's counted wait covers them; wave w moves pieces w and w + 8 of { 2 per part: the tile's BM x (sum, sum of squares) | 2: colsum | 2: cvec }
   constexpr bool LN_LDS = EPI == 0 && !GATHER;
   if constexpr (LN_LDS) {
-    if (a.ln_stats) {   // (me_gemm: ln_parts <= 4)
-      const int np = 2 * a.ln_parts;
+    if (a.ln_stats) {   // (me_gemm: ln_parts <= 4; the part slots past ln_parts get a zero-length range: the DMA fills them with zeros)
+      constexpr int np = 8;
       for (int q = wave; q < np + 4; q += 8) {
         const char* src;
         unsigned range;
         int dst;
         if (q < np) {
-          src = reinterpret_cast<const char*>(a.ln_stats) + ((long)(q >> 1) * a.ln_stride + 2 * (long)m0) * 4;
-          range = (unsigned)min(a.M - m0, BM) * 8u;
+          const bool live = (q >> 1) < a.ln_parts;
+          src = reinterpret_cast<const char*>(a.ln_stats) + (live ? ((long)(q >> 1) * a.ln_stride + 2 * (long)m0) * 4 : 0L);
+          range = live ? (unsigned)min(a.M - m0, BM) * 8u : 0u;
           dst = (q >> 1) * 2048 + (q & 1) * 1024;
         } else {
           const int k = q - np;

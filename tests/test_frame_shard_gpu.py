@@ -30,6 +30,9 @@ def _worker(rank, world, port, f, out_path, hybrid, temporal, adapter, hw=8, ben
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    # the ranks pack 1.2 G parameters each on the host (fp32 -> packed fp16) at their first step: with torch's default of one thread per core in EVERY rank
+    # four ranks took 360 s over it (8 x 8 and 64 x 64 latents alike: profiles/r06_shard_test_times.txt), two ranks 60 s
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // (2 * world))))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from motioneditor_amd import parallel, synth
