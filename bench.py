@@ -375,8 +375,11 @@ def main():
                     g2 = dist.new_group(ranks) if args.shard_overlap else None     # the adapter's own communicator (--shard-overlap)
                     if rank in ranks:
                         shard_group, side_group = g, g2
+    if dist_on and args.shard_overlap and mode == "frames" and n_shards == 1:   # the sharded code path on ONE rank: the adapter's second communicator over the default group
+        side_group = dist.new_group(list(range(world)))
     shard = None
     comm = "torch" if args.emulate else (args.comm if args.comm != "auto" else ("rccl" if args.graph else "torch"))
+    comm_backend = comm     # (`comm` is re-used for the exchange statistics further down)
     if dist_on and comm == "rccl":   # our own communicators (every rank of a group creates it together); the pipeline takes the adapter in place of the group
         from motioneditor_amd import parallel
         if cfg_group is not None:
@@ -558,7 +561,7 @@ def main():
                           "layernorm_folded": bool(getattr(__import__("motioneditor_amd.models.graph", fromlist=["LN_FOLD"]), "LN_FOLD", False)), "controlnet_side_stream": bool(pipe.overlap_controlnet and world == 1),
                           "step_invariant_reuse": "ControlNet conditioning embedding of the (unchanged) skeleton computed at the first step and kept (exact); "
                                                   "text K|V of all transformer blocks projected by one GEMM per model",
-                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(plan_state["on"]), "launch_plan_error": plan_state["error"], "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
+                          "hip_graph_replay": bool(use_graph), "launch_plan_replay": bool(plan_state["on"]), "launch_plan_error": plan_state["error"], "main_stream_priority": args.main_priority, "side_stream_priority": args.side_priority, "exchange_backend": comm_backend if dist_on else None, "parallel_mode": mode, "shard_exchange": args.shard_exchange if n_shards > 1 else None, "parallelism": desc,
                           "oracle_pins": "UNet3D / adapter / editors / DDIM pinned by reference-generated goldens; ControlNet (diffusers, source not in the reference tree): TRUNK pinned "
                                          "against the reference's own 2-D-degenerate SD-1.5 blocks (tests/golden/controlnet_trunk.npz), its 8 conditioning-embedding convolutions and "
                                          "13 1x1 zero-convolutions self-pinned"},

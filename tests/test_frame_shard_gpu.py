@@ -203,3 +203,15 @@ def test_sharded_step_with_controlnet_and_adapter_on_the_side_stream(tmp_path, h
     from test_model_gpu import record
     record("frame_shard_overlap_" + ("hybrid" if hybrid else "frames4"), r["err"])
     assert r["err"] < 2e-3, r
+
+
+def test_eight_frame_shards_at_configs4_size(tmp_path):
+    """BASELINE configs[4] AS WRITTEN, at its own size and in its own layout: 48 frames x 768^2 (96 x 96 latents), batch 4, two-branch + ControlNet + adapter + both
+    editors, the frames sharded 6 per rank over 8 ranks (8 processes sharing the one GPU, exchanges staged through the host) -- against the plain step of the same
+    inputs on the same GPU (the 918-TFLOP workload has no oracle fixture: the unsharded step's own checks are test_full_size_properties_configs4, the 96 x 96
+    geometry and the 48-frame count have oracle goldens of their own).  A rank's level-0 launches are 6 frames x 9216 pixels x batch 4 = 221184 rows; the world-8
+    frame<->pixel all-to-all moves 1152 pixels per part."""
+    from test_model_gpu import record
+    r = _run(tmp_path, 8, 48, hw=96)
+    record("frame_shard_eight_ranks_configs4_size", r["err"])
+    assert r["err"] < 2e-3, r
