@@ -589,7 +589,7 @@ def main():
                     sd[1] += fl
                     sd[2] += 1
             if args.shapes:
-                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:70]:
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:160]:
                     print(f"[shape] {k:64s} {v[0] / args.steps * 1e3:8.2f} ms/step {v[2] // args.steps:4d} launches {v[1] / v[0] / 1e12:7.1f} TF/s", file=sys.stderr)
             tot = sum(v[0] for v in fam.values())
             exec_tf = sum(v[4] for v in fam.values()) / args.steps / 1e12

@@ -474,9 +474,10 @@ __device__ __forceinline__ void dma16_masked(unsigned lds_dst, const char* base,
       : "memory");
 }
 
-template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD>
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD, bool KVRES = false>
 __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args a) {
   static_assert(!FOLD || DH % 32 != 0, "FOLD needs a spare k-slot in the last QK^T step");
+  static_assert(!KVRES || !FOLD, "KVRES (keys resident across query blocks) is a form of the classic sweep");
   constexpr int NTHR = 64 * NW;
   constexpr int D32 = (DH + 31) / 32;
   constexpr int DT = (DH + 15) / 16;
@@ -503,9 +504,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   const int l15 = lane & 15;
 
   const int nqb = (a.nq + BQ - 1) / BQ;
-  const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqb);
-  const int qb = w % nqb;
-  const int rest = w / nqb;
+  // KVRES (round 6; the 77-key text cross-attention, attention_2d.py:343): every key of the item fits ONE stage, so a block stages K | V once and
+  // walks `qpb` consecutive query blocks of its (item, head) over it -- LDS image, ones / pad chunks, DMA and barriers paid once per qpb * BQ queries;
+  // the walk itself has no barrier (the waves drift apart and cover each other's Q loads).  qpb travels in the private high bits of general_dual.
+  const int qpb = KVRES ? max(a.general_dual >> 8, 1) : 1;
+  const int nqg = (nqb + qpb - 1) / qpb;
+  const int w = xcd_remap(blockIdx.x, a.n_items * a.heads * nqg);
+  int qb = (w % nqg) * qpb;
+  const int rest = w / nqg;
   // HEAD_SLOWEST (round 5, multi-segment launches): blocks ordered (head, item, query block) -- with 8 heads an XCD's contiguous run is ONE head over all
   // items, so the frame that item f reads as `cur` is still in that XCD's L2 when item f + 1 reads it as `prev` (4 items of a head run at a time on the
   // XCD's 32 CUs: 5 frames x 655 KB of K | V at dh = 40, N = 4096 -- inside the 4 MB).  In the (item, head) order the XCD ran 4 (item, head) pairs of
@@ -1115,43 +1121,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
       }
     }
   };
-  if constexpr (FOLD) {
-    sweep(BT{});
-    // one check per block: could any P have saturated?  P >= 0, so a query's denominator (the sum of its P, accumulated in
-    // fp32 by the ones row of the PV MFMA, or in lrun) bounds every one of them: denominator < 65504 => every P was below
-    // fp16's largest value, i.e. exact.  A saturated P (stored as 65504) always trips it; the test is conservative (flat
-    // attention over more than 65504 keys would trip it too) and costs nothing per tile.
-    // Then phase A's result is discarded: phase B = the classic running-maximum sweep over the same keys with the unscaled Q
-    // (K's ones column then meets a zero k-slot).
-    __shared__ int trip_flag;
-    if (tid == 0) trip_flag = 0;
-    __syncthreads();
-    bool trip = false;
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      // (rows past nq carry a zero query: P = 1 for every key, a denominator of n keys -- they must not trip the block)
-      if constexpr (ONES) trip |= qrow[qt] >= 0 && (g == (DH % 16) / 4) && !(o[qt][DH / 16][(DH % 16) % 4] < 65504.f);
-      else trip |= qrow[qt] >= 0 && !(lrun[qt] < 65504.f);
-    }
-    if (trip) trip_flag = 1;
-    __syncthreads();
-    if constexpr (W32) {   // the epilogue wants the offsets in the accumulators' lane order
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) mrun[qt] = __shfl(mq, qt * 16 + l15, 64);
-    }
-    if (trip_flag) {
-      if (tid == 0) atomicAdd(&g_fallback_blocks, 1ull);   // diagnostic: me_attn_fallback_blocks()
-      load_q(BF{});
-      reset_acc();
-      prime();
-      sweep(BF{});
-    }
-  } else {
-    sweep(BF{});
-  }
-
   // ---- finalize: O^T[d = dt*16 + g*4 + r][q = l15] ----
   const float* __restrict__ vsum = reinterpret_cast<const float*>(a.vsum);
+  auto finalize = [&]() {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     float l;
@@ -1190,6 +1162,131 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
       *reinterpret_cast<uint2*>(O + (long)qrow[qt] * a.ldo + h * DH + d) = ov.u;
     }
   }
+  };
+  // KVRES with 65 .. 80 keys -- the 77-key text cross-attention itself: the item's five 16-key tiles in ONE pass.  Every logit of a query is in registers at
+  // once (QT x 20), so the softmax is the plain one: one maximum, one exp2 sweep, no running rescale, no second 64-key tile that is 80 % padding
+  // (20 + 18 MFMAs per 32 queries instead of 32 + 24, 40 exp2 instead of 64, a quarter of the classic tile's bookkeeping).
+  auto tile80 = [&](const char* st) {
+    constexpr int NT = 5, NKK = 3;
+    static_assert(NSUB >= 2 || !KVRES, "tile80 reads the first tile of the second sub-tile");
+    f32x4 s[QT][NT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) s[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < D32; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 fk = *reinterpret_cast<const f16x8*>(st + (t >> 2) * SUB + ((t & 3) * 16 + l15) * KPB + (ks * 4 + g) * 16);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(fk, fq[qt][ks], s[qt][t]);
+      }
+    }
+    f16x8 pf[QT][NKK];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((NT - 1) * 16 + g * 4 + r >= a.nk) s[qt][NT - 1][r] = NEG_BIG;   // (64 < nk <= 80: only the last tile has keys past nk)
+      float mr = s[qt][0][0];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mr = fmaxf(mr, s[qt][t][r]);
+      mr = xor32_max(xor16_max(mr));
+      const float mnew = mr * c;
+      mrun[qt] = mnew;
+      float psum = 0.f;
+      f16x2 ph[2 * NKK][2];
+#pragma unroll
+      for (int t = 0; t < 2 * NKK; ++t)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          if (t < NT) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][2 * h2], c, -mnew)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qt][t][2 * h2 + 1], c, -mnew));
+            if constexpr (!ONES) psum += p0 + p1;
+            ph[t][h2] = __builtin_convertvector((f32x2){p0, p1}, f16x2);
+          } else {
+            ph[t][h2] = f16x2{(f16)0.f, (f16)0.f};
+          }
+        }
+      if constexpr (!ONES) lrun[qt] = psum;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        union { f16x2 h[4]; f16x8 v; } f;
+        f.h[0] = ph[2 * kk][0]; f.h[1] = ph[2 * kk][1]; f.h[2] = ph[2 * kk + 1][0]; f.h[3] = ph[2 * kk + 1][1];
+        pf[qt][kk] = f.v;
+      }
+    }
+    // O^T = V^T P^T: k-slot (g, j) of step kk = key kk*32 + (j>>2)*16 + g*4 + (j&3), i.e. 16-key tiles 2 kk and 2 kk + 1 (tile 5 does not exist: zeros)
+    const unsigned vlane = (unsigned)(size_t)(st + KBYTES + (g * 4 + (l15 >> 2)) * VPB + (l15 & 3) * 8);
+    static_for(std::make_integer_sequence<int, DT>{}, [&](auto dt_c) {
+      constexpr int dt = decltype(dt_c)::value;
+      uint2 r0 = lds_tr16<0 * 16 * VPB + dt * 32>(vlane), r1 = lds_tr16<1 * 16 * VPB + dt * 32>(vlane);
+      uint2 r2 = lds_tr16<2 * 16 * VPB + dt * 32>(vlane), r3 = lds_tr16<3 * 16 * VPB + dt * 32>(vlane);
+      uint2 r4 = lds_tr16<SUB + dt * 32>(vlane);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4));
+      union { uint2 u[2]; f16x8 v; } f0, f1, f2;
+      f0.u[0] = r0; f0.u[1] = r1;
+      f1.u[0] = r2; f1.u[1] = r3;
+      f2.u[0] = r4; f2.u[1] = uint2{0u, 0u};
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        o[qt][dt] = mfma16(f0.v, pf[qt][0], o[qt][dt]);
+        o[qt][dt] = mfma16(f1.v, pf[qt][1], o[qt][dt]);
+        o[qt][dt] = mfma16(f2.v, pf[qt][2], o[qt][dt]);
+      }
+    });
+  };
+  if constexpr (KVRES) {   // (T == 1: one stage holds every key; prime() above has fetched it)
+    const char* st = smem;
+    for (int it = 0; it < qpb && qb < nqb; ++it, ++qb) {
+      if (it > 0) {
+        load_q(BF{});
+        reset_acc();
+      }
+      if (T > 0) tile80(st);   // (me_attn launches this form for 64 < nk <= 80 only)
+      finalize();
+    }
+    return;
+  }
+  if constexpr (FOLD) {
+    sweep(BT{});
+    // one check per block: could any P have saturated?  P >= 0, so a query's denominator (the sum of its P, accumulated in
+    // fp32 by the ones row of the PV MFMA, or in lrun) bounds every one of them: denominator < 65504 => every P was below
+    // fp16's largest value, i.e. exact.  A saturated P (stored as 65504) always trips it; the test is conservative (flat
+    // attention over more than 65504 keys would trip it too) and costs nothing per tile.
+    // Then phase A's result is discarded: phase B = the classic running-maximum sweep over the same keys with the unscaled Q
+    // (K's ones column then meets a zero k-slot).
+    __shared__ int trip_flag;
+    if (tid == 0) trip_flag = 0;
+    __syncthreads();
+    bool trip = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      // (rows past nq carry a zero query: P = 1 for every key, a denominator of n keys -- they must not trip the block)
+      if constexpr (ONES) trip |= qrow[qt] >= 0 && (g == (DH % 16) / 4) && !(o[qt][DH / 16][(DH % 16) % 4] < 65504.f);
+      else trip |= qrow[qt] >= 0 && !(lrun[qt] < 65504.f);
+    }
+    if (trip) trip_flag = 1;
+    __syncthreads();
+    if constexpr (W32) {   // the epilogue wants the offsets in the accumulators' lane order
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) mrun[qt] = __shfl(mq, qt * 16 + l15, 64);
+    }
+    if (trip_flag) {
+      if (tid == 0) atomicAdd(&g_fallback_blocks, 1ull);   // diagnostic: me_attn_fallback_blocks()
+      load_q(BF{});
+      reset_acc();
+      prime();
+      sweep(BF{});
+    }
+  } else {
+    sweep(BF{});
+  }
+
+  finalize();
 }
 
 // column sums of V per kv item: vsum[kit][c] = sum_key V[kit*nk + key][c], fp32 (the query-independent "+1" part of the
@@ -1234,20 +1331,33 @@ __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restric
   out[i] = sacc;
 }
 
-template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD = (DH % 32 != 0)>
+template <int DH, int QT, int NW, int MINW, int NBUF, int NSUB, bool FOLD = (DH % 32 != 0), bool KVRES = false>
 int launch_attn2(const me_attn_args* a, hipStream_t st) {
   constexpr int BQ = 16 * QT * NW;
   const int nqb = (a->nq + BQ - 1) / BQ;
-  const long total = (long)a->n_items * a->heads * nqb;
+  long total = (long)a->n_items * a->heads * nqb;
   me_attn_args b = *a;
   {   // block order (see attn2_kernel): heads slowest for launches whose items share K | V frames with their neighbours (>= 2 segments); ME_ATTN_ORDER=0: A/B
     const char* e = getenv("ME_ATTN_ORDER");
     if (a->nseg >= 2 && !(e && e[0] == '0')) b.general_dual |= ATTN_HEAD_SLOWEST;
   }
-  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD>), dim3((unsigned)total), dim3(64 * NW), 0, st, b);
+  if constexpr (KVRES) {
+    // query blocks per block: the largest divisor of nqb that still leaves >= 6 blocks per CU (three rounds of the two resident ones) -- each block stages
+    // its K | V once; the walk length hardly matters beyond 4 (tools/exp_kvres_qpanels.py, profiles/r06_attn_kvres.txt)
+    int qpb = 1;
+    for (int d = 1; d <= nqb; ++d)
+      if (nqb % d == 0 && (long)a->n_items * a->heads * (nqb / d) >= 1536) qpb = d;
+    if (const char* e = getenv("ME_ATTN_KVRES")) {   // tests: ME_ATTN_KVRES=n (n >= 2) forces n query blocks per block, divisor of nqb or not
+      const int n = atoi(e);
+      if (n >= 2) qpb = n < nqb ? n : nqb;
+    }
+    b.general_dual |= qpb << 8;
+    total = (long)a->n_items * a->heads * ((nqb + qpb - 1) / qpb);
+  }
+  hipLaunchKernelGGL((attn2_kernel<DH, QT, NW, MINW, NBUF, NSUB, FOLD, KVRES>), dim3((unsigned)total), dim3(64 * NW), 0, st, b);
   {
     char nm[64];
-    snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d,%s>", DH, QT, NW, FOLD ? "fold" : "classic");   // (the two variants of a shape are different kernels: bench.py / pmc_summary.py key on this)
+    snprintf(nm, sizeof(nm), "attn2_kernel<%d,%d,%d,%s>", DH, QT, NW, KVRES ? "kvres" : (FOLD ? "fold" : "classic"));   // (the variants of a shape are different kernels: bench.py / pmc_summary.py key on this)
     me_set_kernel(nm);
   }
   return hipGetLastError() == hipSuccess ? ME_OK : ME_EHIP;
@@ -1319,6 +1429,10 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
     // 8 waves x 32 queries when the launch has whole 256-query blocks (halves the K/V fill per query), else 4 waves
     static const bool fold_on = !(getenv("ME_ATTN_FOLD") && atoi(getenv("ME_ATTN_FOLD")) == 0);
     const bool fold = fold_on && a->nk >= 256;
+    // keys resident across query blocks (round 6): one segment of 65 .. 80 keys -- the 77-key text cross-attention (attention_2d.py:343) -- with whole
+    // multi-block query items.  ME_ATTN_KVRES=0: A/B switch (read per call: the tests flip it in-process).
+    const char* kvr = getenv("ME_ATTN_KVRES");
+    const bool kvres = a->nseg == 1 && a->nk > 64 && a->nk <= 80 && !a->vsum && !(kvr && kvr[0] == '0');
     switch (a->dh) {
       // fold (speculative fixed-offset softmax with the classic sweep as in-kernel fallback) pays from a few tiles per query on:
       // its start-up is one extra QK^T tile.  The 77-key text cross-attention stays classic.  ME_ATTN_FOLD=0: A/B switch.
@@ -1328,10 +1442,12 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
 #if !defined(ME_ATTN_NW16) || ME_ATTN_NW16
         if (fold && a->nq >= 512) { rc = launch_attn2<40, 2, 16, 4, 2, 4, true>(a, st); break; }
 #endif
+        if (kvres && a->nq >= 512) { rc = launch_attn2<40, 2, 8, 4, 1, 2, false, true>(a, st); break; }
         if (fold) rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, true>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, true>(a, st);
         else rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, false>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, false>(a, st);
         break;
       case 80:
+        if (kvres && a->nq >= 256) { rc = launch_attn2<80, 1, 8, 3, 1, 2, false, true>(a, st); break; }
         if (fold) rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, true>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, true>(a, st);
         else rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, false>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, false>(a, st);
         break;

@@ -633,8 +633,11 @@ __device__ __forceinline__ void epilogue_geglu_rowpass(const me_gemm_args& a, f3
 #pragma unroll
     for (int jj = 0; jj < NO; ++jj) {
       float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * gelu_sigpoly(acc[2 * jj + 1][i][r]);   // alpha == 1 (me_gemm checks)
+      {   // alpha == 1 (me_gemm checks)
+        const f32x2 v01 = geglu2(f32x2{acc[2 * jj][i][0], acc[2 * jj][i][1]}, f32x2{acc[2 * jj + 1][i][0], acc[2 * jj + 1][i][1]});
+        const f32x2 v23 = geglu2(f32x2{acc[2 * jj][i][2], acc[2 * jj][i][3]}, f32x2{acc[2 * jj + 1][i][2], acc[2 * jj + 1][i][3]});
+        v[0] = v01[0]; v[1] = v01[1]; v[2] = v23[0]; v[3] = v23[1];
+      }
       union { f16x2 h[2]; uint2 u; } o;
       o.h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
       o.h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
@@ -730,8 +733,11 @@ __device__ __forceinline__ void epilogue_geglu(const me_gemm_args& a, f32x4 (&ac
 #pragma unroll
     for (int jj = 0; jj < NO; ++jj) {
       float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[2 * jj][i][r] * gelu_sigpoly(acc[2 * jj + 1][i][r]);   // alpha == 1 (me_gemm checks)
+      {   // alpha == 1 (me_gemm checks)
+        const f32x2 v01 = geglu2(f32x2{acc[2 * jj][i][0], acc[2 * jj][i][1]}, f32x2{acc[2 * jj + 1][i][0], acc[2 * jj + 1][i][1]});
+        const f32x2 v23 = geglu2(f32x2{acc[2 * jj][i][2], acc[2 * jj][i][3]}, f32x2{acc[2 * jj + 1][i][2], acc[2 * jj + 1][i][3]});
+        v[0] = v01[0]; v[1] = v01[1]; v[2] = v23[0]; v[3] = v23[1];
+      }
       o[i][jj].h[0] = __builtin_convertvector((f32x2){v[0], v[1]}, f16x2);
       o[i][jj].h[1] = __builtin_convertvector((f32x2){v[2], v[3]}, f16x2);
     }

@@ -104,6 +104,28 @@ __device__ __forceinline__ float gelu_sigpoly(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(q * x));
 }
 
+// a * gelu_sigpoly(g) on two values per lane with packed fp32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: the polynomial's 4 FMAs, 3 multiplications and the
+// addition, and the gate's product, at half the issue slots; the two exp2 / rcp stay scalar).  Element for element the same operations in the same order
+// as the scalar form -- IEEE fma / mul per element -- so the results are bitwise those of a * gelu_sigpoly(g).  ME_GELU_PK=0 builds the scalar form (A/B).
+#ifndef ME_GELU_PK
+#define ME_GELU_PK 1
+#endif
+__device__ __forceinline__ f32x2 geglu2(f32x2 av, f32x2 x) {
+#if ME_GELU_PK
+  const f32x2 x2 = x * x;
+  f32x2 q = __builtin_elementwise_fma(f32x2{-3.2291018214891665e-06f, -3.2291018214891665e-06f}, x2, f32x2{8.824012184049934e-05f, 8.824012184049934e-05f});
+  q = __builtin_elementwise_fma(q, x2, f32x2{0.00036026412271894515f, 0.00036026412271894515f});
+  q = __builtin_elementwise_fma(q, x2, f32x2{-0.10522667318582535f, -0.10522667318582535f});
+  q = __builtin_elementwise_fma(q, x2, f32x2{-2.3020453453063965f, -2.3020453453063965f});
+  const f32x2 t = q * x;
+  const f32x2 d = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+  const f32x2 g = x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  return av * g;
+#else
+  return f32x2{av[0] * gelu_sigpoly(x[0]), av[1] * gelu_sigpoly(x[1])};
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

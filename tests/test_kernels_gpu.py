@@ -446,6 +446,39 @@ def test_attention_cross_text_77_keys(ops, dh, nq):
     check(got, emu.attention(q, kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, **args), f"attn cross dh={dh}")
 
 
+@pytest.mark.parametrize("dh,nq,nk,B,f,il", [(40, 4096, 77, 2, 3, False), (40, 1024, 77, 4, 2, True), (40, 600, 80, 2, 2, False), (40, 512, 65, 1, 2, False),
+                                             (80, 1024, 77, 2, 3, False), (80, 320, 70, 2, 2, True), (80, 256, 77, 4, 24, False)])
+def test_attention_keys_resident_across_query_blocks(ops, dh, nq, nk, B, f, il):
+    """Round 6: the text cross-attention (attention_2d.py:343; one segment of 65 .. 80 keys) stages its K | V once per block, walks several query blocks over
+    it and takes all five 16-key tiles of a query in one pass (attn2_kernel<..., KVRES>: plain softmax, no running rescale).  Against the fp32 reference and
+    against the per-query-block launch (ME_ATTN_KVRES=0: the online softmax over two 64-key tiles -- another summation order, so close, not bitwise);
+    bitwise among walks of different lengths (ME_ATTN_KVRES=n: n query blocks per block, a divisor of the item's block count or not).  Cases: the level-0 /
+    level-1 shapes, a ragged last query block, 80 and 65 keys, the ControlNet's interleaved text rows (pipeline_motion_editor.py:615,621), enough items
+    that the launcher's own choice walks only part of an item."""
+    import os
+    from motioneditor_amd import segments
+    C = 8 * dh
+    q, kv = rnd(B * f * nq, C, seed=1), rnd(B * nk, 2 * C, seed=2)
+    si, sm = segments.cross_interleaved(B * f, B, "cpu") if il else segments.cross_text(B, f, "cpu")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=nq, nk=nk)
+    cq, ck, cv, csi, csm = cu(q), cu(kv)[:, :C], cu(kv)[:, C:], cu(si), cu(sm)
+    got = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)   # (the launcher's own choice of the walk)
+    assert "kvres" in ops._last_kernel()
+    try:
+        os.environ["ME_ATTN_KVRES"] = "0"
+        ref = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)
+        assert "kvres" not in ops._last_kernel()
+        assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max())
+        for force in ("2", "3", "16"):
+            os.environ["ME_ATTN_KVRES"] = force
+            walk = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)
+            assert "kvres" in ops._last_kernel()
+            assert torch.equal(walk, got), force
+    finally:
+        os.environ.pop("ME_ATTN_KVRES", None)
+    check(got, emu.attention(q, kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, **args), f"attn cross kvres dh={dh} nq={nq} nk={nk}")
+
+
 @pytest.mark.parametrize("dh,N,binary", [(40, 64, True), (80, 16, True), (40, 256, True), (40, 64, False), (80, 144, True)])
 def test_attention_edited_dual_mask_5N_keys(ops, dh, N, binary):
     """The spatial editor's masked attention: recon rows [prev|cur], edit rows [src prev dual | src cur dual | own cur]

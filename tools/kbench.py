@@ -359,6 +359,31 @@ def bench_attn_order():
     os.environ.pop("ME_ATTN_ORDER", None)
 
 
+def bench_attn_kvres():
+    """The 77-key text cross-attention with K | V resident across query blocks (round 6, attn2_kernel<..., KVRES>; ME_ATTN_KVRES flips per call): same
+    process, alternating, bitwise check.  GB/s = Q read + O written (the launch's algorithmic bytes; K | V are 4 x 77 rows)."""
+    import os
+    B, f = 4, 24
+    print(f"{'cross-attention, 77 keys':28s} {'per-block ms':>13s} {'resident ms':>12s} {'x':>6s} {'GB/s':>7s}  vs per-block")
+    for name, dh, N, items, il in [("L0 UNet", 40, 4096, B * f, False), ("L0 ControlNet", 40, 4096, 2 * f, True), ("L1 UNet", 80, 1024, B * f, False), ("L1 ControlNet", 80, 1024, 2 * f, True)]:
+        C = 8 * dh
+        q = rnd(items * N, C)
+        kv = rnd(B * 77, 2 * C)
+        si, sm = segments.cross_interleaved(items, 2, dev) if il else segments.cross_text(B, f, dev)
+        fn = lambda: ops.attention(q, kv[:, :C], kv[:, C:], heads=8, dh=dh, n_items=items, nq=N, nk=77, seg_item=si, seg_mode=sm)
+        res = {}
+        for rep in range(2):
+            for sw in ("0", "1"):
+                os.environ["ME_ATTN_KVRES"] = sw
+                out = fn()
+                res.setdefault(sw, []).append(timeit(fn))
+                res["out" + sw] = out
+        t0, t1 = min(res["0"]), min(res["1"])
+        print(f"{name:28s} {t0:13.4f} {t1:12.4f} {t0 / t1:6.3f} {2 * items * N * C * 2 / t1 / 1e6:7.0f}  max |diff| {float((res['out0'].float() - res['out1'].float()).abs().max()):.2e}", flush=True)
+        del q, kv
+    os.environ.pop("ME_ATTN_KVRES", None)
+
+
 def bench_attn_headmajor():
     """Experiment: the L0 [prev|cur] launch with K/V (and Q) stored head-major (contiguous 80-byte rows per head): heads folded into the batch axis."""
     B, f, dh, N = 4, 24, 40, 4096
@@ -491,6 +516,8 @@ if __name__ == "__main__":
         bench_gemm_cached()
     if "attnorder" in what:
         bench_attn_order()
+    if "attnkvres" in what:
+        bench_attn_kvres()
     if "attnhm" in what:
         bench_attn_headmajor()
     if "attnhmp" in what:
