@@ -495,7 +495,9 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   constexpr int BQ = 16 * QT * NW;
   static_assert(KBYTES % 1024 == 0 && VBYTES % 1024 == 0, "stage layout");
 
-  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE + 64];
+  // KVRES: + a wave-private scratch of QT * 16 rows x dh halves, where the output tile turns from the MFMA layout into whole 16-byte row pieces (finalize_rows)
+  constexpr int OROWS = QT * 16, OSCR = KVRES ? OROWS * DH * 2 : 0;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * STAGE + 64 + NW * OSCR];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1065,19 +1067,22 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
   // denominator keep full fp16 precision (re-basing all the way down to 1, as a running maximum does, pushed the light keys of a peaky row
   // into fp16's subnormals: 2-3 ulp on such rows instead of 1).  One compare and a wave-uniform branch per query tile and stage; only a
   // jump of more than ~2^7 in the denominator inside ONE stage still ends in phase B.
+  // (a lane without the ones row tests its QUARTER of the denominator; where a stage holds 128 keys -- dh = 80 at 32 queries per wave -- the test comes half
+  // as often per key, so its threshold is a quarter: the growth one test interval may bring, 65504 / (4 x threshold), stays 2^7)
+  constexpr float REBASE_LANE = (!ONES && NSUB > 1) ? REBASE_AT * 0.25f : REBASE_AT;
   auto rebase = [&]() {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float lq;
       if constexpr (ONES) lq = (g == (DH % 16) / 4) ? o[qt][DH / 16][(DH % 16) % 4] : 0.f;   // the ones row of the PV accumulators
       else lq = lrun[qt];                                                                     // this lane's share of the denominator
-      if (__builtin_amdgcn_readfirstlane(__any(lq > REBASE_AT))) {
+      if (__builtin_amdgcn_readfirstlane(__any(lq > REBASE_LANE))) {
         float l;
         if constexpr (ONES) l = __shfl(o[qt][DH / 16][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
         else l = xor32_sum(xor16_sum(lrun[qt]));
         // per query (lane column); the four lane groups of a query agree.  A denominator at or beyond 65504 may already contain a saturated P:
         // that query is left alone -- its denominator can only grow, and the check after the sweep sends the block to phase B.
-        const float d = (l > REBASE_AT && l < 65504.f) ? ceilf(__log2f(l)) - REBASE_TO_LOG2 : 0.f;
+        const float d = (l > REBASE_LANE && l < 65504.f) ? ceilf(__log2f(l)) - REBASE_TO_LOG2 : 0.f;
         const float sc = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] *= sc;
@@ -1239,6 +1244,39 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
       }
     });
   };
+  // KVRES epilogue: the launch is paced by the CU's in-order memory pipeline (profiles/r06_attn_kvres.txt: loads + arithmetic 0.09 ms, with the direct
+  // epilogue's stores 0.196 -- 8-byte stores that touch 16 rows each), so the wave parks its fp16 tile in its private LDS scratch (MFMA layout: lane (q, g)
+  // holds 4 consecutive d of query q) and stores it as 16-byte pieces of whole dh-wide row slices, 12.8 / 6.4 rows per instruction instead of 16 rows per
+  // HALF-size instruction.  Wave-private, LDS operations of a wave execute in order: no barrier.
+  auto finalize_rows = [&]() {
+    constexpr int PITCH = DH * 2, CPR = DH / 8, NPIECE = OROWS * CPR, NIT = (NPIECE + 63) / 64;
+    char* sc = smem + NBUF * STAGE + 64 + wave * OSCR;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float l;
+      if constexpr (ONES) l = __shfl(o[qt][DH / 16][(DH % 16) % 4], ((DH % 16) / 4) * 16 + l15, 64);
+      else l = xor32_sum(xor16_sum(lrun[qt]));
+      if (a.lse && g == 0 && qrow[qt] >= 0) reinterpret_cast<float*>(a.lse)[(long)qrow[qt] * a.heads + h] = mrun[qt] + __log2f(l);
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = dt * 16 + g * 4;
+        if (d >= DH) continue;
+        U64 ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov.e[r] = (f16)(o[qt][dt][r] * inv);
+        *reinterpret_cast<uint2*>(sc + (qt * 16 + l15) * PITCH + d * 2) = ov.u;
+      }
+    }
+    const int q0 = qb * BQ + wave * OROWS;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int p = i * 64 + lane;
+      const int row = p / CPR, ch = p - row * CPR;
+      if (p < NPIECE && q0 + row < a.nq)
+        *reinterpret_cast<uint4*>(O + ((long)item * a.nq + q0 + row) * a.ldo + h * DH + ch * 8) = *reinterpret_cast<const uint4*>(sc + row * PITCH + ch * 16);
+    }
+  };
   if constexpr (KVRES) {   // (T == 1: one stage holds every key; prime() above has fetched it)
     const char* st = smem;
     for (int it = 0; it < qpb && qb < nqb; ++it, ++qb) {
@@ -1246,8 +1284,14 @@ __global__ __launch_bounds__(64 * NW, MINW) void attn2_kernel(const me_attn_args
         load_q(BF{});
         reset_acc();
       }
-      if (T > 0) tile80(st);   // (me_attn launches this form for 64 < nk <= 80 only)
-      finalize();
+#ifndef ME_KVRES_ABL   // ablation builds (tools/build_abl.sh): 1 = no tile arithmetic, 2 = no O stores (an impossible condition keeps the code alive)
+#define ME_KVRES_ABL 0
+#endif
+      if (T > 0 && !(ME_KVRES_ABL & 1)) tile80(st);   // (me_attn launches this form for 64 < nk <= 80 only)
+      if (!(ME_KVRES_ABL & 2) || a.nk < 0) {
+        if (ME_KVRES_ABL & 4) finalize();   // (ablation: the direct epilogue)
+        else finalize_rows();
+      }
     }
     return;
   }
@@ -1432,7 +1476,7 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
     // keys resident across query blocks (round 6): one segment of 65 .. 80 keys -- the 77-key text cross-attention (attention_2d.py:343) -- with whole
     // multi-block query items.  ME_ATTN_KVRES=0: A/B switch (read per call: the tests flip it in-process).
     const char* kvr = getenv("ME_ATTN_KVRES");
-    const bool kvres = a->nseg == 1 && a->nk > 64 && a->nk <= 80 && !a->vsum && !(kvr && kvr[0] == '0');
+    const bool kvres = a->nseg == 1 && a->nk > 64 && a->nk <= 80 && !a->vsum && a->ldo % 8 == 0 && !((uintptr_t)a->O & 15) && !(kvr && kvr[0] == '0');
     switch (a->dh) {
       // fold (speculative fixed-offset softmax with the classic sweep as in-kernel fallback) pays from a few tiles per query on:
       // its start-up is one extra QK^T tile.  The 77-key text cross-attention stays classic.  ME_ATTN_FOLD=0: A/B switch.
@@ -1442,16 +1486,29 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
 #if !defined(ME_ATTN_NW16) || ME_ATTN_NW16
         if (fold && a->nq >= 512) { rc = launch_attn2<40, 2, 16, 4, 2, 4, true>(a, st); break; }
 #endif
-        if (kvres && a->nq >= 512) { rc = launch_attn2<40, 2, 8, 4, 1, 2, false, true>(a, st); break; }
+#ifndef ME_KV40_QT   // (experiment builds: query tiles per wave / waves per SIMD of the resident-key kernel)
+#define ME_KV40_QT 2
+#define ME_KV40_MINW 4
+#endif
+        if (kvres && a->nq >= 512) { rc = launch_attn2<40, ME_KV40_QT, 8, ME_KV40_MINW, 1, 2, false, true>(a, st); break; }
         if (fold) rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, true>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, true>(a, st);
         else rc = a->nq >= 256 ? launch_attn2<40, 2, 8, 4, 2, 2, false>(a, st) : launch_attn2<40, 2, 4, 3, 2, 1, false>(a, st);
         break;
       case 80:
         if (kvres && a->nq >= 256) { rc = launch_attn2<80, 1, 8, 3, 1, 2, false, true>(a, st); break; }
+        // 8 waves x 32 queries and 128 keys per barrier when the launch has whole 256-query blocks (round 6): at 16 queries per wave every K / V fragment read
+        // from LDS feeds ONE MFMA (22 KB of fragment reads per 22 MFMAs: the LDS pipe as busy as the matrix pipe); 32 queries halve that.  Level-1 [prev | cur]
+        // 0.702 -> 0.648 ms, edited 0.888 -> 0.819, bitwise the same output (profiles/r06_attn80_qt2.txt; with 64-key stages: +-0).  ME_ATTN_80_QT2=0: A/B.
+        if (fold && a->nq >= 256) {
+          const char* e = getenv("ME_ATTN_80_QT2");
+          if (!(e && e[0] == '0')) { rc = launch_attn2<80, 2, 8, 2, 2, 2, true>(a, st); break; }
+        }
         if (fold) rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, true>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, true>(a, st);
         else rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, false>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, false>(a, st);
         break;
-      case 160: rc = launch_attn2<160, 1, 4, 2, 1, 1>(a, st); break;
+      case 160:
+        rc = launch_attn2<160, 1, 4, 2, 1, 1>(a, st);
+        break;
       default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;
     }
   }

@@ -479,6 +479,36 @@ def test_attention_keys_resident_across_query_blocks(ops, dh, nq, nk, B, f, il):
     check(got, emu.attention(q, kv[:, :C], kv[:, C:], seg_item=si, seg_mode=sm, **args), f"attn cross kvres dh={dh} nq={nq} nk={nk}")
 
 
+@pytest.mark.parametrize("kind,N", [("pc", 1024), ("ed_bin", 1024), ("pc", 300)])
+def test_attention_dh80_32_queries_per_wave(ops, kind, N):
+    """Round 6: the dh = 80 launches with whole 256-query blocks take 8 waves x 32 queries and 128-key stages (every K / V fragment read feeds two MFMAs).
+    Same tile arithmetic per query as the 16-queries-per-wave kernel (ME_ATTN_80_QT2=0) -- only the re-basing points of the fixed-offset softmax move with the
+    stage length, so the two agree to rounding (bitwise on data that never re-bases) -- and both against the fp32 reference."""
+    import os
+    from motioneditor_amd import segments
+    dh, f = 80, 3
+    C = 8 * dh
+    B = 4 if kind == "ed_bin" else 2
+    qkv = rnd(B * f * N, 3 * C, seed=5)
+    g = torch.Generator().manual_seed(9)
+    mask = (torch.rand(8, N, generator=g) > 0.5).half() if kind == "ed_bin" else None
+    si, sm = segments.edited_spatial(f, "cpu", True) if kind == "ed_bin" else segments.prev_cur(B, f, "cpu")
+    args = dict(heads=8, dh=dh, n_items=B * f, nq=N, nk=N)
+    c = cu(qkv)
+    run = lambda: ops.attention(c[:, :C], c[:, C:2 * C], c[:, 2 * C:], seg_item=cu(si), seg_mode=cu(sm), mask=None if mask is None else cu(mask), **args)
+    got = run()
+    assert ops._last_kernel() == "attn2_kernel<80,2,8,fold>"
+    try:
+        os.environ["ME_ATTN_80_QT2"] = "0"
+        ref = run()
+        assert ops._last_kernel() == "attn2_kernel<80,1,8,fold>"
+    finally:
+        os.environ.pop("ME_ATTN_80_QT2", None)
+    assert float((got.float() - ref.float()).abs().max()) <= 1e-3 * float(ref.float().abs().max())
+    want = emu.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], seg_item=si, seg_mode=sm, mask=mask, **args)
+    check(got, want, f"attn dh=80 QT=2 {kind} N={N}")
+
+
 @pytest.mark.parametrize("dh,N,binary", [(40, 64, True), (80, 16, True), (40, 256, True), (40, 64, False), (80, 144, True)])
 def test_attention_edited_dual_mask_5N_keys(ops, dh, N, binary):
     """The spatial editor's masked attention: recon rows [prev|cur], edit rows [src prev dual | src cur dual | own cur]
