@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const me_gemm_args a) {
   constexpr int GR = BM / 2, HALF = GR / 2, MH = HALF / 16, MT = 2 * MH;
   constexpr int NPA = 2 * HALF / 8;   // 8-row DMA pieces per A part (both wave groups): 16, or 12 -- then waves 4-7 issue one piece, waves 0-3 two
   constexpr int ABYTES = BM * 128, BUFBYTES = (BM + BN) * 128;
-  static_assert(BN % 64 == 0 && NT1 >= 1 && HALF % 16 == 0 && NPA > 8 && NPA <= 16, "wave tile");
+  static_assert(BN % 64 == 0 && NT1 >= 1 && HALF % 16 == 0 && NPA >= 8 && NPA <= 16, "wave tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A BM rows | B BN rows][128 B], then (GATHER) the source-row table [taps][256]
 
   const int tid = threadIdx.x;
@@ -1632,8 +1632,24 @@ bool tile_order_exp() {   // ME_GEMM_TILE_ORDER=1: row blocks fastest inside an 
 
 long min_tiles_192() {   // ME_GEMM_8P_192: smallest grid (in 192 x 320 tiles) that takes the 192-row 8-phase kernel (0 = never)
   const char* e = getenv("ME_GEMM_8P_192");
-  const long v = e ? atol(e) : 448;
+  const long v = e ? atol(e) : 192;
   return v > 0 ? v : (1L << 60);
+}
+
+long min_tiles_128() {   // ME_GEMM_8P_128: smallest grid (in 128 x 320 tiles) that takes the 128-row 8-phase kernel (0 = never; read per call)
+  const char* e = getenv("ME_GEMM_8P_128");
+  const long v = e ? atol(e) : 192;
+  return v > 0 ? v : (1L << 60);
+}
+
+long geglu_min_tiles() {   // ME_GEMM_GEGLU_MIN: smallest grid (in 256 x 256 tiles) that takes the 8-phase GEGLU kernel (read per call: tools/ flip it)
+  const char* e = getenv("ME_GEMM_GEGLU_MIN");
+  return e ? atol(e) : 240;
+}
+
+int min_ktiles_192() {   // ME_GEMM_192_MINK: fewest K tiles (of 64) for the 192-row 8-phase kernel (read per call: tools/kbench.py flips it)
+  const char* e = getenv("ME_GEMM_192_MINK");
+  return e ? atoi(e) : 4;
 }
 
 long n64_below() {   // ME_GEMM_N64_BELOW: grids of fewer 128 x 128 tiles than this take 128 x 64 tiles (M = 1536 convolutions: 0.136 -> 0.117 ms)
@@ -1877,6 +1893,9 @@ static int gemm_dispatch(const me_gemm_args* a, void* stream) {
     const bool buf = a->K % 64 == 0 && buf_stage();   // scalar-offset buffer staging (no K tail, no packed-tap mode)
     const int nit8 = (a->K / 64) * (a->gather == ME_GATHER_CONV3 ? 9 : (a->gather == ME_GATHER_TCONV ? 3 : 1));
     const bool dense = a->gather == ME_GATHER_DENSE;
+    // GEGLU on the 256-wide 8-phase kernel from geglu_min_tiles() tiles of 256 x 256 on (round 6: its own threshold -- it used to share the 256 x 320 kernels')
+    if (a->geglu && dense && buf && use_8p() > 0 && nit8 >= use_8p() && a->N % 256 == 0 && (long)((Msel + 255) / 256) * (a->N / 256) >= geglu_min_tiles())
+      return launch_gemm8p<256, 256, false>(a, st);
     if (a->N % 320 == 0 && big_blocks >= big_min_blocks()) {
       // the 8-phase kernel: K tiles of 64, at least use_8p() of them; GEGLU pairs (value, gate) column tiles inside a wave -> 256-wide
       // tiles with 4 column tiles per wave (every GEGLU width of the model, 2560 ... 10240, is a multiple of 256)
@@ -1889,8 +1908,12 @@ static int gemm_dispatch(const me_gemm_args* a, void* stream) {
     // grids of 256 < tiles < 512 (the M = 24576 level at N = 1280: 384 tiles = 1.5 rounds of the 256 CUs): 192-row tiles of the 8-phase kernel
     // make it 512 = 2 full rounds
     // (K >= 512 only: the K = 320 projections of this size are bound by their residual / output traffic and measured 7 % slower)
-    if (a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= 8 && nit8 >= use_8p() && (long)((Msel + 191) / 192) * (a->N / 320) >= min_tiles_192())
+    if (a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= min_ktiles_192() && nit8 >= use_8p() && (long)((Msel + 191) / 192) * (a->N / 320) >= min_tiles_192())
       return dense ? launch_gemm8p<192, 320, false>(a, st) : launch_gemm8p<192, 320, true>(a, st);
+    // ... and 128-row tiles of it (round 6) for DENSE grids from min_tiles_128() tiles of 128 x 320 on (the M = 6144 level at N = 1280: 192 tiles): +4 ... 30 % with
+    // terms / row sums, +-0 without; the gather form measured 10 % SLOWER than 128 x 128 tiles there and stays out (profiles/r06_gemm_dispatch.txt)
+    if (dense && a->N % 320 == 0 && !a->geglu && buf && use_8p() > 0 && nit8 >= min_ktiles_192() && nit8 >= use_8p() && (long)((Msel + 127) / 128) * (a->N / 320) >= min_tiles_128())
+      return launch_gemm8p<128, 320, false>(a, st);
     // small grids (level 3 / mid block / ControlNet): 128-wide N tiles give 25 % more blocks until the 256 CUs have
     // two each (+8 % on those shapes; 64-row tiles measured worse)
     const long blocks160 = (long)((Msel + 127) / 128) * ((a->N + 159) / 160);

@@ -310,12 +310,15 @@ def basic_block(P: Packed, p: str, x: Act, text: Optional[torch.Tensor], text_se
             a = spatial(call=call, is_cross=True, place_in_unet=place, num_heads=HEADS, text_seg=text_seg)
         else:
             a = call.run(*text_seg)
+        if expand > 1:
+            # from here on the launches hold the full batch -- the attention output `a` already does: me_gemm selects their kernels by their own row count again
+            # (unet_forward set the scale for the shared sub-batch; the 8-phase and the 128-row kernels leave different partial row sums behind and round a
+            # LayerNorm-folded projection differently, so the choice has to be the full launch's.  Round 6: the reset stood BEHIND this projection, which then
+            # chose as for twice the batch -- harmless until the 192-row 8-phase kernel took grids that small)
+            ops.SELECT_ROWS_SCALE = 1
         t, st = _gemm_st(a, P.mat(p + ".attn2.to_out.0.weight"), bias=P.vec(p + ".attn2.to_out.0.bias"), res=t, **({"res_rows": t.shape[0]} if expand > 1 else {}))
         if expand > 1:
             x = Act(t, x.B * expand, x.f, x.h, x.w)
-            # from here on the launches hold the full batch: me_gemm selects their kernels by their own row count again (unet_forward set the scale for the
-            # shared sub-batch; the 8-phase and the 128-row kernels round a LayerNorm-folded projection differently, so the choice has to be the full launch's)
-            ops.SELECT_ROWS_SCALE = 1
     # --- feed-forward (attention_2d.py:531)
     t, st = feed_forward(P, p + ".ff", LN(P, p + ".norm3", t, st), t, want_stats=has_temp)
     # --- temporal attention over frames, causal (attention_2d.py:534-545)
