@@ -40,6 +40,10 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('ME_LN_FOLD=$v', d['ms_per_step'], 'ms/step', {k:v['ms_per_step'] for k,v in d['kernel_families'].items()}, 'launches', d['launch_plan']['launches'])" >> $ab
   done
 done
+# later in the round: the resident-key cross-attention, dh = 80 at 32 queries per wave, the dispatch thresholds (A/B on this box)
+timeout 200 python tools/kbench.py attnkvres > gpurun_out/${tag}_kbench_attnkvres.txt 2>&1
+timeout 200 python tools/exp_attn80.py > gpurun_out/${tag}_attn80.txt 2>&1
+timeout 600 bash tools/exp_dispatch_ab.sh > gpurun_out/${tag}_dispatch_ab_collection_box.txt 2>&1
 # secondary workloads
 sec=gpurun_out/${tag}_secondary.jsonl
 : > $sec
