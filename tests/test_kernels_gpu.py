@@ -462,13 +462,16 @@ def test_attention_keys_resident_across_query_blocks(ops, dh, nq, nk, B, f, il):
     si, sm = segments.cross_interleaved(B * f, B, "cpu") if il else segments.cross_text(B, f, "cpu")
     args = dict(heads=8, dh=dh, n_items=B * f, nq=nq, nk=nk)
     cq, ck, cv, csi, csm = cu(q), cu(kv)[:, :C], cu(kv)[:, C:], cu(si), cu(sm)
-    got = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)   # (the launcher's own choice of the walk)
+    lse = torch.empty(B * f * nq, 8, dtype=torch.float32, device="cuda")   # (the log-sum-exp the backward reads: written by both forms)
+    got = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, lse=lse, **args)   # (the launcher's own choice of the walk)
     assert "kvres" in ops._last_kernel()
     try:
         os.environ["ME_ATTN_KVRES"] = "0"
-        ref = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)
+        lse_ref = torch.empty_like(lse)
+        ref = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, lse=lse_ref, **args)
         assert "kvres" not in ops._last_kernel()
         assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * float(ref.float().abs().max())
+        assert float((lse - lse_ref).abs().max()) <= 1e-4 * max(1.0, float(lse_ref.abs().max()))
         for force in ("2", "3", "16"):
             os.environ["ME_ATTN_KVRES"] = force
             walk = ops.attention(cq, ck, cv, seg_item=csi, seg_mode=csm, **args)
