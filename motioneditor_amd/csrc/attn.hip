@@ -1507,6 +1507,8 @@ extern "C" int me_attn(const me_attn_args* a, void* stream) {
         else rc = a->nq >= 128 ? launch_attn2<80, 1, 8, 3, 2, 1, false>(a, st) : launch_attn2<80, 2, 4, 2, 2, 1, false>(a, st);
         break;
       case 160:
+        // (level 2: 256 queries per item -- two 128-query blocks walk the staged keys; 0.080 -> 0.062 ms per launch, profiles/r06_attn_kvres.txt)
+        if (kvres && a->nq >= 256) { rc = launch_attn2<160, 1, 8, 2, 1, 2, false, true>(a, st); break; }
         rc = launch_attn2<160, 1, 4, 2, 1, 1>(a, st);
         break;
       default: me_set_error("me_attn: head dim must be 40, 80 or 160"); return ME_EINVAL;

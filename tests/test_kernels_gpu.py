@@ -447,7 +447,8 @@ def test_attention_cross_text_77_keys(ops, dh, nq):
 
 
 @pytest.mark.parametrize("dh,nq,nk,B,f,il", [(40, 4096, 77, 2, 3, False), (40, 1024, 77, 4, 2, True), (40, 600, 80, 2, 2, False), (40, 512, 65, 1, 2, False),
-                                             (80, 1024, 77, 2, 3, False), (80, 320, 70, 2, 2, True), (80, 256, 77, 4, 24, False)])
+                                             (80, 1024, 77, 2, 3, False), (80, 320, 70, 2, 2, True), (80, 256, 77, 4, 24, False),
+                                             (160, 256, 77, 4, 6, False), (160, 576, 77, 2, 3, True), (160, 300, 66, 2, 2, False)])
 def test_attention_keys_resident_across_query_blocks(ops, dh, nq, nk, B, f, il):
     """Round 6: the text cross-attention (attention_2d.py:343; one segment of 65 .. 80 keys) stages its K | V once per block, walks several query blocks over
     it and takes all five 16-key tiles of a query in one pass (attn2_kernel<..., KVRES>: plain softmax, no running rescale).  Against the fp32 reference and
